@@ -1,0 +1,551 @@
+/*
+ * mppi_oracle.c -- CPU restatement of the reference MPPI hot path (see mppi_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY: checker for tests/, smoke() and bench.py's
+ * cpu_baseline leg.  Never linked into or called from the product library.
+ *
+ * Parity: "unpinned" for rollout/cost/weighting/reduction (the reference has no
+ * fixtures and its CUDA cannot be built here); NN dynamics pinned by
+ * tests/golden/nn_dynamics_golden.npz; MRG32k3a pinned by published jump matrices.
+ *
+ * Build: gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp (oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: every fused multiply-add below is an explicit
+ * fmaf() placed where nvcc's default contraction would put one (fma_mode=1), and
+ * everything else must round exactly as written.
+ *
+ * Citations are relative to /root/reference/autorally_control/ ;
+ *   PI/ = include/autorally_control/path_integral/
+ */
+#include "mppi_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAX_WIDTH 512
+
+static inline float mac(float a, float b, float c, int fma_mode)
+{
+  if (fma_mode) return fmaf(a, b, c);
+  float p = a * b;
+  return p + c;
+}
+
+int orc_num_params(const int *layers, int n_layers)
+{
+  /* PI/meta_math.h:38-51 param_counter */
+  int n = 0;
+  for (int i = 0; i + 1 < n_layers; i++) n += (layers[i] + 1) * layers[i + 1];
+  return n;
+}
+
+/* PI/neural_net_model.cu:357-410.  k ascending, bias added after the dot product (:389-394). */
+void orc_nn_forward(const float *theta, const int *layers, int n_layers, const float *in,
+                    float *out, int fma_mode)
+{
+  float buf0[ORC_MAX_WIDTH], buf1[ORC_MAX_WIDTH];
+  float *cur = buf0, *nxt = buf1;
+  for (int i = 0; i < layers[0]; i++) cur[i] = in[i];
+  int off = 0;
+  for (int l = 0; l + 1 < n_layers; l++) {
+    const int nin = layers[l], nout = layers[l + 1];
+    const float *W = theta + off;            /* stride_idcs_[2l]   (:123) */
+    const float *b = theta + off + nout * nin; /* stride_idcs_[2l+1] (:131) */
+    for (int j = 0; j < nout; j++) {
+      float tmp = 0.0f;
+      for (int k = 0; k < nin; k++) tmp = mac(W[j * nin + k], cur[k], tmp, fma_mode);
+      tmp += b[j];
+      if (l < n_layers - 2) tmp = tanhf(tmp); /* MPPI_NNET_NONLINEARITY, :35 */
+      nxt[j] = tmp;
+    }
+    off += nout * nin + nout;
+    float *t = cur; cur = nxt; nxt = t;
+  }
+  for (int i = 0; i < layers[n_layers - 1]; i++) out[i] = cur[i];
+}
+
+/* computeKinematics (:346-355) + computeDynamics (:357-410) */
+void orc_state_deriv(const orc_problem *p, const float *s, const float *u, float *sd)
+{
+  const float c = cosf(s[2]), sn = sinf(s[2]);
+  if (p->fma_mode) {
+    sd[0] = fmaf(c, s[4], -(sn * s[5]));
+    sd[1] = fmaf(sn, s[4], c * s[5]);
+  } else {
+    float a = c * s[4], b = sn * s[5];
+    sd[0] = a - b;
+    a = sn * s[4]; b = c * s[5];
+    sd[1] = a + b;
+  }
+  sd[2] = p->negate_yaw_der ? -s[6] : s[6];
+  float in[6] = { s[3], s[4], s[5], s[6], u[0], u[1] };
+  float out[ORC_MAX_WIDTH];
+  orc_nn_forward(p->theta, p->layers, p->n_layers, in, out, p->fma_mode);
+  for (int i = 0; i < 4; i++) sd[3 + i] = out[i];
+}
+
+/* enforceConstraints, neural_net_model.cu:311-323 */
+static inline void clamp_controls(const orc_problem *p, float *u)
+{
+  for (int i = 0; i < ORC_CONTROL_DIM; i++) {
+    if (u[i] < p->u_lo[i]) u[i] = p->u_lo[i];
+    else if (u[i] > p->u_hi[i]) u[i] = p->u_hi[i];
+  }
+}
+
+/* incrementState, neural_net_model.cu:334-344 */
+static inline void increment_state(const orc_problem *p, float *s, const float *sd)
+{
+  for (int i = 0; i < ORC_STATE_DIM; i++) s[i] = mac(sd[i], p->dt, s[i], p->fma_mode);
+}
+
+void orc_update_state(const orc_problem *p, float *s, float *u)
+{
+  float sd[ORC_STATE_DIM];
+  clamp_controls(p, u);
+  orc_state_deriv(p, s, u, sd);
+  increment_state(p, s, sd);
+}
+
+/* point-sampled, clamped, normalised-coordinate float4 texture: costs.cu:128-154, 373, 377 */
+static inline float texel_x(const orc_problem *p, float x, float y)
+{
+  const orc_cost_params *P = &p->P;
+  /* coorTransform, costs.cu:351-357 */
+  float u, v, w;
+  if (p->fma_mode) {
+    u = fmaf(P->r_c1[0], x, P->r_c2[0] * y) + P->trs[0];
+    v = fmaf(P->r_c1[1], x, P->r_c2[1] * y) + P->trs[1];
+    w = fmaf(P->r_c1[2], x, P->r_c2[2] * y) + P->trs[2];
+  } else {
+    float a, b;
+    a = P->r_c1[0] * x; b = P->r_c2[0] * y; u = (a + b) + P->trs[0];
+    a = P->r_c1[1] * x; b = P->r_c2[1] * y; v = (a + b) + P->trs[1];
+    a = P->r_c1[2] * x; b = P->r_c2[2] * y; w = (a + b) + P->trs[2];
+  }
+  const float un = u / w, vn = v / w;
+  float fi = floorf(un * (float)p->map_w);
+  float fj = floorf(vn * (float)p->map_h);
+  if (!(fi >= 0.0f)) fi = 0.0f; /* also catches NaN */
+  if (!(fj >= 0.0f)) fj = 0.0f;
+  if (fi > (float)(p->map_w - 1)) fi = (float)(p->map_w - 1);
+  if (fj > (float)(p->map_h - 1)) fj = (float)(p->map_h - 1);
+  const int i = (int)fi, j = (int)fj;
+  return p->map_rgba[4 * ((size_t)j * (size_t)p->map_w + (size_t)i)];
+}
+
+/* costs.cu:396-409 and the helpers it calls (:307-393) */
+float orc_compute_cost(const orc_problem *p, const float *s, const float *u, const float *du,
+                       int *crash)
+{
+  const orc_cost_params *P = &p->P;
+  /* getControlCost :307-313 (u clamped, du unclamped) */
+  float control_cost = 0.0f;
+  control_cost += P->steering_coeff * du[0] * (u[0] - du[0]) / (p->nu[0] * p->nu[0]);
+  control_cost += P->throttle_coeff * du[1] * (u[1] - du[1]) / (p->nu[1] * p->nu[1]);
+
+  /* getTrackCost :359-393.  __cosf/__sinf (Q7) have no CPU equivalent; cosf/sinf used. */
+  const float cpsi = cosf(s[2]), spsi = sinf(s[2]);
+  const float x_front = mac(0.5f, cpsi, s[0], p->fma_mode);
+  const float y_front = mac(0.5f, spsi, s[1], p->fma_mode);
+  const float x_back = mac(-0.5f, cpsi, s[0], p->fma_mode);
+  const float y_back = mac(-0.5f, spsi, s[1], p->fma_mode);
+  const float tf = texel_x(p, x_front, y_front);
+  const float tb = texel_x(p, x_back, y_back);
+  float track_cost = (float)((double)(fabsf(tf) + fabsf(tb)) / 2.0);
+  if (fabsf(track_cost) < P->track_slop) track_cost = 0.0f;
+  else track_cost = P->track_coeff * track_cost;
+  if (tf >= P->boundary_threshold || tb >= P->boundary_threshold) crash[0] = 1;
+
+  /* getSpeedCost :315-326 */
+  const float err = s[4] - P->desired_speed;
+  const float speed_cost = P->speed_coeff * (P->l1_cost ? fabsf(err) : err * err);
+
+  /* (1.0 - params_.discount)*getCrashCost :402, :328-335 (double, Q6) */
+  const float crash_raw = (crash[0] > 0) ? P->crash_coeff : 0.0f;
+  const float crash_cost = (float)((1.0 - (double)P->discount) * (double)crash_raw);
+
+  /* getStabilizingCost :337-349 */
+  float stabilizing_cost = 0.0f;
+  if ((double)fabsf(s[4]) > 0.001) {
+    const float slip = -atanf(s[5] / fabsf(s[4]));
+    stabilizing_cost = P->slip_penalty * (slip * slip); /* powf(slip,2) */
+    if (fabsf(slip) > P->max_slip_ang) stabilizing_cost += P->crash_coeff;
+  }
+  float cost = control_cost + speed_cost + crash_cost + track_cost + stabilizing_cost;
+  if ((double)cost > 1e12 || isnan(cost)) cost = (float)1e12;
+  return cost;
+}
+
+static void rollout_one(const orc_problem *p, const float *state, const float *U, float *epsV,
+                        int k, float *cost_out, int *crash_out)
+{
+  const int T = p->T;
+  float s[ORC_STATE_DIM], sd[ORC_STATE_DIM], u[2], du[2];
+  int crash = 0;
+  float running_cost = 0.0f;
+  for (int i = 0; i < ORC_STATE_DIM; i++) s[i] = state[i];
+  const int pure_noise = ((double)k >= .99 * (double)p->K); /* mppi_controller.cu:141 */
+  for (int t = 0; t < T; t++) {
+    for (int j = 0; j < 2; j++) {
+      const size_t idx = (size_t)2 * T * k + 2 * t + j; /* :133 */
+      if (k == 0 || t < p->opt_delay) {
+        du[j] = 0.0f;
+        u[j] = U[2 * t + j];
+      } else if (pure_noise) {
+        du[j] = epsV[idx] * p->nu[j];
+        u[j] = du[j];
+      } else {
+        du[j] = epsV[idx] * p->nu[j];
+        u[j] = U[2 * t + j] + du[j];
+      }
+      epsV[idx] = u[j]; /* stored BEFORE the clamp (Q3), :153 */
+    }
+    clamp_controls(p, u);
+    if (t > 0) { /* crash[0] > -1 is always true (Q5) */
+      const float c = orc_compute_cost(p, s, u, du, &crash);
+      running_cost = (float)((double)running_cost + (double)(c - running_cost) / (1.0 * t));
+    }
+    orc_state_deriv(p, s, u, sd);
+    increment_state(p, s, sd);
+    if ((double)fabsf(s[3]) > 1.57) crash = 1; /* getCrash, costs.cu:301-305 */
+  }
+  *cost_out = running_cost + 0.0f; /* terminalCost = 0, costs.cu:411-414 */
+  if (crash_out) *crash_out = crash;
+}
+
+void orc_rollouts(const orc_problem *p, const float *state, const float *U, float *epsV,
+                  float *costs, int *crash_out)
+{
+  const int K = p->K;
+#ifdef _OPENMP
+  const int nt = p->nthreads > 1 ? p->nthreads : 1;
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
+#endif
+  for (int k = 0; k < K; k++)
+    rollout_one(p, state, U, epsV, k, &costs[k], crash_out ? &crash_out[k] : NULL);
+}
+
+void orc_weights(const float *costs, int K, float gamma, float *w, float *baseline_out,
+                 float *eta_out, float *traj_cost_out)
+{
+  /* mppi_controller.cu:627-632 */
+  float baseline = costs[0];
+  for (int i = 0; i < K; i++)
+    if (costs[i] < baseline) baseline = costs[i];
+  /* normExpKernel :193-203 */
+  for (int i = 0; i < K; i++) {
+    const float cost2go = costs[i] - baseline;
+    w[i] = expf(-gamma * cost2go);
+  }
+  /* :641-652, sequential fp32 sums (Q8) */
+  float eta = 0.0f;
+  for (int i = 0; i < K; i++) eta += w[i];
+  float tc = 0.0f;
+  for (int i = 0; i < K; i++) tc += w[i] * w[i] / eta;
+  if (baseline_out) *baseline_out = baseline;
+  if (eta_out) *eta_out = eta;
+  if (traj_cost_out) *traj_cost_out = tc;
+}
+
+void orc_weighted_reduction(const float *w, float eta, const float *V, int K, int T, float *Unew,
+                            int fma_mode)
+{
+  /* mppi_controller.cu:219-267: block t, thread m sums rollouts 64m..64m+63 in order,
+   * thread 0 sums the partials in order. */
+  const int nthr = (K - 1) / 64 + 1;
+  float *partial = (float *)malloc(sizeof(float) * 2 * (size_t)nthr);
+  for (int t = 0; t < T; t++) {
+    for (int m = 0; m < nthr; m++) {
+      float a0 = 0.0f, a1 = 0.0f;
+      for (int i = 0; i < 64; i++) {
+        const int k = 64 * m + i;
+        if (k < K) {
+          const float weight = w[k] / eta;
+          a0 = mac(weight, V[(size_t)k * 2 * T + 2 * t + 0], a0, fma_mode);
+          a1 = mac(weight, V[(size_t)k * 2 * T + 2 * t + 1], a1, fma_mode);
+        }
+      }
+      partial[2 * m] = a0;
+      partial[2 * m + 1] = a1;
+    }
+    float u0 = 0.0f, u1 = 0.0f;
+    for (int m = 0; m < nthr; m++) {
+      u0 += partial[2 * m];
+      u1 += partial[2 * m + 1];
+    }
+    Unew[2 * t] = u0;
+    Unew[2 * t + 1] = u1;
+  }
+  free(partial);
+}
+
+void orc_savgol(float *U, const float *hist, int T)
+{
+  /* mppi_controller.cu:468-499 */
+  const float coef[5] = { -3.0f, 12.0f, 17.0f, 12.0f, -3.0f };
+  float f[5];
+  for (int m = 0; m < 5; m++) f[m] = coef[m] / 35.0f;
+  float *X = (float *)malloc(sizeof(float) * 2 * (size_t)(T + 4));
+  for (int i = 0; i < T + 4; i++)
+    for (int j = 0; j < 2; j++) {
+      if (i < 2) X[2 * i + j] = hist[2 * i + j];
+      else if (i < T + 2) X[2 * i + j] = U[2 * (i - 2) + j];
+      else X[2 * i + j] = U[2 * (T - 1) + j];
+    }
+  for (int i = 0; i < T; i++)
+    for (int j = 0; j < 2; j++) {
+      float acc = f[0] * X[2 * i + j];
+      for (int m = 1; m < 5; m++) {
+        const float prod = f[m] * X[2 * (i + m) + j];
+        acc = acc + prod;
+      }
+      U[2 * i + j] = acc;
+    }
+  free(X);
+}
+
+void orc_nominal_traj(const orc_problem *p, const float *state, const float *U, float *state_seq,
+                      float *control_seq)
+{
+  /* mppi_controller.cu:501-519 */
+  float s[ORC_STATE_DIM], u[2];
+  for (int j = 0; j < ORC_STATE_DIM; j++) s[j] = state[j];
+  for (int i = 0; i < p->T; i++) {
+    for (int j = 0; j < ORC_STATE_DIM; j++) state_seq[i * ORC_STATE_DIM + j] = s[j];
+    u[0] = U[2 * i];
+    u[1] = U[2 * i + 1];
+    orc_update_state(p, s, u);
+    control_seq[2 * i] = u[0];
+    control_seq[2 * i + 1] = u[1];
+  }
+}
+
+void orc_slide_control_seq(float *U, float *hist, const float *init_u, int T, int stride)
+{
+  /* mppi_controller.cu:527-554 (flat-index quirk Q15 kept) */
+  if (stride == 1) {
+    hist[0] = hist[2];
+    hist[1] = hist[3];
+    hist[2] = U[0];
+    hist[3] = U[1];
+  } else {
+    const int t = stride - 2;
+    for (int i = 0; i < 4; i++) hist[i] = U[t + i];
+  }
+  for (int i = 0; i < T - stride; i++)
+    for (int j = 0; j < 2; j++) U[i * 2 + j] = U[(i + stride) * 2 + j];
+  for (int j = 1; j <= stride; j++)
+    for (int i = 0; i < 2; i++) U[(T - j) * 2 + i] = init_u[i];
+}
+
+void orc_compute_control(const orc_problem *p, int num_iters, const float *state, float *U,
+                         const float *hist, float *eps, float *traj_cost, float *costs_out,
+                         float *w_out)
+{
+  /* mppi_controller.cu:600-675 */
+  const int K = p->K, T = p->T;
+  float *costs = (float *)malloc(sizeof(float) * (size_t)K);
+  float *w = (float *)malloc(sizeof(float) * (size_t)K);
+  float eta = 0.0f, tc = 0.0f;
+  for (int it = 0; it < num_iters; it++) {
+    float *V = eps + (size_t)it * K * T * 2;
+    orc_rollouts(p, state, U, V, costs, NULL);
+    orc_weights(costs, K, p->gamma, w, NULL, &eta, &tc);
+    orc_weighted_reduction(w, eta, V, K, T, U, p->fma_mode);
+  }
+  orc_savgol(U, hist, T);
+  if (traj_cost) *traj_cost = tc;
+  if (costs_out) memcpy(costs_out, costs, sizeof(float) * (size_t)K);
+  if (w_out) memcpy(w_out, w, sizeof(float) * (size_t)K);
+  free(costs);
+  free(w);
+}
+
+/* ======================= noise generator spec =======================
+ * MRG32k3a (L'Ecuyer 1999, "Good parameters and implementations for combined
+ * multiple recursive random number generators"), one subsequence of 2^76 draws
+ * per rollout (the spacing cuRAND's MRG32k3a uses), draws turned into N(0,1)
+ * pairs with a Box-Muller transform written ONLY in IEEE basic operations so
+ * that the HIP generator reproduces it bit for bit.  Reference call sites being
+ * replaced: mppi_controller.cu:330-331, 612 (cuRAND XORWOW, not reproducible).
+ */
+#define M1 4294967087ULL
+#define M2 4294944443ULL
+#define A12 1403580ULL
+#define A13N 810728ULL
+#define A21 527612ULL
+#define A23N 1370589ULL
+
+static inline uint32_t mulmod(uint64_t a, uint64_t b, uint64_t m) { return (uint32_t)((a * b) % m); }
+
+void orc_mrg_seed(orc_mrg_state *st, uint64_t seed)
+{
+  for (int i = 0; i < 3; i++) { st->s1[i] = 12345u; st->s2[i] = 12345u; }
+  if (seed != 0) {
+    const uint32_t x1 = ((uint32_t)seed) ^ 0x55555555u;
+    const uint32_t x2 = (uint32_t)((seed >> 32) ^ 0xAAAAAAAAu);
+    st->s1[0] = mulmod(x1, st->s1[0], M1);
+    st->s1[1] = mulmod(x2, st->s1[1], M1);
+    st->s1[2] = mulmod(x1, st->s1[2], M1);
+    st->s2[0] = mulmod(x2, st->s2[0], M2);
+    st->s2[1] = mulmod(x1, st->s2[1], M2);
+    st->s2[2] = mulmod(x2, st->s2[2], M2);
+  }
+}
+
+uint32_t orc_mrg_next_z(orc_mrg_state *st)
+{
+  /* p1 = (a12*s1[1] - a13n*s1[0]) mod m1 ; p2 = (a21*s2[2] - a23n*s2[0]) mod m2 */
+  const uint64_t p1 = (A12 * st->s1[1] + (M1 - A13N) * st->s1[0]) % M1;
+  st->s1[0] = st->s1[1]; st->s1[1] = st->s1[2]; st->s1[2] = (uint32_t)p1;
+  const uint64_t p2 = (A21 * st->s2[2] + (M2 - A23N) * st->s2[0]) % M2;
+  st->s2[0] = st->s2[1]; st->s2[1] = st->s2[2]; st->s2[2] = (uint32_t)p2;
+  uint64_t z = (p1 >= p2) ? (p1 - p2) : (p1 + M1 - p2);
+  if (z == 0) z = M1;
+  return (uint32_t)z; /* in [1, m1] */
+}
+
+double orc_mrg_next_u01(orc_mrg_state *st)
+{
+  return (double)orc_mrg_next_z(st) * 2.328306549295727688e-10;
+}
+
+static void mat3_mul(const uint32_t *A, const uint32_t *B, uint32_t *C, uint64_t m)
+{
+  uint32_t R[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      uint64_t acc = 0;
+      for (int k = 0; k < 3; k++) acc = (acc + (uint64_t)A[3 * i + k] * B[3 * k + j] % m) % m;
+      R[3 * i + j] = (uint32_t)acc;
+    }
+  memcpy(C, R, sizeof(R));
+}
+
+static void mat3_vec(const uint32_t *A, uint32_t *v, uint64_t m)
+{
+  uint32_t r[3];
+  for (int i = 0; i < 3; i++) {
+    uint64_t acc = 0;
+    for (int k = 0; k < 3; k++) acc = (acc + (uint64_t)A[3 * i + k] * v[k] % m) % m;
+    r[i] = (uint32_t)acc;
+  }
+  memcpy(v, r, sizeof(r));
+}
+
+static void base_matrices(uint32_t *A1, uint32_t *A2)
+{
+  const uint32_t a1[9] = { 0, 1, 0, 0, 0, 1, (uint32_t)(M1 - A13N), (uint32_t)A12, 0 };
+  const uint32_t a2[9] = { 0, 1, 0, 0, 0, 1, (uint32_t)(M2 - A23N), 0, (uint32_t)A21 };
+  memcpy(A1, a1, sizeof(a1));
+  memcpy(A2, a2, sizeof(a2));
+}
+
+void orc_mrg_jump_matrices(int e, uint32_t A1[9], uint32_t A2[9])
+{
+  base_matrices(A1, A2);
+  for (int i = 0; i < e; i++) {
+    mat3_mul(A1, A1, A1, M1);
+    mat3_mul(A2, A2, A2, M2);
+  }
+}
+
+/* advance by n * 2^e draws */
+static void skip_pow2(orc_mrg_state *st, uint64_t n, int e)
+{
+  uint32_t A1[9], A2[9];
+  orc_mrg_jump_matrices(e, A1, A2);
+  while (n) {
+    if (n & 1) { mat3_vec(A1, st->s1, M1); mat3_vec(A2, st->s2, M2); }
+    mat3_mul(A1, A1, A1, M1);
+    mat3_mul(A2, A2, A2, M2);
+    n >>= 1;
+  }
+}
+
+void orc_mrg_skip_subsequences(orc_mrg_state *st, uint64_t n) { skip_pow2(st, n, 76); }
+void orc_mrg_skip(orc_mrg_state *st, uint64_t n) { skip_pow2(st, n, 0); }
+
+/* log(x) for normal positive x; fdlibm e_logf algorithm, evaluated exactly as written. */
+static float spec_logf(float x)
+{
+  const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+  const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f,
+              Lg4 = 0.24279078841f;
+  uint32_t ix;
+  memcpy(&ix, &x, 4);
+  ix += 0x3f800000u - 0x3f3504f3u;
+  const int k = (int)(ix >> 23) - 0x7f;
+  ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+  memcpy(&x, &ix, 4);
+  const float f = x - 1.0f;
+  const float s = f / (2.0f + f);
+  const float z = s * s;
+  const float w = z * z;
+  const float t1 = w * (Lg2 + w * Lg4);
+  const float t2 = z * (Lg1 + w * Lg3);
+  const float R = t2 + t1;
+  const float hfsq = (0.5f * f) * f;
+  const float dk = (float)k;
+  return (((s * (hfsq + R) + dk * ln2_lo) - hfsq) + f) + dk * ln2_hi;
+}
+
+/* sin(2*pi*v), cos(2*pi*v) for v in (0,1]; octant reduction + fdlibm k_sinf/k_cosf polynomials. */
+static void spec_sincos2pi(float v, float *sn, float *cs)
+{
+  const float S1 = -0.16666667163f, S2 = 0.0083333291113f, S3 = -0.00019839334709f,
+              S4 = 2.7183114e-06f;
+  const float C0 = -0.5f, C1 = 0.041666623205f, C2 = -0.0013886763947f, C3 = 2.4390449e-05f;
+  const float x = v - 0.5f;
+  const float kq = rintf(x * 4.0f);
+  const float y = x - kq * 0.25f;
+  const float a = y * 6.2831853071795864769f;
+  const float a2 = a * a;
+  const float ps = S1 + a2 * (S2 + a2 * (S3 + a2 * S4));
+  const float sin_a = a + (a * a2) * ps;
+  const float pc = C0 + a2 * (C1 + a2 * (C2 + a2 * C3));
+  const float cos_a = 1.0f + a2 * pc;
+  const int q = ((int)kq) & 3;
+  float s2, c2; /* sin/cos of 2*pi*x */
+  switch (q) {
+    case 0: s2 = sin_a; c2 = cos_a; break;
+    case 1: s2 = cos_a; c2 = -sin_a; break;
+    case 2: s2 = -sin_a; c2 = -cos_a; break;
+    default: s2 = -cos_a; c2 = sin_a; break;
+  }
+  *sn = -s2; /* v = x + 1/2 */
+  *cs = -c2;
+}
+
+void orc_box_muller(float u1, float u2, float *n0, float *n1)
+{
+  const float r = sqrtf(-2.0f * spec_logf(u1));
+  float sn, cs;
+  spec_sincos2pi(u2, &sn, &cs);
+  *n0 = r * sn;
+  *n1 = r * cs;
+}
+
+void orc_generate_noise(uint64_t seed, uint64_t offset, int K, int T, float *eps)
+{
+  orc_mrg_state base;
+  orc_mrg_seed(&base, seed);
+  uint32_t A1[9], A2[9];
+  orc_mrg_jump_matrices(76, A1, A2);
+  orc_mrg_state sub = base; /* subsequence k: base advanced by k*2^76 */
+  for (int k = 0; k < K; k++) {
+    orc_mrg_state st = sub;
+    orc_mrg_skip(&st, offset);
+    for (int t = 0; t < T; t++) {
+      const float u1 = (float)orc_mrg_next_z(&st) * 0x1p-32f;
+      const float u2 = (float)orc_mrg_next_z(&st) * 0x1p-32f;
+      orc_box_muller(u1, u2, &eps[(size_t)k * 2 * T + 2 * t], &eps[(size_t)k * 2 * T + 2 * t + 1]);
+    }
+    mat3_vec(A1, sub.s1, M1);
+    mat3_vec(A2, sub.s2, M2);
+  }
+}

@@ -1,0 +1,128 @@
+"""Pins the CPU oracle's NN dynamics step against outputs of the reference's own
+Python restatement (tests/golden/gen_golden.py, scripts/ml_pipeline/utils.py) and its
+RNG against L'Ecuyer's published MRG32k3a constants."""
+import os
+
+import numpy as np
+import pytest
+
+from autorally_amd import params as P
+from autorally_amd import synthetic as S
+from oracle import oracle as O
+
+MODELS = ["autorally_nnet_09_12_2018", "gazebo_nnet_09_12_2018", "shallow_network_08_20_2020",
+          "wider_deeper_network_08_20_2020"]
+
+
+def _oracle_for(golden_dir, name, g, fma_mode):
+    layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", name + ".npz"))
+    assert layers == list(g[name + "/layers"])
+    cfg = S.make_config(64, 10, layers=layers, theta=theta,
+                        negate_yaw_der=bool(g[name + "/negate_yaw_der"][0]))
+    return O.Oracle(cfg, fma_mode=fma_mode)
+
+
+def test_num_params(golden_dir):
+    # NUM_PARAMS = 1412 for 6-32-32-4, 4868 for 6-64-64-4
+    for layers, n in (([6, 32, 32, 4], 1412), ([6, 64, 64, 4], 4868)):
+        _, theta = P.synthetic_model(layers)
+        assert theta.size == n
+    layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", MODELS[0] + ".npz"))
+    assert layers == [6, 32, 32, 4] and theta.size == 1412
+
+
+def test_sample_from_survey(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    orc = _oracle_for(golden_dir, MODELS[0], g, 1)
+    out = orc.nn_forward(g["sample_in"])
+    np.testing.assert_allclose(out, g["sample_out"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(g["sample_out"], [-0.15874888, 5.03792211, -0.46054682, -0.24567117],
+                               atol=1e-8)
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("fma_mode", [0, 1])
+def test_state_deriv_matches_reference_python(golden_dir, name, fma_mode):
+    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    orc = _oracle_for(golden_dir, name, g, fma_mode)
+    states, ctrls, ders = g[name + "/states"], g[name + "/controls"], g[name + "/state_ders"]
+    worst = 0.0
+    for s, u, d in zip(states, ctrls, ders):
+        sd = orc.state_deriv(s, u)
+        scale = np.maximum(1.0, np.abs(d))
+        worst = max(worst, float(np.max(np.abs(sd - d) / scale)))
+    # fp32 oracle vs fp64 reference: tolerance 1e-5
+    assert worst < 1e-5, worst
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_open_loop_trajectory(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    orc = _oracle_for(golden_dir, name, g, 1)
+    traj, tctrl = g[name + "/traj_states"], g[name + "/traj_controls"]
+    s = traj[0].astype(np.float32)
+    for i in range(10):
+        s, _ = orc.update_state(s, tctrl[i])
+        np.testing.assert_allclose(s, traj[i + 1], atol=2e-5, rtol=1e-5)
+
+
+def test_fma_and_nofma_variants_agree(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    a = _oracle_for(golden_dir, MODELS[0], g, 0)
+    b = _oracle_for(golden_dir, MODELS[0], g, 1)
+    for s, u in zip(g[MODELS[0] + "/states"], g[MODELS[0] + "/controls"]):
+        np.testing.assert_allclose(a.state_deriv(s, u), b.state_deriv(s, u), atol=2e-5, rtol=1e-5)
+
+
+# ---------------- MRG32k3a known answers ----------------
+# L'Ecuyer, Simard, Chen, Kelton, "An object-oriented random-number package with many long
+# streams and substreams" (RngStreams): A1p76, A2p76, A1p127, A2p127.
+A1P76 = [[82758667, 1871391091, 4127413238], [3672831523, 69195019, 1871391091],
+         [3672091415, 3528743235, 69195019]]
+A2P76 = [[1511326704, 3759209742, 1610795712], [4292754251, 1511326704, 3889917532],
+         [3859662829, 4292754251, 3708466080]]
+A1P127 = [[2427906178, 3580155704, 949770784], [226153695, 1230515664, 3580155704],
+          [1988835001, 986791581, 1230515664]]
+A2P127 = [[1464411153, 277697599, 1610723613], [32183930, 1464411153, 1022607788],
+          [2824425944, 32183930, 2093834863]]
+
+
+def test_mrg32k3a_published_jump_matrices():
+    a1, a2 = O.jump_matrices(76)
+    assert a1.tolist() == A1P76 and a2.tolist() == A2P76
+    a1, a2 = O.jump_matrices(127)
+    assert a1.tolist() == A1P127 and a2.tolist() == A2P127
+
+
+def test_mrg32k3a_first_outputs_and_skip():
+    import ctypes as C
+    L = O.lib()
+    st = O.MrgState()
+    L.orc_mrg_seed(C.byref(st), 0)  # seed 0 = L'Ecuyer's default state 12345 x 6
+    assert list(st.s1) == [12345] * 3 and list(st.s2) == [12345] * 3
+    u = [L.orc_mrg_next_u01(C.byref(st)) for _ in range(4)]
+    # RngStreams' first stream starts 0.12701112, 0.31852757, 0.30918602, 0.82584686
+    np.testing.assert_allclose(u, [0.1270111220, 0.3185275654, 0.3091860156, 0.8258468629], atol=5e-10)
+    # skip(n) == n single steps
+    a, b = O.MrgState(), O.MrgState()
+    L.orc_mrg_seed(C.byref(a), 1234)
+    L.orc_mrg_seed(C.byref(b), 1234)
+    for _ in range(1000):
+        L.orc_mrg_next_z(C.byref(a))
+    L.orc_mrg_skip(C.byref(b), 1000)
+    assert list(a.s1) == list(b.s1) and list(a.s2) == list(b.s2)
+
+
+def test_noise_moments_and_layout():
+    K, T = 256, 50
+    e = O.generate_noise(1234, 0, K, T)
+    assert e.shape == (K, T, 2) and np.all(np.isfinite(e))
+    assert abs(e.mean()) < 0.02 and abs(e.std() - 1.0) < 0.02
+    assert abs(np.mean(e ** 3)) < 0.05 and abs(np.mean(e ** 4) - 3.0) < 0.15
+    # offset continues the per-rollout stream: draws [2T, 4T) of each subsequence
+    e2 = O.generate_noise(1234, 2 * T, K, T)
+    e_long = O.generate_noise(1234, 0, K, 2 * T)
+    np.testing.assert_array_equal(e_long[:, T:, :], e2)
+    np.testing.assert_array_equal(e_long[:, :T, :], e)
+    # different rollouts use different subsequences
+    assert not np.array_equal(e[0], e[1])
