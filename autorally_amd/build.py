@@ -1,0 +1,68 @@
+"""Builds libmppi_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this also is the "does it build" check run on CPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmppi_hip.so")
+SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_valu.hip", "solve_kernels.hip",
+           "noise_mrg32k3a.hip"]
+HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
+# -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
+         "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    cc = hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn:
+                print(warn, file=sys.stderr)
+    if jobs or force or _stale(LIB, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,320 @@
+"""ctypes binding of libmppi_hip.so (include/mppi_hip.h) -- plumbing for tests and bench.py.
+
+The product is the shared library; this module only marshals numpy arrays across the C ABI.
+It never computes anything itself and has no CPU fallback: if the library is missing or no
+gfx950 device is usable, it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmppi_hip.so")
+MAX_LAYERS = 8
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(6)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int),
+        ("num_rollouts", C.c_int),
+        ("num_timesteps", C.c_int),
+        ("hz", C.c_int),
+        ("optimization_stride", C.c_int),
+        ("gamma", C.c_float),
+        ("num_iters", C.c_int),
+        ("n_layers", C.c_int),
+        ("layers", C.c_int * MAX_LAYERS),
+        ("exploration_std", C.c_float * 2),
+        ("init_control", C.c_float * 2),
+        ("control_min", C.c_float * 2),
+        ("control_max", C.c_float * 2),
+        ("negate_yaw_der", C.c_int),
+        ("seed", C.c_uint64),
+    ]
+
+
+class CostParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "desired_speed", "speed_coeff", "track_coeff", "max_slip_ang", "slip_penalty", "track_slop",
+        "crash_coeff", "steering_coeff", "throttle_coeff", "boundary_threshold", "discount")] + [
+        ("l1_cost", C.c_int)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("n_solves", C.c_int), ("noise_ms", C.c_float), ("rollout_ms", C.c_float),
+                ("weights_ms", C.c_float), ("reduction_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+# every symbol include/mppi_hip.h declares
+SYMBOLS = [
+    "mppi_abi_version", "mppi_strerror", "mppi_last_error", "mppi_device_count", "mppi_create",
+    "mppi_destroy", "mppi_set_nn_params", "mppi_update_model", "mppi_set_control_limits",
+    "mppi_set_costmap", "mppi_set_costmap_channel", "mppi_set_cost_params", "mppi_reset_controls",
+    "mppi_set_control_seq", "mppi_get_control_seq", "mppi_set_control_hist", "mppi_get_control_hist",
+    "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
+    "mppi_compute_control", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
+    "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
+    "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
+    "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
+]
+
+_lib = None
+
+
+class MppiError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("mppi status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib():
+    """Loads libmppi_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmppi_hip.so is missing: run `python -m autorally_amd.build` "
+                               "or __graft_entry__.build() first")
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        hp = C.c_void_p
+        L.mppi_abi_version.restype = C.c_int
+        L.mppi_strerror.restype = C.c_char_p
+        L.mppi_strerror.argtypes = [C.c_int]
+        L.mppi_last_error.restype = C.c_char_p
+        L.mppi_last_error.argtypes = [hp]
+        L.mppi_device_count.restype = C.c_int
+        L.mppi_create.argtypes = [C.POINTER(Config), C.POINTER(hp)]
+        L.mppi_destroy.argtypes = [hp]
+        L.mppi_set_nn_params.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_update_model.argtypes = [hp, C.POINTER(C.c_int), C.c_int, fp, C.c_size_t]
+        L.mppi_set_control_limits.argtypes = [hp, fp, fp]
+        L.mppi_set_costmap.argtypes = [hp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.mppi_set_costmap_channel.argtypes = [hp, C.c_int, fp, C.c_size_t]
+        L.mppi_set_cost_params.argtypes = [hp, C.POINTER(CostParams)]
+        L.mppi_reset_controls.argtypes = [hp]
+        L.mppi_set_control_seq.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_get_control_seq.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_set_control_hist.argtypes = [hp, fp]
+        L.mppi_get_control_hist.argtypes = [hp, fp]
+        L.mppi_slide_control_seq.argtypes = [hp, C.c_int]
+        L.mppi_seed.argtypes = [hp, C.c_uint64, C.c_uint64]
+        L.mppi_set_noise.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_generate_noise.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_compute_control.argtypes = [hp, fp]
+        L.mppi_compute_control_async.argtypes = [hp, fp]
+        L.mppi_synchronize.argtypes = [hp]
+        L.mppi_get_results.argtypes = [hp, fp, fp, fp, fp]
+        L.mppi_get_applied_controls.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_rollout_only.argtypes = [hp, fp, fp]
+        L.mppi_nominal_traj.argtypes = [hp, fp, fp, fp]
+        L.mppi_enable_stage_timing.argtypes = [hp, C.c_int]
+        L.mppi_reset_stage_times.argtypes = [hp]
+        L.mppi_get_stage_times.argtypes = [hp, C.POINTER(StageTimes)]
+        L.mppi_rollout_variant.restype = C.c_char_p
+        L.mppi_rollout_variant.argtypes = [hp]
+        L.mppi_set_rollout_variant.argtypes = [hp, C.c_char_p]
+        L.mppi_debug_dynamics.argtypes = [hp, C.c_int, fp, fp, fp]
+        for s in SYMBOLS:
+            fn = getattr(L, s)
+            if fn.restype is C.c_int and s not in ("mppi_abi_version", "mppi_device_count"):
+                pass
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def make_config_struct(cfg, device=0):
+    c = Config()
+    c.device = int(device)
+    c.num_rollouts = int(cfg["K"])
+    c.num_timesteps = int(cfg["T"])
+    c.hz = int(cfg["hz"])
+    c.optimization_stride = int(cfg["opt_stride"])
+    c.gamma = float(cfg["gamma"])
+    c.num_iters = int(cfg.get("num_iters", 1))
+    layers = [int(x) for x in cfg["layers"]]
+    c.n_layers = len(layers)
+    for i, v in enumerate(layers):
+        c.layers[i] = v
+    for i in range(2):
+        c.exploration_std[i] = float(cfg["nu"][i])
+        c.init_control[i] = float(cfg["init_u"][i])
+        c.control_min[i] = float(cfg["u_lo"][i])
+        c.control_max[i] = float(cfg["u_hi"][i])
+    c.negate_yaw_der = int(bool(cfg["negate_yaw_der"]))
+    c.seed = int(cfg.get("seed", 1234))
+    return c
+
+
+def make_cost_struct(cost):
+    p = CostParams()
+    for n, _ in CostParams._fields_[:-1]:
+        setattr(p, n, float(cost[n]))
+    p.l1_cost = int(bool(cost.get("l1_cost", False)))
+    return p
+
+
+class Solver:
+    """One mppi_handle: a thin object wrapper over the C ABI (method names follow the ABI)."""
+
+    def __init__(self, cfg, device=0):
+        self.L = lib()
+        self.cfg = cfg
+        self.K, self.T = int(cfg["K"]), int(cfg["T"])
+        self.num_iters = int(cfg.get("num_iters", 1))
+        self.h = C.c_void_p()
+        c = make_config_struct(cfg, device)
+        rc = self.L.mppi_create(C.byref(c), C.byref(self.h))
+        if rc != OK:
+            self.h = C.c_void_p()
+            raise MppiError(rc, self.L.mppi_strerror(rc).decode())
+        theta = _f32(cfg["theta"])
+        self._ck(self.L.mppi_set_nn_params(self.h, _fp(theta), theta.size))
+        m = _f32(cfg["map_rgba"])
+        H, W = m.shape[0], m.shape[1]
+        self._ck(self.L.mppi_set_costmap(self.h, W, H, _fp(m), _fp(_f32(cfg["r_c1"])),
+                                         _fp(_f32(cfg["r_c2"])), _fp(_f32(cfg["trs"]))))
+        p = make_cost_struct(cfg["cost"])
+        self._ck(self.L.mppi_set_cost_params(self.h, C.byref(p)))
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise MppiError(rc, "%s (%s)" % (self.L.mppi_strerror(rc).decode(),
+                                             self.L.mppi_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.L.mppi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- setters / getters ---
+    def set_cost_params(self, cost):
+        p = make_cost_struct(cost)
+        self._ck(self.L.mppi_set_cost_params(self.h, C.byref(p)))
+
+    def set_control_limits(self, lo, hi):
+        self._ck(self.L.mppi_set_control_limits(self.h, _fp(_f32(lo)), _fp(_f32(hi))))
+
+    def set_control_seq(self, U):
+        U = _f32(U)
+        self._ck(self.L.mppi_set_control_seq(self.h, _fp(U), U.size))
+
+    def get_control_seq(self):
+        U = np.zeros((self.T, 2), dtype=np.float32)
+        self._ck(self.L.mppi_get_control_seq(self.h, _fp(U), U.size))
+        return U
+
+    def reset_controls(self):
+        self._ck(self.L.mppi_reset_controls(self.h))
+
+    def set_control_hist(self, hist):
+        self._ck(self.L.mppi_set_control_hist(self.h, _fp(_f32(hist, (4,)))))
+
+    def get_control_hist(self):
+        h = np.zeros(4, dtype=np.float32)
+        self._ck(self.L.mppi_get_control_hist(self.h, _fp(h)))
+        return h
+
+    def slide_control_seq(self, stride):
+        self._ck(self.L.mppi_slide_control_seq(self.h, int(stride)))
+
+    def seed(self, seed, offset=0):
+        self._ck(self.L.mppi_seed(self.h, int(seed), int(offset)))
+
+    def set_noise(self, eps):
+        eps = _f32(eps)
+        self._ck(self.L.mppi_set_noise(self.h, _fp(eps), eps.size))
+
+    def generate_noise(self):
+        e = np.zeros((self.K, self.T, 2), dtype=np.float32)
+        self._ck(self.L.mppi_generate_noise(self.h, _fp(e), e.size))
+        return e
+
+    def update_model(self, description, data):
+        d = (C.c_int * len(description))(*[int(x) for x in description])
+        data = _f32(data)
+        self._ck(self.L.mppi_update_model(self.h, d, len(description), _fp(data), data.size))
+
+    def set_costmap_channel(self, channel, data):
+        data = _f32(data)
+        self._ck(self.L.mppi_set_costmap_channel(self.h, int(channel), _fp(data), data.size))
+
+    # --- compute ---
+    def compute_control(self, state):
+        self._ck(self.L.mppi_compute_control(self.h, _fp(_f32(state, (7,)))))
+
+    def compute_control_async(self, state):
+        self._ck(self.L.mppi_compute_control_async(self.h, _fp(_f32(state, (7,)))))
+
+    def synchronize(self):
+        self._ck(self.L.mppi_synchronize(self.h))
+
+    def get_results(self, with_vectors=True):
+        U = np.zeros((self.T, 2), dtype=np.float32)
+        tc = C.c_float()
+        costs = np.zeros(self.K, dtype=np.float32) if with_vectors else None
+        w = np.zeros(self.K, dtype=np.float32) if with_vectors else None
+        self._ck(self.L.mppi_get_results(self.h, _fp(U), C.byref(tc),
+                                         _fp(costs) if with_vectors else None,
+                                         _fp(w) if with_vectors else None))
+        return dict(U=U, traj_cost=tc.value, costs=costs, w=w)
+
+    def get_applied_controls(self):
+        V = np.zeros((self.K, self.T, 2), dtype=np.float32)
+        self._ck(self.L.mppi_get_applied_controls(self.h, _fp(V), V.size))
+        return V
+
+    def rollout_only(self, state):
+        costs = np.zeros(self.K, dtype=np.float32)
+        self._ck(self.L.mppi_rollout_only(self.h, _fp(_f32(state, (7,))), _fp(costs)))
+        return costs
+
+    def nominal_traj(self, state):
+        ss = np.zeros((self.T, 7), dtype=np.float32)
+        cs = np.zeros((self.T, 2), dtype=np.float32)
+        self._ck(self.L.mppi_nominal_traj(self.h, _fp(_f32(state, (7,))), _fp(ss), _fp(cs)))
+        return ss, cs
+
+    def debug_dynamics(self, states, controls):
+        states = _f32(states).reshape(-1, 7)
+        controls = _f32(controls).reshape(-1, 2)
+        out = np.zeros_like(states)
+        self._ck(self.L.mppi_debug_dynamics(self.h, states.shape[0], _fp(states), _fp(controls), _fp(out)))
+        return out
+
+    # --- measurement ---
+    def enable_stage_timing(self, on=True):
+        self._ck(self.L.mppi_enable_stage_timing(self.h, int(on)))
+
+    def reset_stage_times(self):
+        self._ck(self.L.mppi_reset_stage_times(self.h))
+
+    def get_stage_times(self):
+        st = StageTimes()
+        self._ck(self.L.mppi_get_stage_times(self.h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in StageTimes._fields_}
+
+    def rollout_variant(self):
+        return self.L.mppi_rollout_variant(self.h).decode()
+
+    def set_rollout_variant(self, name):
+        self._ck(self.L.mppi_set_rollout_variant(self.h, name.encode()))

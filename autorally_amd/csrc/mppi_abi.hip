@@ -1,0 +1,972 @@
+// mppi_abi.hip -- host side of libmppi_hip.so: the C ABI of include/mppi_hip.h.
+//
+// Owns one HIP stream and all device memory of a solver instance, enqueues one MPPI solve
+// (PI/mppi_controller.cu:600-671) as: [H2D U|hist] -> noise -> rollout -> weights -> weighted
+// reduction -> Savitzky-Golay -> [D2H scal|U], with ONE stream synchronisation per solve (the
+// reference has three plus five blocking parameter uploads).
+// There is no CPU fallback anywhere in this file: without a gfx950 device every compute entry
+// point returns an error.
+#include "../../include/mppi_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mppi_kernels.hpp"
+
+using namespace mppi;
+
+namespace {
+
+constexpr uint64_t M1 = 4294967087ULL, M2 = 4294944443ULL;
+
+struct Mat3 {
+  uint32_t a[9];
+};
+Mat3 mat_mul(const Mat3 &A, const Mat3 &B, uint64_t m)
+{
+  Mat3 R;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      uint64_t acc = 0;
+      for (int k = 0; k < 3; k++) acc = (acc + (uint64_t)A.a[3 * i + k] * B.a[3 * k + j] % m) % m;
+      R.a[3 * i + j] = (uint32_t)acc;
+    }
+  return R;
+}
+Mat3 mat_identity()
+{
+  Mat3 R{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  return R;
+}
+Mat3 mat_pow(Mat3 A, uint64_t e, uint64_t m)
+{
+  Mat3 R = mat_identity();
+  while (e) {
+    if (e & 1) R = mat_mul(R, A, m);
+    A = mat_mul(A, A, m);
+    e >>= 1;
+  }
+  return R;
+}
+Mat3 base_A1() { return Mat3{{0, 1, 0, 0, 0, 1, (uint32_t)(M1 - 810728ULL), 1403580u, 0}}; }
+Mat3 base_A2() { return Mat3{{0, 1, 0, 0, 0, 1, (uint32_t)(M2 - 1370589ULL), 0, 527612u}}; }
+
+struct Events {
+  hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+}  // namespace
+
+struct mppi_handle {
+  mppi_config cfg{};
+  int K = 0, T = 0;
+  float dt = 0.0f;
+  NetDesc net{};
+  bool mfma_ok = false;
+  int hidden = 0, n_hidden = 0;
+  int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
+  int block_threads = 64;
+  hipStream_t stream = nullptr;
+
+  std::vector<float> U, hist, theta, map_rgba;
+  int map_w = 0, map_h = 0;
+  mppi_cost_params cost{};
+  float r_c1[3] = {0, 0, 0}, r_c2[3] = {0, 0, 0}, trs[3] = {0, 0, 1};
+  float u_lo[2] = {0, 0}, u_hi[2] = {0, 0};
+  bool have_nn = false, have_map = false, have_cost = false;
+
+  float *d_in = nullptr, *d_res = nullptr, *d_scal = nullptr;
+  float *d_noise = nullptr, *d_stage = nullptr;
+  float *d_costs = nullptr, *d_w = nullptr, *d_wn = nullptr;
+  float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
+  uint32_t *d_rng[2] = {nullptr, nullptr};
+  uint32_t *d_jump = nullptr, *d_sub = nullptr, *d_one = nullptr;
+  int rng_cur = 0;
+  int noise_L = 1, noise_C = 1;
+  float *h_in = nullptr, *h_res = nullptr;
+  int explicit_iters = 0;  // >0: d_noise holds that many explicit iterations for the next solve
+  int last_noise_slot = 0;
+  bool pending = false;       // a solve is enqueued, results not yet collected
+  bool pending_timed = false;
+  float traj_cost = 0.0f, baseline = 0.0f, eta = 0.0f;
+
+  bool timing = false;
+  std::vector<Events> ev;  // one set per iteration
+  mppi_stage_times acc{};
+  std::string err;
+};
+
+namespace {
+
+int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess)
+{
+  if (h) {
+    h->err = what;
+    if (e != hipSuccess) {
+      h->err += ": ";
+      h->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIPCHK(h, call)                                                  \
+  do {                                                                   \
+    hipError_t e__ = (call);                                             \
+    if (e__ != hipSuccess) return fail((h), MPPI_ERR_HIP, #call, e__);   \
+  } while (0)
+
+int compute_k99(int K)
+{
+  // smallest k with (double)k >= .99*NUM_ROLLOUTS, mppi_controller.cu:141
+  const double thr = .99 * (double)K;
+  int k = 0;
+  while (k < K && !((double)k >= thr)) k++;
+  return k;
+}
+
+// A-operand / bias register image for rollout_mfma.hip (see the mapping comment there).
+std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int NHID)
+{
+  const int MT = H / 16, KSH = H / 4;
+  const int nA0 = MT * 2, nAH = MT * KSH, nAL = KSH;
+  const int nA = nA0 + (NHID - 1) * nAH + nAL;
+  const int nBias = NHID * MT * 4 + 4;
+  std::vector<float> out((size_t)(nA + nBias) * 64, 0.0f);
+  // offsets of W_l / b_l in theta, layers = 6, H x NHID, 4
+  std::vector<int> wo, bo, nin, nout;
+  int off = 0, prev = kNetIn;
+  for (int l = 0; l <= NHID; l++) {
+    const int no = (l < NHID) ? H : kNetOut;
+    wo.push_back(off);
+    bo.push_back(off + no * prev);
+    nin.push_back(prev);
+    nout.push_back(no);
+    off += no * prev + no;
+    prev = no;
+  }
+  for (int lane = 0; lane < 64; lane++) {
+    const int row = lane & 15, kk = lane >> 4;  // A operand: A[row][k = kk]
+    const int gq = row >> 2, rq = row & 3;
+    // layer 0
+    for (int m = 0; m < MT; m++)
+      for (int s = 0; s < 2; s++) {
+        const int n = 16 * m + 4 * rq + gq, kap = 4 * s + kk;
+        out[(size_t)(m * 2 + s) * 64 + lane] = (kap < kNetIn) ? theta[wo[0] + n * kNetIn + kap] : 0.0f;
+      }
+    for (int l = 1; l < NHID; l++) {
+      const int aoff = nA0 + (l - 1) * nAH;
+      for (int m = 0; m < MT; m++)
+        for (int s = 0; s < KSH; s++) {
+          const int n = 16 * m + 4 * rq + gq, kap = 4 * s + kk;
+          out[(size_t)(aoff + m * KSH + s) * 64 + lane] = theta[wo[l] + n * H + kap];
+        }
+    }
+    {
+      const int aoff = nA0 + (NHID - 1) * nAH;
+      for (int s = 0; s < KSH; s++) {
+        const int o = row & 3, kap = 4 * s + kk;
+        out[(size_t)(aoff + s) * 64 + lane] = theta[wo[NHID] + o * H + kap];
+      }
+    }
+    // biases: lane (j, g) register (m, r) holds D row 16m+4g+r = neuron 16m+4r+g
+    const int g = lane >> 4;
+    for (int l = 0; l < NHID; l++)
+      for (int m = 0; m < MT; m++)
+        for (int r = 0; r < 4; r++)
+          out[(size_t)(nA + l * MT * 4 + m * 4 + r) * 64 + lane] = theta[bo[l] + 16 * m + 4 * r + g];
+    for (int r = 0; r < 4; r++) out[(size_t)(nA + NHID * MT * 4 + r) * 64 + lane] = theta[bo[NHID] + r];
+  }
+  return out;
+}
+
+bool use_mfma(const mppi_handle *h)
+{
+  if (h->variant_pref == 2) return false;
+  return h->mfma_ok;
+}
+
+void fill_cost_args(const mppi_handle *h, CostArgs &c)
+{
+  const mppi_cost_params &p = h->cost;
+  c.desired_speed = p.desired_speed;
+  c.speed_coeff = p.speed_coeff;
+  c.track_coeff = p.track_coeff;
+  c.max_slip_ang = p.max_slip_ang;
+  c.slip_penalty = p.slip_penalty;
+  c.track_slop = p.track_slop;
+  c.crash_coeff = p.crash_coeff;
+  c.steering_coeff = p.steering_coeff;
+  c.throttle_coeff = p.throttle_coeff;
+  c.boundary_threshold = p.boundary_threshold;
+  c.crash_cost_discounted = (float)((1.0 - (double)p.discount) * (double)p.crash_coeff);
+  c.l1_cost = p.l1_cost ? 1 : 0;
+  for (int i = 0; i < 3; i++) {
+    c.r_c1[i] = h->r_c1[i];
+    c.r_c2[i] = h->r_c2[i];
+    c.trs[i] = h->trs[i];
+  }
+  c.affine = (h->r_c1[2] == 0.0f && h->r_c2[2] == 0.0f && h->trs[2] == 1.0f) ? 1 : 0;
+  const float n0 = h->cfg.exploration_std[0], n1 = h->cfg.exploration_std[1];
+  const bool nu_ok = std::isfinite(n0) && std::isfinite(n1) && n0 * n0 > 0.0f && n1 * n1 > 0.0f &&
+                     std::isfinite(n0 * n0) && std::isfinite(n1 * n1);
+  c.need_control_cost = (p.steering_coeff != 0.0f || p.throttle_coeff != 0.0f || !nu_ok) ? 1 : 0;
+  c.map_w = h->map_w;
+  c.map_h = h->map_h;
+  c.map = h->d_map;
+}
+
+void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, RolloutArgs &a)
+{
+  for (int i = 0; i < kStateDim; i++) a.state[i] = state[i];
+  a.U = h->d_in;
+  a.noise = noise;
+  a.costs = h->d_costs;
+  a.wpack = use_mfma(h) ? h->d_wpack : h->d_theta;
+  a.K = h->K;
+  a.T = h->T;
+  a.opt_delay = h->cfg.optimization_stride;
+  a.k99 = compute_k99(h->K);
+  for (int i = 0; i < 2; i++) {
+    a.nu[i] = h->cfg.exploration_std[i];
+    a.u_lo[i] = h->u_lo[i];
+    a.u_hi[i] = h->u_hi[i];
+  }
+  a.dt = h->dt;
+  a.negate_yaw_der = h->cfg.negate_yaw_der ? 1 : 0;
+  fill_cost_args(h, a.cost);
+}
+
+int launch_rollout(mppi_handle *h, const RolloutArgs &a)
+{
+  hipError_t e = use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, h->block_threads, h->stream)
+                             : launch_rollout_valu(h->net, a, h->stream);
+  if (e != hipSuccess) return fail(h, MPPI_ERR_HIP, "rollout launch", e);
+  return MPPI_OK;
+}
+
+int seed_device(mppi_handle *h, uint64_t seed, uint64_t offset)
+{
+  // base state: L'Ecuyer's default 12345 x 6, scrambled by the seed (DESIGN.md noise spec)
+  uint32_t base[6] = {12345u, 12345u, 12345u, 12345u, 12345u, 12345u};
+  if (seed != 0) {
+    const uint32_t x1 = ((uint32_t)seed) ^ 0x55555555u;
+    const uint32_t x2 = (uint32_t)((seed >> 32) ^ 0xAAAAAAAAu);
+    base[0] = (uint32_t)((uint64_t)x1 * base[0] % M1);
+    base[1] = (uint32_t)((uint64_t)x2 * base[1] % M1);
+    base[2] = (uint32_t)((uint64_t)x1 * base[2] % M1);
+    base[3] = (uint32_t)((uint64_t)x2 * base[3] % M2);
+    base[4] = (uint32_t)((uint64_t)x1 * base[4] % M2);
+    base[5] = (uint32_t)((uint64_t)x2 * base[5] % M2);
+  }
+  int sub_bits = 0;
+  while ((1LL << sub_bits) < (long long)h->K) sub_bits++;
+  HIPCHK(h, launch_noise_init(h->d_rng[0], h->K, base, h->d_sub, sub_bits, h->d_one, offset, h->stream));
+  h->rng_cur = 0;
+  h->cfg.seed = seed;
+  return MPPI_OK;
+}
+
+int upload_rng_tables(mppi_handle *h)
+{
+  std::vector<uint32_t> sub(32 * 18), one(64 * 18), jump((size_t)h->noise_C * 18);
+  Mat3 a1 = base_A1(), a2 = base_A2();
+  for (int b = 0; b < 64; b++) {  // A^(2^b)
+    memcpy(&one[(size_t)b * 18], a1.a, 36);
+    memcpy(&one[(size_t)b * 18 + 9], a2.a, 36);
+    a1 = mat_mul(a1, a1, M1);
+    a2 = mat_mul(a2, a2, M2);
+  }
+  for (int b = 64; b < 76; b++) {
+    a1 = mat_mul(a1, a1, M1);
+    a2 = mat_mul(a2, a2, M2);
+  }
+  for (int b = 0; b < 32; b++) {  // A^(2^76 * 2^b)
+    memcpy(&sub[(size_t)b * 18], a1.a, 36);
+    memcpy(&sub[(size_t)b * 18 + 9], a2.a, 36);
+    a1 = mat_mul(a1, a1, M1);
+    a2 = mat_mul(a2, a2, M2);
+  }
+  const Mat3 j1 = mat_pow(base_A1(), 2ULL * (uint64_t)h->noise_L, M1);
+  const Mat3 j2 = mat_pow(base_A2(), 2ULL * (uint64_t)h->noise_L, M2);
+  Mat3 c1 = mat_identity(), c2 = mat_identity();
+  for (int c = 0; c < h->noise_C; c++) {  // A^(2 L c)
+    memcpy(&jump[(size_t)c * 18], c1.a, 36);
+    memcpy(&jump[(size_t)c * 18 + 9], c2.a, 36);
+    c1 = mat_mul(j1, c1, M1);
+    c2 = mat_mul(j2, c2, M2);
+  }
+  HIPCHK(h, hipMemcpy(h->d_sub, sub.data(), sub.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_one, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice));
+  return MPPI_OK;
+}
+
+int enqueue_noise(mppi_handle *h, float *dst)
+{
+  HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T,
+                         h->noise_L, h->noise_C, dst, h->stream));
+  h->rng_cur = 1 - h->rng_cur;
+  return MPPI_OK;
+}
+
+int check_ready(mppi_handle *h)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  if (!h->have_nn) return fail(h, MPPI_ERR_STATE, "mppi_set_nn_params has not been called");
+  if (!h->have_map) return fail(h, MPPI_ERR_STATE, "mppi_set_costmap has not been called");
+  if (!h->have_cost) return fail(h, MPPI_ERR_STATE, "mppi_set_cost_params has not been called");
+  return MPPI_OK;
+}
+
+int collect(mppi_handle *h)
+{
+  // after the stream is idle: adopt the results of the pending solve
+  if (!h->pending) return MPPI_OK;
+  h->pending = false;
+  h->baseline = h->h_res[0];
+  h->eta = h->h_res[1];
+  h->traj_cost = h->h_res[2];
+  memcpy(h->U.data(), h->h_res + 4, sizeof(float) * 2 * (size_t)h->T);
+  if (h->pending_timed) {
+    h->pending_timed = false;
+    for (size_t it = 0; it < h->ev.size(); it++) {
+      float ms[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < 5; i++) hipEventElapsedTime(&ms[i], h->ev[it].e[i], h->ev[it].e[i + 1]);
+      h->acc.noise_ms += ms[0];
+      h->acc.rollout_ms += ms[1];
+      h->acc.weights_ms += ms[2];
+      h->acc.reduction_ms += ms[3] + ms[4];
+      h->acc.total_ms += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+    }
+    h->acc.n_solves += 1;
+  }
+  return MPPI_OK;
+}
+
+int enqueue_solve(mppi_handle *h, const float *state)
+{
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!state) return fail(h, MPPI_ERR_INVALID, "state is NULL");
+  if (h->pending) {  // finish the previous asynchronous solve first
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    collect(h);
+  }
+  const int K = h->K, T = h->T, iters = h->cfg.num_iters;
+  if (h->explicit_iters > 0 && h->explicit_iters != iters)
+    return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
+  memcpy(h->h_in, h->U.data(), sizeof(float) * 2 * (size_t)T);
+  memcpy(h->h_in + 2 * T, h->hist.data(), sizeof(float) * 4);
+  HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_in, sizeof(float) * (2 * (size_t)T + 4), hipMemcpyHostToDevice,
+                           h->stream));
+  const bool timed = h->timing;
+  const size_t slot = (size_t)K * T * 2;
+  for (int it = 0; it < iters; it++) {
+    float *noise = h->d_noise + (h->explicit_iters > 0 ? (size_t)it * slot : 0);
+    h->last_noise_slot = (h->explicit_iters > 0) ? it : 0;
+    Events *ev = timed ? &h->ev[it] : nullptr;
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[0], h->stream));
+    if (h->explicit_iters == 0) {
+      rc = enqueue_noise(h, noise);
+      if (rc) return rc;
+    }
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[1], h->stream));
+    RolloutArgs a;
+    fill_rollout_args(h, state, noise, a);
+    rc = launch_rollout(h, a);
+    if (rc) return rc;
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
+    HIPCHK(h, launch_weights(h->d_costs, K, h->cfg.gamma, h->d_w, h->d_wn, h->d_scal, h->stream));
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[3], h->stream));
+    HIPCHK(h, launch_weighted_reduction(h->d_wn, noise, K, T, h->d_in, h->stream));
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[4], h->stream));
+    if (it == iters - 1)
+      HIPCHK(h, launch_savgol(h->d_in, h->d_in + 2 * T, T, h->d_scal, h->d_res, 1, h->stream));
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[5], h->stream));
+  }
+  HIPCHK(h, hipMemcpyAsync(h->h_res, h->d_res, sizeof(float) * (4 + 2 * (size_t)T), hipMemcpyDeviceToHost,
+                           h->stream));
+  h->explicit_iters = 0;
+  h->pending = true;
+  h->pending_timed = timed;
+  return MPPI_OK;
+}
+
+void free_all(mppi_handle *h)
+{
+  if (!h) return;
+  float *fp[] = {h->d_in, h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
+                 h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map};
+  for (float *p : fp)
+    if (p) (void)hipFree(p);
+  uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
+  for (uint32_t *p : up)
+    if (p) (void)hipFree(p);
+  if (h->h_in) (void)hipHostFree(h->h_in);
+  if (h->h_res) (void)hipHostFree(h->h_res);
+  for (auto &s : h->ev)
+    for (auto &e : s.e)
+      if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+
+const char *mppi_strerror(int status)
+{
+  switch (status) {
+    case MPPI_OK: return "ok";
+    case MPPI_ERR_INVALID: return "invalid argument";
+    case MPPI_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case MPPI_ERR_HIP: return "HIP runtime error";
+    case MPPI_ERR_STATE: return "call order / missing setup";
+    case MPPI_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+const char *mppi_last_error(const mppi_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int mppi_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; i++) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  return ok;
+}
+
+int mppi_create(const mppi_config *cfg, mppi_handle **out)
+{
+  if (!cfg || !out) return MPPI_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->num_rollouts <= 0 || cfg->num_rollouts % 64 != 0) return MPPI_ERR_INVALID;
+  if (cfg->num_timesteps < 2 || cfg->hz <= 0 || cfg->num_iters < 1) return MPPI_ERR_INVALID;
+  if (cfg->optimization_stride < 0) return MPPI_ERR_INVALID;
+  if (cfg->n_layers < 2 || cfg->n_layers > MPPI_MAX_LAYERS) return MPPI_ERR_INVALID;
+  if (cfg->layers[0] != kNetIn || cfg->layers[cfg->n_layers - 1] != kNetOut) return MPPI_ERR_INVALID;
+  for (int i = 0; i < cfg->n_layers; i++)
+    if (cfg->layers[i] <= 0 || cfg->layers[i] > 256) return MPPI_ERR_INVALID;
+  if ((size_t)cfg->num_rollouts * (size_t)cfg->num_timesteps > (size_t)1 << 28) return MPPI_ERR_INVALID;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MPPI_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return MPPI_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return MPPI_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MPPI_ERR_NO_DEVICE;
+  if (hipSetDevice(cfg->device) != hipSuccess) return MPPI_ERR_HIP;
+
+  mppi_handle *h = new (std::nothrow) mppi_handle();
+  if (!h) return MPPI_ERR_HIP;
+  h->cfg = *cfg;
+  h->K = cfg->num_rollouts;
+  h->T = cfg->num_timesteps;
+  h->dt = (float)(1.0 / cfg->hz);  // path_integral_main.cu:100
+  h->net.n_layers = cfg->n_layers;
+  h->net.max_width = 0;
+  h->net.num_params = 0;
+  for (int i = 0; i < 8; i++) h->net.layers[i] = (i < cfg->n_layers) ? cfg->layers[i] : 0;
+  for (int i = 0; i < cfg->n_layers; i++) h->net.max_width = std::max(h->net.max_width, cfg->layers[i]);
+  for (int i = 0; i + 1 < cfg->n_layers; i++) h->net.num_params += (cfg->layers[i] + 1) * cfg->layers[i + 1];
+  // MFMA variant: 6 -> H x NHID -> 4
+  h->n_hidden = cfg->n_layers - 2;
+  h->hidden = (h->n_hidden > 0) ? cfg->layers[1] : 0;
+  bool uniform = h->n_hidden > 0;
+  for (int i = 1; i <= h->n_hidden; i++) uniform = uniform && (cfg->layers[i] == h->hidden);
+  h->mfma_ok = uniform && mfma_variant_supported(h->hidden, h->n_hidden);
+  for (int i = 0; i < 2; i++) {
+    h->u_lo[i] = cfg->control_min[i];
+    h->u_hi[i] = cfg->control_max[i];
+  }
+  h->U.assign(2 * (size_t)h->T, 0.0f);
+  for (int t = 0; t < h->T; t++) {  // resetControls, mppi_controller.cu:448-458
+    h->U[2 * t] = cfg->init_control[0];
+    h->U[2 * t + 1] = cfg->init_control[1];
+  }
+  h->hist.assign(4, 0.0f);  // control_hist_, :347
+  // noise chunking: enough (k, chunk) threads to cover the chip
+  {
+    int chunks = std::max(1, (1 << 16) / h->K);
+    chunks = std::min(chunks, 64);
+    h->noise_L = std::max(1, (h->T + chunks - 1) / chunks);
+    h->noise_C = (h->T + h->noise_L - 1) / h->noise_L;
+  }
+  const size_t KT2 = (size_t)h->K * h->T * 2;
+#define CR(call)                                                        \
+  do {                                                                  \
+    hipError_t e__ = (call);                                            \
+    if (e__ != hipSuccess) {                                            \
+      fprintf(stderr, "mppi_create: %s: %s\n", #call, hipGetErrorString(e__)); \
+      free_all(h);                                                      \
+      return MPPI_ERR_HIP;                                              \
+    }                                                                   \
+  } while (0)
+  CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CR(hipMalloc(&h->d_in, sizeof(float) * (2 * (size_t)h->T + 4)));
+  CR(hipMalloc(&h->d_res, sizeof(float) * (2 * (size_t)h->T + 4)));
+  CR(hipMalloc(&h->d_scal, sizeof(float) * 4));
+  CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)cfg->num_iters));
+  CR(hipMalloc(&h->d_stage, sizeof(float) * KT2));
+  CR(hipMalloc(&h->d_costs, sizeof(float) * h->K));
+  CR(hipMalloc(&h->d_w, sizeof(float) * h->K));
+  CR(hipMalloc(&h->d_wn, sizeof(float) * h->K));
+  CR(hipMalloc(&h->d_theta, sizeof(float) * h->net.num_params));
+  if (h->mfma_ok)
+    CR(hipMalloc(&h->d_wpack, sizeof(float) * 64 * (size_t)mfma_pack_floats_per_lane(h->hidden, h->n_hidden)));
+  CR(hipMalloc(&h->d_rng[0], sizeof(uint32_t) * 6 * h->K));
+  CR(hipMalloc(&h->d_rng[1], sizeof(uint32_t) * 6 * h->K));
+  CR(hipMalloc(&h->d_jump, sizeof(uint32_t) * 18 * h->noise_C));
+  CR(hipMalloc(&h->d_sub, sizeof(uint32_t) * 18 * 32));
+  CR(hipMalloc(&h->d_one, sizeof(uint32_t) * 18 * 64));
+  CR(hipHostMalloc(&h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
+  CR(hipHostMalloc(&h->h_res, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
+  CR(hipMemset(h->d_scal, 0, sizeof(float) * 4));
+  CR(hipMemset(h->d_res, 0, sizeof(float) * (2 * (size_t)h->T + 4)));
+  h->ev.resize(cfg->num_iters);
+  for (auto &s : h->ev)
+    for (auto &e : s.e) CR(hipEventCreate(&e));
+#undef CR
+  int rc = upload_rng_tables(h);
+  if (rc == MPPI_OK) rc = seed_device(h, cfg->seed, 0);
+  if (rc == MPPI_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = MPPI_ERR_HIP;
+  if (rc != MPPI_OK) {
+    fprintf(stderr, "mppi_create: rng setup failed: %s\n", h->err.c_str());
+    free_all(h);
+    return rc;
+  }
+  *out = h;
+  return MPPI_OK;
+}
+
+int mppi_destroy(mppi_handle *h)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_all(h);
+  return MPPI_OK;
+}
+
+int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
+{
+  if (!h || !theta) return MPPI_ERR_INVALID;
+  if (n != (size_t)h->net.num_params) return fail(h, MPPI_ERR_INVALID, "theta size != NUM_PARAMS");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->theta.assign(theta, theta + n);
+  HIPCHK(h, hipMemcpy(h->d_theta, theta, n * sizeof(float), hipMemcpyHostToDevice));
+  if (h->mfma_ok) {
+    const std::vector<float> pk = pack_mfma_weights(h->theta, h->hidden, h->n_hidden);
+    HIPCHK(h, hipMemcpy(h->d_wpack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  h->have_nn = true;
+  return MPPI_OK;
+}
+
+int mppi_update_model(mppi_handle *h, const int *description, int n_desc, const float *data, size_t n)
+{
+  if (!h || !description || !data) return MPPI_ERR_INVALID;
+  // neural_net_model.cu:155-161: a mismatching description leaves the model untouched
+  for (int i = 0; i < n_desc; i++)
+    if (i >= h->net.n_layers || description[i] != h->net.layers[i])
+      return fail(h, MPPI_ERR_INVALID, "description does not match the network structure");
+  if (n != (size_t)h->net.num_params) return fail(h, MPPI_ERR_INVALID, "data size != NUM_PARAMS");
+  // data = [W1|W2|..|b1|b2|..] -> packed [W1|b1|W2|b2|..]
+  std::vector<float> theta(n);
+  size_t woff = 0, boff = 0, poff = 0;
+  for (int l = 0; l + 1 < h->net.n_layers; l++) boff += (size_t)h->net.layers[l] * h->net.layers[l + 1];
+  for (int l = 0; l + 1 < h->net.n_layers; l++) {
+    const size_t nw = (size_t)h->net.layers[l] * h->net.layers[l + 1], nb = h->net.layers[l + 1];
+    memcpy(&theta[poff], data + woff, nw * sizeof(float));
+    memcpy(&theta[poff + nw], data + boff, nb * sizeof(float));
+    woff += nw;
+    boff += nb;
+    poff += nw + nb;
+  }
+  return mppi_set_nn_params(h, theta.data(), n);
+}
+
+int mppi_set_control_limits(mppi_handle *h, const float umin[2], const float umax[2])
+{
+  if (!h || !umin || !umax) return MPPI_ERR_INVALID;
+  for (int i = 0; i < 2; i++) {
+    h->u_lo[i] = umin[i];
+    h->u_hi[i] = umax[i];
+  }
+  return MPPI_OK;
+}
+
+int mppi_set_costmap(mppi_handle *h, int width, int height, const float *rgba, const float r_c1[3],
+                     const float r_c2[3], const float trs[3])
+{
+  if (!h || !rgba || !r_c1 || !r_c2 || !trs) return MPPI_ERR_INVALID;
+  if (width <= 0 || height <= 0 || (size_t)width * (size_t)height > ((size_t)1 << 30))
+    return fail(h, MPPI_ERR_INVALID, "bad costmap size");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t n = (size_t)width * height;
+  h->map_rgba.assign(rgba, rgba + 4 * n);
+  std::vector<float> ch0(n);
+  for (size_t i = 0; i < n; i++) ch0[i] = rgba[4 * i];  // only .x is sampled (costs.cu:380-381)
+  if (h->d_map) {
+    HIPCHK(h, hipFree(h->d_map));
+    h->d_map = nullptr;
+  }
+  HIPCHK(h, hipMalloc(&h->d_map, n * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->d_map, ch0.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  h->map_w = width;
+  h->map_h = height;
+  for (int i = 0; i < 3; i++) {
+    h->r_c1[i] = r_c1[i];
+    h->r_c2[i] = r_c2[i];
+    h->trs[i] = trs[i];
+  }
+  h->have_map = true;
+  return MPPI_OK;
+}
+
+int mppi_set_costmap_channel(mppi_handle *h, int channel, const float *data, size_t n)
+{
+  if (!h || !data) return MPPI_ERR_INVALID;
+  if (!h->have_map) return fail(h, MPPI_ERR_STATE, "mppi_set_costmap has not been called");
+  if (channel < 0 || channel > 3 || n != (size_t)h->map_w * h->map_h)
+    return fail(h, MPPI_ERR_INVALID, "bad channel or size");
+  for (size_t i = 0; i < n; i++) h->map_rgba[4 * i + channel] = data[i];
+  if (channel == 0) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->d_map, data, n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return MPPI_OK;
+}
+
+int mppi_set_cost_params(mppi_handle *h, const mppi_cost_params *p)
+{
+  if (!h || !p) return MPPI_ERR_INVALID;
+  h->cost = *p;
+  h->have_cost = true;
+  return MPPI_OK;
+}
+
+int mppi_reset_controls(mppi_handle *h)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  for (int t = 0; t < h->T; t++) {
+    h->U[2 * t] = h->cfg.init_control[0];
+    h->U[2 * t + 1] = h->cfg.init_control[1];
+  }
+  return MPPI_OK;
+}
+
+int mppi_set_control_seq(mppi_handle *h, const float *U, size_t n)
+{
+  if (!h || !U || n != 2 * (size_t)h->T) return MPPI_ERR_INVALID;
+  memcpy(h->U.data(), U, n * sizeof(float));
+  return MPPI_OK;
+}
+
+int mppi_get_control_seq(mppi_handle *h, float *U, size_t n)
+{
+  if (!h || !U || n != 2 * (size_t)h->T) return MPPI_ERR_INVALID;
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
+  memcpy(U, h->U.data(), n * sizeof(float));
+  return MPPI_OK;
+}
+
+int mppi_set_control_hist(mppi_handle *h, const float hist[4])
+{
+  if (!h || !hist) return MPPI_ERR_INVALID;
+  memcpy(h->hist.data(), hist, 4 * sizeof(float));
+  return MPPI_OK;
+}
+
+int mppi_get_control_hist(mppi_handle *h, float hist[4])
+{
+  if (!h || !hist) return MPPI_ERR_INVALID;
+  memcpy(hist, h->hist.data(), 4 * sizeof(float));
+  return MPPI_OK;
+}
+
+int mppi_slide_control_seq(mppi_handle *h, int stride)
+{
+  if (!h || stride < 1 || stride > h->T) return MPPI_ERR_INVALID;
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
+  // mppi_controller.cu:527-554
+  float *U = h->U.data(), *hist = h->hist.data();
+  const int T = h->T;
+  if (stride == 1) {
+    hist[0] = hist[2];
+    hist[1] = hist[3];
+    hist[2] = U[0];
+    hist[3] = U[1];
+  } else {
+    const int t = stride - 2;
+    for (int i = 0; i < 4; i++) hist[i] = U[t + i];
+  }
+  for (int i = 0; i < T - stride; i++)
+    for (int j = 0; j < 2; j++) U[i * 2 + j] = U[(i + stride) * 2 + j];
+  for (int j = 1; j <= stride; j++)
+    for (int i = 0; i < 2; i++) U[(T - j) * 2 + i] = h->cfg.init_control[i];
+  return MPPI_OK;
+}
+
+int mppi_seed(mppi_handle *h, uint64_t seed, uint64_t offset)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  int rc = seed_device(h, seed, offset);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+int mppi_set_noise(mppi_handle *h, const float *eps, size_t n)
+{
+  if (!h || !eps) return MPPI_ERR_INVALID;
+  const size_t slot = (size_t)h->K * h->T * 2;
+  if (n != slot * (size_t)h->cfg.num_iters) return fail(h, MPPI_ERR_INVALID, "noise size != num_iters*K*T*2");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  for (int it = 0; it < h->cfg.num_iters; it++) {
+    HIPCHK(h, hipMemcpyAsync(h->d_stage, eps + (size_t)it * slot, slot * sizeof(float),
+                             hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_kt_to_tk(h->d_stage, h->d_noise + (size_t)it * slot, h->K, h->T, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  h->explicit_iters = h->cfg.num_iters;
+  return MPPI_OK;
+}
+
+int mppi_generate_noise(mppi_handle *h, float *eps_out, size_t n)
+{
+  if (!h || !eps_out) return MPPI_ERR_INVALID;
+  const size_t slot = (size_t)h->K * h->T * 2;
+  if (n != slot) return fail(h, MPPI_ERR_INVALID, "n != K*T*2");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  int rc = enqueue_noise(h, h->d_noise);
+  if (rc) return rc;
+  HIPCHK(h, launch_tk_to_kt(h->d_noise, h->d_stage, h->K, h->T, h->stream));
+  HIPCHK(h, hipMemcpyAsync(eps_out, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+int mppi_compute_control_async(mppi_handle *h, const float state[MPPI_STATE_DIM])
+{
+  if (!h) return MPPI_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  return enqueue_solve(h, state);
+}
+
+int mppi_synchronize(mppi_handle *h)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return collect(h);
+}
+
+int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM])
+{
+  int rc = mppi_compute_control_async(h, state);
+  if (rc) return rc;
+  return mppi_synchronize(h);
+}
+
+int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, float *weights)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  if (U) memcpy(U, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
+  if (traj_cost) *traj_cost = h->traj_cost;
+  if (costs) HIPCHK(h, hipMemcpy(costs, h->d_costs, sizeof(float) * h->K, hipMemcpyDeviceToHost));
+  if (weights) HIPCHK(h, hipMemcpy(weights, h->d_w, sizeof(float) * h->K, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+int mppi_get_applied_controls(mppi_handle *h, float *V, size_t n)
+{
+  if (!h || !V) return MPPI_ERR_INVALID;
+  const size_t slot = (size_t)h->K * h->T * 2;
+  if (n != slot) return fail(h, MPPI_ERR_INVALID, "n != K*T*2");
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)h->last_noise_slot * slot, h->d_stage, h->K, h->T, h->stream));
+  HIPCHK(h, hipMemcpyAsync(V, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *costs)
+{
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!state || !costs) return fail(h, MPPI_ERR_INVALID, "NULL argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  rc = mppi_synchronize(h);
+  if (rc) return rc;
+  memcpy(h->h_in, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
+  memcpy(h->h_in + 2 * h->T, h->hist.data(), sizeof(float) * 4);
+  HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipMemcpyHostToDevice,
+                           h->stream));
+  if (h->explicit_iters == 0) {
+    rc = enqueue_noise(h, h->d_noise);
+    if (rc) return rc;
+  }
+  h->explicit_iters = 0;
+  h->last_noise_slot = 0;
+  RolloutArgs a;
+  fill_rollout_args(h, state, h->d_noise, a);
+  rc = launch_rollout(h, a);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(costs, h->d_costs, sizeof(float) * h->K, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MPPI_OK;
+}
+
+int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *state_seq, float *control_seq)
+{
+  if (!h || !state || !state_seq || !control_seq) return MPPI_ERR_INVALID;
+  if (!h->have_nn) return fail(h, MPPI_ERR_STATE, "mppi_set_nn_params has not been called");
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
+  // computeNominalTraj (mppi_controller.cu:501-519) -> host updateState (neural_net_model.cu:280-288):
+  // like the reference this replay runs on the host (T sequential 1.4k-MAC steps).
+  float s[kStateDim];
+  for (int i = 0; i < kStateDim; i++) s[i] = state[i];
+  std::vector<float> a(h->net.max_width), b(h->net.max_width);
+  for (int t = 0; t < h->T; t++) {
+    for (int i = 0; i < kStateDim; i++) state_seq[t * kStateDim + i] = s[i];
+    float u[2] = {h->U[2 * t], h->U[2 * t + 1]};
+    for (int i = 0; i < 2; i++) {
+      if (u[i] < h->u_lo[i]) u[i] = h->u_lo[i];
+      else if (u[i] > h->u_hi[i]) u[i] = h->u_hi[i];
+    }
+    const float c = cosf(s[2]), sn = sinf(s[2]);
+    float sd[kStateDim];
+    sd[0] = fmaf(c, s[4], -(sn * s[5]));
+    sd[1] = fmaf(sn, s[4], c * s[5]);
+    sd[2] = h->cfg.negate_yaw_der ? -s[6] : s[6];
+    a[0] = s[3]; a[1] = s[4]; a[2] = s[5]; a[3] = s[6]; a[4] = u[0]; a[5] = u[1];
+    size_t off = 0;
+    for (int l = 0; l + 1 < h->net.n_layers; l++) {
+      const int nin = h->net.layers[l], nout = h->net.layers[l + 1];
+      const float *W = &h->theta[off], *bias = &h->theta[off + (size_t)nin * nout];
+      for (int j = 0; j < nout; j++) {
+        float tmp = 0.0f;
+        for (int k = 0; k < nin; k++) tmp = fmaf(W[j * nin + k], a[k], tmp);
+        tmp += bias[j];
+        if (l < h->net.n_layers - 2) tmp = tanhf(tmp);
+        b[j] = tmp;
+      }
+      off += (size_t)nin * nout + nout;
+      std::swap(a, b);
+    }
+    for (int i = 0; i < 4; i++) sd[3 + i] = a[i];
+    for (int i = 0; i < kStateDim; i++) s[i] = fmaf(sd[i], h->dt, s[i]);
+    control_seq[2 * t] = u[0];
+    control_seq[2 * t + 1] = u[1];
+  }
+  return MPPI_OK;
+}
+
+int mppi_enable_stage_timing(mppi_handle *h, int on)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  h->timing = on != 0;
+  return MPPI_OK;
+}
+
+int mppi_reset_stage_times(mppi_handle *h)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  h->acc = mppi_stage_times{};
+  return MPPI_OK;
+}
+
+int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out)
+{
+  if (!h || !out) return MPPI_ERR_INVALID;
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
+  *out = h->acc;
+  return MPPI_OK;
+}
+
+const char *mppi_rollout_variant(const mppi_handle *h)
+{
+  if (!h) return "";
+  if (!use_mfma(h)) return "valu_lds";
+  static thread_local char buf[64];
+  snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_b%d", h->hidden, h->n_hidden, h->block_threads);
+  return buf;
+}
+
+int mppi_set_rollout_variant(mppi_handle *h, const char *name)
+{
+  if (!h || !name) return MPPI_ERR_INVALID;
+  if (strcmp(name, "auto") == 0) h->variant_pref = 0;
+  else if (strcmp(name, "mfma") == 0) {
+    if (!h->mfma_ok) return fail(h, MPPI_ERR_UNSUPPORTED, "MFMA variant needs 6-HxN-4 with H in {32,64}, N in {2,4}");
+    h->variant_pref = 1;
+  } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
+  else if (strcmp(name, "block64") == 0) h->block_threads = 64;
+  else if (strcmp(name, "block256") == 0) h->block_threads = 256;
+  else return fail(h, MPPI_ERR_INVALID, "unknown variant");
+  return MPPI_OK;
+}
+
+/* Debug/test entry (not part of the drop-in surface): state derivatives of n (state, control)
+ * pairs through the same device functions as the rollout kernel. */
+int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float *controls, float *ders)
+{
+  if (!h || n <= 0 || !states || !controls || !ders) return MPPI_ERR_INVALID;
+  if (!h->have_nn) return fail(h, MPPI_ERR_STATE, "mppi_set_nn_params has not been called");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  float *d_s = nullptr, *d_u = nullptr, *d_o = nullptr;
+  HIPCHK(h, hipMalloc(&d_s, sizeof(float) * 7 * n));
+  HIPCHK(h, hipMalloc(&d_u, sizeof(float) * 2 * n));
+  HIPCHK(h, hipMalloc(&d_o, sizeof(float) * 7 * n));
+  hipError_t e = hipMemcpy(d_s, states, sizeof(float) * 7 * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_u, controls, sizeof(float) * 2 * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = use_mfma(h) ? launch_dynamics_mfma(h->hidden, h->n_hidden, h->d_wpack, d_s, d_u, d_o, n,
+                                           h->cfg.negate_yaw_der ? 1 : 0, h->stream)
+                    : launch_dynamics_valu(h->net, h->d_theta, d_s, d_u, d_o, n,
+                                           h->cfg.negate_yaw_der ? 1 : 0, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(ders, d_o, sizeof(float) * 7 * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d_s);
+  (void)hipFree(d_u);
+  (void)hipFree(d_o);
+  if (e != hipSuccess) return fail(h, MPPI_ERR_HIP, "mppi_debug_dynamics", e);
+  return MPPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// mppi_kernels.hpp -- launchers implemented in the .hip kernel files.
+#pragma once
+#include "mppi_device.hpp"
+
+namespace mppi {
+
+// rollout_mfma.hip
+bool mfma_variant_supported(int hidden, int n_hidden);
+int mfma_pack_floats_per_lane(int hidden, int n_hidden);
+hipError_t launch_rollout_mfma(int hidden, int n_hidden, const RolloutArgs &a, int block_threads,
+                               hipStream_t stream);
+hipError_t launch_dynamics_mfma(int hidden, int n_hidden, const float *wpack, const float *states,
+                                const float *controls, float *ders, int n, int negate_yaw_der,
+                                hipStream_t stream);
+
+// rollout_valu.hip (generic vector-ALU kernel, any layer list)
+struct NetDesc {
+  int n_layers;
+  int layers[8];
+  int max_width;
+  int num_params;
+};
+size_t valu_lds_bytes(const NetDesc &net);
+hipError_t launch_rollout_valu(const NetDesc &net, const RolloutArgs &a, hipStream_t stream);
+hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const float *states,
+                                const float *controls, float *ders, int n, int negate_yaw_der,
+                                hipStream_t stream);
+
+// solve_kernels.hip
+hipError_t launch_weights(const float *costs, int K, float gamma, float *w, float *wn, float *scal,
+                          hipStream_t stream);
+hipError_t launch_weighted_reduction(const float *wn, const float *V, int K, int T, float *Unew,
+                                     hipStream_t stream);
+hipError_t launch_savgol(float *U, const float *hist, int T, const float *scal, float *res, int smooth,
+                         hipStream_t stream);
+hipError_t launch_kt_to_tk(const float *src, float *dst, int K, int T, hipStream_t stream);
+hipError_t launch_tk_to_kt(const float *src, float *dst, int K, int T, hipStream_t stream);
+
+// noise_mrg32k3a.hip
+hipError_t launch_noise(const uint32_t *rng_in, uint32_t *rng_out, const uint32_t *jump, int K, int T,
+                        int L, int C, float *eps, hipStream_t stream);
+hipError_t launch_noise_init(uint32_t *rng, int K, const uint32_t base[6], const uint32_t *sub,
+                             int sub_bits, const uint32_t *one, uint64_t offset, hipStream_t stream);
+
+}  // namespace mppi

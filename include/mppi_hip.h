@@ -1,0 +1,181 @@
+/*
+ * mppi_hip.h -- C ABI of libmppi_hip.so, the MI355X (gfx950) MPPI solver.
+ *
+ * Drop-in boundary for the rollout hot path of rdesc/autorally's
+ * autorally_control/src/path_integral.  The reference has no FFI for this path:
+ * its boundary is the C++ template class MPPIController<DYNAMICS_T, COSTS_T, ...>
+ * plus two cnpy-loaded .npz formats.  Each entry point below names the reference
+ * interface it replaces; paths are relative to /root/reference/autorally_control/,
+ *   PI/ = include/autorally_control/path_integral/.
+ *
+ * Conventions: extern "C"; opaque handle; every call returns an int status
+ * (MPPI_OK == 0); no exceptions cross the ABI; the caller owns every host
+ * buffer and the library copies; a handle owns all its device memory and one HIP
+ * stream; a handle is single-threaded, distinct handles may be driven from
+ * distinct host threads (one per GPU).  On error outputs are left untouched
+ * (the reference logs CUDA errors and continues, PI/gpu_err_chk.h:74).
+ *
+ * There is NO CPU fallback: every compute entry point fails with
+ * MPPI_ERR_NO_DEVICE / MPPI_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef MPPI_HIP_H_
+#define MPPI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_ABI_VERSION 1
+#define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
+#define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
+#define MPPI_MAX_LAYERS 8
+
+enum {
+  MPPI_OK = 0,
+  MPPI_ERR_INVALID = 1,   /* bad argument / size mismatch */
+  MPPI_ERR_NO_DEVICE = 2, /* no usable gfx950 device */
+  MPPI_ERR_HIP = 3,       /* a HIP runtime call failed; see mppi_last_error */
+  MPPI_ERR_STATE = 4,     /* call order (e.g. solve before set_nn_params / set_costmap) */
+  MPPI_ERR_UNSUPPORTED = 5
+};
+
+typedef struct mppi_handle mppi_handle;
+
+/* Constructor arguments of MPPIController (PI/mppi_controller.cuh:101-102,
+ * PI/mppi_controller.cu:321-363) + NeuralNetModel(dt, control_rngs)
+ * (PI/neural_net_model.cu:38-67) + the template constants of
+ * src/path_integral/path_integral_main.cu:65-78 made runtime values. */
+typedef struct {
+  int device;                 /* HIP device ordinal */
+  int num_rollouts;           /* K; must be a multiple of 64 (mppi_controller.cuh:58-60) */
+  int num_timesteps;          /* T */
+  int hz;                     /* dt = (float)(1.0/hz) */
+  int optimization_stride;    /* opt_delay of rolloutKernel */
+  float gamma;
+  int num_iters;
+  int n_layers;               /* entries of layers[], input and output included */
+  int layers[MPPI_MAX_LAYERS];/* e.g. {6,32,32,4}; layers[0]==6, layers[n-1]==4 */
+  float exploration_std[2];   /* nu */
+  float init_control[2];      /* init_u */
+  float control_min[2];       /* control_rngs_[i].x */
+  float control_max[2];       /* control_rngs_[i].y */
+  int negate_yaw_der;
+  uint64_t seed;              /* reference: 1234 (mppi_controller.cu:331) */
+} mppi_config;
+
+/* MPPICosts::CostParams scalars (PI/costs.cuh:67-85) + l1_cost_ (costs.cuh:276).
+ * The transform (r_c1, r_c2, trs) travels with the costmap, see mppi_set_costmap. */
+typedef struct {
+  float desired_speed;
+  float speed_coeff;
+  float track_coeff;
+  float max_slip_ang;
+  float slip_penalty;
+  float track_slop;
+  float crash_coeff;
+  float steering_coeff;
+  float throttle_coeff;
+  float boundary_threshold;
+  float discount;
+  int l1_cost;
+} mppi_cost_params;
+
+/* Per-stage device times of the most recent solves (HIP events on the handle's stream). */
+typedef struct {
+  int n_solves;            /* solves accumulated since mppi_reset_stage_times */
+  float noise_ms;          /* sums over n_solves */
+  float rollout_ms;
+  float weights_ms;
+  float reduction_ms;      /* weighted reduction + Savitzky-Golay */
+  float total_ms;          /* first launch -> last kernel end */
+} mppi_stage_times;
+
+int mppi_abi_version(void);
+const char *mppi_strerror(int status);
+/* Last HIP/validation error text of this handle ("" if none). */
+const char *mppi_last_error(const mppi_handle *h);
+/* Number of visible HIP devices whose architecture is gfx950 (0 if none / no runtime). */
+int mppi_device_count(void);
+
+/* MPPIController::MPPIController + allocateCudaMem (mppi_controller.cu:321-387). */
+int mppi_create(const mppi_config *cfg, mppi_handle **out);
+/* deallocateCudaMem (mppi_controller.cu:389-400), without the double free of Q14. */
+int mppi_destroy(mppi_handle *h);
+
+/* NeuralNetModel::paramsToDevice (neural_net_model.cu:120-150): theta is the packed
+ * [W1|b1|W2|b2|...] blob, n == NUM_PARAMS. The .npz is read by the C++ host layer. */
+int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n);
+/* NeuralNetModel::updateModel (neural_net_model.cu:152-180): data = [W1|W2|..|b1|b2|..]. */
+int mppi_update_model(mppi_handle *h, const int *description, int n_desc, const float *data, size_t n);
+/* control_rngs_ (cutThrottle, mppi_controller.cu:460-466, sets control_max[1]=0). */
+int mppi_set_control_limits(mppi_handle *h, const float umin[2], const float umax[2]);
+
+/* MPPICosts::loadTrackData/updateTransform/costmapToTexture (costs.cu:190-232, 175-188,
+ * 128-154): rgba = float4[H][W] (x fastest).  Texture semantics reproduced: point
+ * filter, clamp, normalised coordinates. */
+int mppi_set_costmap(mppi_handle *h, int width, int height, const float *rgba,
+                     const float r_c1[3], const float r_c2[3], const float trs[3]);
+/* costmapToTexture(float*, channel) (costs.cu:101-126). */
+int mppi_set_costmap_channel(mppi_handle *h, int channel, const float *data, size_t n);
+/* updateParams / updateParams_dcfg / paramsToDevice (costs.cu:156-173, 75-87, 234-238). */
+int mppi_set_cost_params(mppi_handle *h, const mppi_cost_params *p);
+
+/* U_ accessors (resetControls :448-458; setControlSequence-like). U is [T][2]. */
+int mppi_reset_controls(mppi_handle *h);
+int mppi_set_control_seq(mppi_handle *h, const float *U, size_t n);
+int mppi_get_control_seq(mppi_handle *h, float *U, size_t n);
+/* control_hist_ (mppi_controller.cu:347, 528-541): two controls executed before U_0. */
+int mppi_set_control_hist(mppi_handle *h, const float hist[4]);
+int mppi_get_control_hist(mppi_handle *h, float hist[4]);
+/* slideControlSeq (mppi_controller.cu:527-554), flat-index quirk for stride>2 kept. */
+int mppi_slide_control_seq(mppi_handle *h, int stride);
+
+/* Replaces curandCreateGenerator/SetSeed (mppi_controller.cu:330-331): this build's
+ * MRG32k3a generator, one 2^76-draw subsequence per rollout, `offset` draws skipped. */
+int mppi_seed(mppi_handle *h, uint64_t seed, uint64_t offset);
+/* Explicit-noise mode (what the parity tests use): eps = [num_iters][K][T][2] N(0,1),
+ * consumed by the NEXT mppi_compute_control / mppi_rollout_only instead of the generator. */
+int mppi_set_noise(mppi_handle *h, const float *eps, size_t n);
+/* Runs the generator for one iteration worth of draws ([K][T][2]) and copies it out;
+ * advances the stream exactly as a solve iteration would. */
+int mppi_generate_noise(mppi_handle *h, float *eps_out, size_t n);
+
+/* MPPIController::computeControl(state) up to and including savitskyGolay()
+ * (mppi_controller.cu:600-671); computeNominalTraj is mppi_nominal_traj. Blocking. */
+int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM]);
+/* Same solve, enqueued only; results are valid after mppi_synchronize. */
+int mppi_compute_control_async(mppi_handle *h, const float state[MPPI_STATE_DIM]);
+int mppi_synchronize(mppi_handle *h);
+/* getComputedTrajectoryCost (:683-687) + optional per-rollout vectors of the last
+ * iteration: costs[K] (traj_costs_ after the rollout), weights[K] (after normExpKernel). */
+int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, float *weights);
+/* The rewritten du_d buffer of the last iteration, [K][T][2] (applied, unclamped controls, Q3). */
+int mppi_get_applied_controls(mppi_handle *h, float *V, size_t n);
+/* Stage-level entry: noise (or explicit noise) + rolloutKernel only; costs[K]. */
+int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *costs);
+/* computeNominalTraj (mppi_controller.cu:501-519), host replay of U_ like the reference:
+ * state_seq [T][7], control_seq [T][2] (clamped). */
+int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *state_seq,
+                      float *control_seq);
+
+/* Measurement hooks. */
+int mppi_enable_stage_timing(mppi_handle *h, int on);
+int mppi_reset_stage_times(mppi_handle *h);
+int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
+/* Name of the rollout kernel variant selected for this net ("mfma16_h32", "valu", ...). */
+const char *mppi_rollout_variant(const mppi_handle *h);
+/* Force a variant (A/B of SURVEY cfg 4): "auto", "mfma", "valu". */
+int mppi_set_rollout_variant(mppi_handle *h, const char *name);
+
+/* Test hook (not part of the drop-in surface): d/dt of n independent (state[7], control[2])
+ * pairs through the SAME device functions the rollout kernel uses (computeKinematics +
+ * computeDynamics, neural_net_model.cu:346-410); ders is [n][7]. */
+int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float *controls, float *ders);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_HIP_H_ */
