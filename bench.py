@@ -37,7 +37,12 @@ def cpu_baseline(cfg, budget_s=12.0):
     """The CPU oracle (a C port of the reference kernels, OpenMP over rollouts) timed on this
     host on the SAME workload: a bounded sample of whole solves."""
     from oracle import oracle as O
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    # the GPU box gives one GPU's share of host cores (16); never oversubscribe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
     orc = O.Oracle(cfg, fma_mode=1, nthreads=threads)
     K, T = cfg["K"], cfg["T"]
     U = np.zeros((T, 2), np.float32)

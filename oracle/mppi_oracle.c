@@ -34,6 +34,15 @@ static inline float mac(float a, float b, float c, int fma_mode)
   return p + c;
 }
 
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_params(const int *layers, int n_layers)
 {
   /* PI/meta_math.h:38-51 param_counter */
@@ -257,30 +266,31 @@ void orc_weighted_reduction(const float *w, float eta, const float *V, int K, in
   /* mppi_controller.cu:219-267: block t, thread m sums rollouts 64m..64m+63 in order,
    * thread 0 sums the partials in order. */
   const int nthr = (K - 1) / 64 + 1;
-  float *partial = (float *)malloc(sizeof(float) * 2 * (size_t)nthr);
+  /* weight = states_d[k]/normalizer is recomputed per (t,k) in the kernel (:244); the value is
+   * the same every time, so it is hoisted here. */
+  float *wn = (float *)malloc(sizeof(float) * (size_t)K);
+  for (int k = 0; k < K; k++) wn[k] = w[k] / eta;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (K * T > 100000)
+#endif
   for (int t = 0; t < T; t++) {
+    float u0 = 0.0f, u1 = 0.0f;
     for (int m = 0; m < nthr; m++) {
       float a0 = 0.0f, a1 = 0.0f;
       for (int i = 0; i < 64; i++) {
         const int k = 64 * m + i;
         if (k < K) {
-          const float weight = w[k] / eta;
-          a0 = mac(weight, V[(size_t)k * 2 * T + 2 * t + 0], a0, fma_mode);
-          a1 = mac(weight, V[(size_t)k * 2 * T + 2 * t + 1], a1, fma_mode);
+          a0 = mac(wn[k], V[(size_t)k * 2 * T + 2 * t + 0], a0, fma_mode);
+          a1 = mac(wn[k], V[(size_t)k * 2 * T + 2 * t + 1], a1, fma_mode);
         }
       }
-      partial[2 * m] = a0;
-      partial[2 * m + 1] = a1;
-    }
-    float u0 = 0.0f, u1 = 0.0f;
-    for (int m = 0; m < nthr; m++) {
-      u0 += partial[2 * m];
-      u1 += partial[2 * m + 1];
+      u0 += a0; /* thread 0 adds the partials in order, :256-260 */
+      u1 += a1;
     }
     Unew[2 * t] = u0;
     Unew[2 * t + 1] = u1;
   }
-  free(partial);
+  free(wn);
 }
 
 void orc_savgol(float *U, const float *hist, int T)
@@ -400,9 +410,10 @@ void orc_mrg_seed(orc_mrg_state *st, uint64_t seed)
 uint32_t orc_mrg_next_z(orc_mrg_state *st)
 {
   /* p1 = (a12*s1[1] - a13n*s1[0]) mod m1 ; p2 = (a21*s2[2] - a23n*s2[0]) mod m2 */
-  const uint64_t p1 = (A12 * st->s1[1] + (M1 - A13N) * st->s1[0]) % M1;
+  /* each product is < 2^53; reduce before combining so nothing can wrap 2^64 */
+  const uint64_t p1 = ((A12 * st->s1[1]) % M1 + M1 - (A13N * st->s1[0]) % M1) % M1;
   st->s1[0] = st->s1[1]; st->s1[1] = st->s1[2]; st->s1[2] = (uint32_t)p1;
-  const uint64_t p2 = (A21 * st->s2[2] + (M2 - A23N) * st->s2[0]) % M2;
+  const uint64_t p2 = ((A21 * st->s2[2]) % M2 + M2 - (A23N * st->s2[0]) % M2) % M2;
   st->s2[0] = st->s2[1]; st->s2[1] = st->s2[2]; st->s2[2] = (uint32_t)p2;
   uint64_t z = (p1 >= p2) ? (p1 - p2) : (p1 + M1 - p2);
   if (z == 0) z = M1;

@@ -71,6 +71,8 @@ typedef struct {
   int nthreads;       /* OpenMP threads for the k loop; <=1 = serial */
 } orc_problem;
 
+/* OpenMP team size used by loops that have no orc_problem (weighted reduction). */
+void orc_set_num_threads(int n);
 int orc_num_params(const int *layers, int n_layers);
 
 /* neural_net_model.cu:357-410 (device computeDynamics): in[layers[0]] -> out[layers[L-1]] */

@@ -91,6 +91,7 @@ def lib():
         fp = C.POINTER(C.c_float)
         ip = C.POINTER(C.c_int)
         pp = C.POINTER(Problem)
+        L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_num_params.restype = C.c_int
         L.orc_num_params.argtypes = [ip, C.c_int]
         L.orc_nn_forward.argtypes = [fp, ip, C.c_int, fp, fp, C.c_int]
@@ -166,6 +167,7 @@ class Oracle:
         p.map_rgba = _fp(self.map)
         p.fma_mode = int(fma_mode)
         p.nthreads = int(nthreads)
+        self.L.orc_set_num_threads(int(nthreads))
         self.p = p
 
     # -- pieces --

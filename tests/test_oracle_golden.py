@@ -126,3 +126,24 @@ def test_noise_moments_and_layout():
     np.testing.assert_array_equal(e_long[:, :T, :], e)
     # different rollouts use different subsequences
     assert not np.array_equal(e[0], e[1])
+
+
+def test_mrg32k3a_long_run_against_bigint():
+    """The recurrence must hold over long runs (catches 64-bit wrap in a12*s11 - a13n*s10)."""
+    import ctypes as C
+    L = O.lib()
+    st = O.MrgState()
+    L.orc_mrg_seed(C.byref(st), 1234)
+    s1, s2 = [int(x) for x in st.s1], [int(x) for x in st.s2]
+    m1, m2 = 4294967087, 4294944443
+    n = 300000
+    zs = np.array([L.orc_mrg_next_z(C.byref(st)) for _ in range(n)], dtype=np.uint64)
+    ref = np.zeros(n, dtype=np.uint64)
+    for i in range(n):
+        p1 = (1403580 * s1[1] - 810728 * s1[0]) % m1
+        s1 = [s1[1], s1[2], p1]
+        p2 = (527612 * s2[2] - 1370589 * s2[0]) % m2
+        s2 = [s2[1], s2[2], p2]
+        z = (p1 - p2) % m1
+        ref[i] = z if z > 0 else m1
+    np.testing.assert_array_equal(zs, ref)

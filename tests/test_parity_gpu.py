@@ -108,16 +108,23 @@ def test_rollout_costs_and_controls(K, T, track, layers, variant):
     np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
     err = rel_err(got["costs"], ref["costs"])
     bad = int(np.sum(err > 1e-4))
-    # threshold chaos: a 1-ulp tanh/sincos difference may flip a boundary / slip
-    # threshold for a rollout that grazes it; such rollouts must be few and carry no weight.
-    # Crash-free problems (K=128 ring) must have none.
+    # Threshold chaos: the nearest-texel lookup and the crash/slip thresholds are
+    # discontinuous, so a 1-ulp tanh/sincos difference moves a few grazing rollouts to the
+    # neighbouring texel (the oracle's own FMA / no-FMA builds disagree on the same rollouts).
+    # Such rollouts must be few and the weight they move must be negligible.
     assert bad <= K // 200, (bad, float(err.max()))
+    assert float(np.max(err[err <= 1e-4])) < 2e-5
     wsum = float(ref["w"].sum())
-    assert float(ref["w"][err > 1e-4].sum()) / wsum < 1e-3
+    assert float(np.abs(got["w"] - ref["w"]).sum()) / wsum < 1e-4
     assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
     assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"])
-    ok = err <= 1e-4
-    assert np.max(np.abs(got["w"][ok] - ref["w"][ok])) < 1e-4
+    # downstream stages alone: oracle weighting + reduction + smoothing fed with the GPU's own
+    # costs and applied controls must reproduce the GPU's U (no chaos left in this comparison)
+    orc = O.Oracle(cfg, fma_mode=1)
+    w, _, eta, tc = orc.weights(got["costs"])
+    U2 = orc.savgol(orc.weighted_reduction(w, eta, got["V"]), np.zeros(4, np.float32))
+    assert np.max(np.abs(U2 - got["U"])) <= 2e-6
+    assert abs(tc - got["traj_cost"]) <= 1e-5 * abs(tc)
 
 
 def test_mfma_and_valu_variants_agree_bitwise():
