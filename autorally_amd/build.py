@@ -15,8 +15,10 @@ SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_valu.hip", "solve_kernel
            "noise_mrg32k3a.hip"]
 HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file), which removes
+# the v_accvgpr_read per accumulator register after every layer
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def hipcc():

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmppi_hip.so")
+# MPPI_LIB_PATH: developer override used for kernel A/B builds (scratch/), never a fallback
+LIB_PATH = os.environ.get("MPPI_LIB_PATH") or os.path.join(HERE, "libmppi_hip.so")
 MAX_LAYERS = 8
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(6)

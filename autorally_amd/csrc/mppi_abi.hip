@@ -85,6 +85,7 @@ struct mppi_handle {
   float *d_noise = nullptr, *d_stage = nullptr;
   float *d_costs = nullptr, *d_w = nullptr, *d_wn = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
+  double *d_invt = nullptr;
   uint32_t *d_rng[2] = {nullptr, nullptr};
   uint32_t *d_jump = nullptr, *d_sub = nullptr, *d_one = nullptr;
   int rng_cur = 0;
@@ -229,6 +230,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.noise = noise;
   a.costs = h->d_costs;
   a.wpack = use_mfma(h) ? h->d_wpack : h->d_theta;
+  a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
   a.opt_delay = h->cfg.optimization_stride;
@@ -406,6 +408,7 @@ void free_all(mppi_handle *h)
                  h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map};
   for (float *p : fp)
     if (p) (void)hipFree(p);
+  if (h->d_invt) (void)hipFree(h->d_invt);
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
   for (uint32_t *p : up)
     if (p) (void)hipFree(p);
@@ -536,6 +539,12 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_one, sizeof(uint32_t) * 18 * 64));
   CR(hipHostMalloc(&h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
   CR(hipHostMalloc(&h->h_res, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
+  CR(hipMalloc(&h->d_invt, sizeof(double) * (size_t)h->T));
+  {
+    std::vector<double> invt((size_t)h->T, 0.0);
+    for (int t = 1; t < h->T; t++) invt[t] = 1.0 / (double)t;  // correctly rounded reciprocal
+    CR(hipMemcpy(h->d_invt, invt.data(), sizeof(double) * (size_t)h->T, hipMemcpyHostToDevice));
+  }
   CR(hipMemset(h->d_scal, 0, sizeof(float) * 4));
   CR(hipMemset(h->d_res, 0, sizeof(float) * (2 * (size_t)h->T + 4)));
   h->ev.resize(cfg->num_iters);

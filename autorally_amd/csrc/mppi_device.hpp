@@ -3,6 +3,9 @@
 // All kernels are compiled with -ffp-contract=off: every fused multiply-add is an
 // explicit fmaf()/MFMA placed where the reference's nvcc build contracts one
 // (SURVEY 8c "fidelity rules"); everything else rounds exactly as written.
+// The per-step helpers are written branch-free (selects instead of if/else) so that one
+// rollout step is a single basic block and the scheduler can interleave the cost / kinematics
+// arithmetic with the MFMA chain of the network.
 // Reference citations are relative to /root/reference/autorally_control/,
 //   PI/ = include/autorally_control/path_integral/.
 #pragma once
@@ -37,6 +40,7 @@ struct RolloutArgs {
   float *noise;     // [T][K][2]: in N(0,1), out applied unclamped control (Q3)
   float *costs;     // [K]
   const float *wpack;  // MFMA-ordered weights (see pack_mfma_weights) or packed theta (VALU kernel)
+  const double *inv_t; // inv_t[t] = RN(1.0 / t) in double, t = 1..T-1 (running-mean division)
   int K, T, opt_delay, k99;
   float nu[2], u_lo[2], u_hi[2], dt;
   int negate_yaw_der;
@@ -47,17 +51,18 @@ struct RolloutArgs {
 //   (double)x > 1.57   <=>  x >= kRollCrash   (costs.cu:302)
 //   (double)x > 0.001  <=>  x >= kMinSpeed    (costs.cu:340)
 //   (double)x > 1e12   <=>  x >= kCostCapGt   (costs.cu:405); replacement value (float)1e12
-__device__ constexpr float kRollCrash = 1.57000005245208740234375f;     // nextafter((float)1.57 < 1.57 ? ...)
+__device__ constexpr float kRollCrash = 1.57000005245208740234375f;
 __device__ constexpr float kMinSpeed = 0.001000000047497451305389404296875f;
 __device__ constexpr float kCostCapGt = 1000000061440.0f;
 __device__ constexpr float kCostCap = 999999995904.0f;
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
 {
-  // enforceConstraints, neural_net_model.cu:311-323 (NaN passes through unchanged)
-  if (v < lo) v = lo;
-  else if (v > hi) v = hi;
-  return v;
+  // enforceConstraints, neural_net_model.cu:311-323: if (v < lo) v = lo; else if (v > hi) v = hi;
+  // as two selects (lo wins when both hold; NaN passes through unchanged)
+  float r = (v > hi) ? hi : v;
+  r = (v < lo) ? lo : r;
+  return r;
 }
 
 // tanh for the hidden layers (MPPI_NNET_NONLINEARITY, neural_net_model.cu:35).
@@ -70,66 +75,123 @@ __device__ __forceinline__ float tanh_fast(float x)
   return fmaf(-2.0f, r, 1.0f);
 }
 
-__device__ __forceinline__ float texel_x(const CostArgs &c, float x, float y)
+// sin/cos for the kinematics and the track-cost look-ahead points (neural_net_model.cu:348-349,
+// costs.cu:364-367; the reference uses cosf/sinf for the former and __cosf/__sinf for the latter,
+// Q7 -- one precise pair serves both here).  Reduction by pi/2 in double (two-constant, exact for
+// |x| < 2^30) + degree-7/6 float polynomials: <= 1.3e-7 absolute error, branch-free.
+__device__ __forceinline__ void sincos_fast(float x, float &sn, float &cs)
 {
-  // coorTransform (costs.cu:351-357) + point/clamp/normalised tex2D (costs.cu:128-154)
+  const double xd = (double)x;
+  const double q = rint(xd * 0.63661977236758134308);
+  double rd = fma(-q, 1.5707963267948966, xd);
+  rd = fma(-q, 6.123233995736766e-17, rd);
+  const float r = (float)rd;
+  const float r2 = r * r;
+  const float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+  const float s0 = fmaf(r * r2, ps, r);
+  const float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+  const float c0 = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const int qi = (int)q;
+  const float a = (qi & 1) ? c0 : s0;
+  const float b = (qi & 1) ? s0 : c0;
+  sn = (qi & 2) ? -a : a;
+  cs = ((qi + 1) & 2) ? -b : b;
+}
+
+// coorTransform (costs.cu:351-357) + point/clamp/normalised tex2D addressing (costs.cu:128-154):
+// index of the texel that tex2D<float4>(tex, u/w, v/w) returns.
+template <bool AFFINE>
+__device__ __forceinline__ unsigned texel_index(const CostArgs &c, float x, float y)
+{
   float u = fmaf(c.r_c1[0], x, c.r_c2[0] * y) + c.trs[0];
   float v = fmaf(c.r_c1[1], x, c.r_c2[1] * y) + c.trs[1];
-  if (!c.affine) {
+  if (!AFFINE) {  // AFFINE: w == 1 exactly, u/w == u
     const float w = fmaf(c.r_c1[2], x, c.r_c2[2] * y) + c.trs[2];
     u = u / w;
     v = v / w;
   }
   float fi = floorf(u * (float)c.map_w);
   float fj = floorf(v * (float)c.map_h);
-  if (!(fi >= 0.0f)) fi = 0.0f;
-  if (!(fj >= 0.0f)) fj = 0.0f;
-  fi = fminf(fi, (float)(c.map_w - 1));
-  fj = fminf(fj, (float)(c.map_h - 1));
-  const int i = (int)fi, j = (int)fj;
-  return c.map[(size_t)j * (size_t)c.map_w + (size_t)i];
+  fi = fminf(fmaxf(fi, 0.0f), (float)(c.map_w - 1));  // fmaxf(NaN, 0) = 0
+  fj = fminf(fmaxf(fj, 0.0f), (float)(c.map_h - 1));
+  return (unsigned)((int)fj * c.map_w + (int)fi);
 }
 
-// MPPICosts::computeCost (costs.cu:396-409).  cpsi/spsi = cos/sin of s[2] (the reference uses
-// __cosf/__sinf here, Q7; this build reuses the precise values already needed by the kinematics).
-__device__ __forceinline__ float compute_cost(const CostArgs &c, const float nu[2], const float *s,
-                                              float cpsi, float spsi, float u0, float u1, float du0,
-                                              float du1, int &crash)
+// First half of getTrackCost (costs.cu:359-377): the two costmap fetches (front and back of the
+// car).  Issued early in the step so that their latency hides under the NN layers.
+template <bool AFFINE>
+__device__ __forceinline__ void track_fetch(const CostArgs &c, const float *s, float cpsi, float spsi,
+                                            float &tf, float &tb)
+{
+  const float xf = fmaf(0.5f, cpsi, s[0]), yf = fmaf(0.5f, spsi, s[1]);
+  const float xb = fmaf(-0.5f, cpsi, s[0]), yb = fmaf(-0.5f, spsi, s[1]);
+  tf = c.map[texel_index<AFFINE>(c, xf, yf)];
+  tb = c.map[texel_index<AFFINE>(c, xb, yb)];
+}
+
+// MPPICosts::computeCost (costs.cu:396-409) in two halves, so that the half that needs no
+// costmap texel can run a network layer earlier than the half that does.
+struct CostTerms {
+  float control_cost, speed_cost, stabilizing_cost;
+};
+
+// control (:307-313), speed (:315-326) and stabilizing (:337-349) terms.  s4/s5 = u_x, u_y of
+// the state being costed.
+template <bool CTRL_COST>
+__device__ __forceinline__ void cost_terms_a(const CostArgs &c, const float nu[2], float s4, float s5,
+                                             float u0, float u1, float du0, float du1, CostTerms &o)
 {
   float control_cost = 0.0f;
-  if (c.need_control_cost) {  // getControlCost :307-313
+  if (CTRL_COST) {  // exactly +0 when both coefficients are 0 and nu is finite and non-zero
     control_cost += c.steering_coeff * du0 * (u0 - du0) / (nu[0] * nu[0]);
     control_cost += c.throttle_coeff * du1 * (u1 - du1) / (nu[1] * nu[1]);
   }
-  // getTrackCost :359-393
-  const float xf = fmaf(0.5f, cpsi, s[0]), yf = fmaf(0.5f, spsi, s[1]);
-  const float xb = fmaf(-0.5f, cpsi, s[0]), yb = fmaf(-0.5f, spsi, s[1]);
-  const float tf = texel_x(c, xf, yf);
-  const float tb = texel_x(c, xb, yb);
+  o.control_cost = control_cost;
+  const float err = s4 - c.desired_speed;
+  o.speed_cost = c.speed_coeff * (c.l1_cost ? fabsf(err) : err * err);
+  // computed unconditionally, selected afterwards (the reference guards with |s4| > 0.001)
+  const float slip = -atanf(s5 / fabsf(s4));
+  float stab = c.slip_penalty * (slip * slip);
+  stab = (fabsf(slip) > c.max_slip_ang) ? stab + c.crash_coeff : stab;
+  o.stabilizing_cost = (fabsf(s4) >= kMinSpeed) ? stab : 0.0f;
+}
+
+// track term (:379-393), crash flag and crash term (:402, :328-335), the sum in the reference's
+// order and the 1e12 / NaN cap (:404-407).  crash is the sticky flag (0/1), updated in place.
+__device__ __forceinline__ float cost_terms_b(const CostArgs &c, const CostTerms &a, float tf, float tb,
+                                              int &crash)
+{
   float track_cost = (fabsf(tf) + fabsf(tb)) * 0.5f;  // == (float)((double)(..)/2.0)
   track_cost = (fabsf(track_cost) < c.track_slop) ? 0.0f : c.track_coeff * track_cost;
-  if (tf >= c.boundary_threshold || tb >= c.boundary_threshold) crash = 1;
-  // getSpeedCost :315-326
-  const float err = s[4] - c.desired_speed;
-  const float speed_cost = c.speed_coeff * (c.l1_cost ? fabsf(err) : err * err);
-  // (1.0 - discount) * getCrashCost :402, :328-335
+  crash |= (int)(tf >= c.boundary_threshold) | (int)(tb >= c.boundary_threshold);
   const float crash_cost = (crash > 0) ? c.crash_cost_discounted : 0.0f;
-  // getStabilizingCost :337-349
-  float stabilizing_cost = 0.0f;
-  if (fabsf(s[4]) >= kMinSpeed) {
-    const float slip = -atanf(s[5] / fabsf(s[4]));
-    stabilizing_cost = c.slip_penalty * (slip * slip);
-    if (fabsf(slip) > c.max_slip_ang) stabilizing_cost += c.crash_coeff;
-  }
-  float cost = control_cost + speed_cost + crash_cost + track_cost + stabilizing_cost;
-  if (cost >= kCostCapGt || cost != cost) cost = kCostCap;
+  float cost = a.control_cost + a.speed_cost + crash_cost + track_cost + a.stabilizing_cost;
+  cost = (cost >= kCostCapGt || cost != cost) ? kCostCap : cost;
   return cost;
 }
 
-// running_cost += (cost - running_cost)/(1.0*i)  in double (mppi_controller.cu:165, Q5)
-__device__ __forceinline__ float running_mean(float J, float c, int t)
+template <bool CTRL_COST>
+__device__ __forceinline__ float cost_finish(const CostArgs &c, const float nu[2], float s4, float s5,
+                                             float tf, float tb, float u0, float u1, float du0,
+                                             float du1, int &crash)
 {
-  return (float)((double)J + (double)(c - J) / (double)t);
+  CostTerms t;
+  cost_terms_a<CTRL_COST>(c, nu, s4, s5, u0, u1, du0, du1, t);
+  return cost_terms_b(c, t, tf, tb, crash);
+}
+
+// running_cost += (cost - running_cost)/(1.0*i), in double (mppi_controller.cu:165, Q5).
+// The IEEE double division by the integer i is done as Markstein's refinement with the
+// correctly rounded reciprocal rt = RN(1/i) from a host table: q0 = d*rt, e = fma(-q0, i, d),
+// q = fma(e, rt, q0) is the correctly rounded d/i (3 f64 ops instead of a ~16-op divide).
+__device__ __forceinline__ float running_mean(float J, float c, int t, double rt)
+{
+  const double d = (double)(c - J);
+  const double td = (double)t;
+  const double q0 = d * rt;
+  const double e = fma(-q0, td, d);
+  const double q = fma(e, rt, q0);
+  return (float)((double)J + q);
 }
 
 }  // namespace mppi

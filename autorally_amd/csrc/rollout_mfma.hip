@@ -33,35 +33,44 @@ struct MfmaNet {
   static constexpr int nPack = nA + nBias;  // floats per lane in wpack
 };
 
-// d[0..3] = NN(s3..s6, u0, u1) for the lane's rollout; every lane of the rollout gets all four.
+// The network is evaluated in three pieces so that the rollout step can place independent
+// cost / kinematics arithmetic next to each piece (they execute in the shadow of the MFMAs).
+//
+// piece 1: layer 0.  B operands: k-step 0 = [s3,s4,s5,s6][g], k-step 1 = [u0,u1,0,0][g].
 template <int H, int NHID>
-__device__ __forceinline__ void nn_forward_mfma(const float (&A)[MfmaNet<H, NHID>::nA],
-                                                const float (&Bi)[MfmaNet<H, NHID>::nBias], int g,
-                                                float s3, float s4, float s5, float s6, float u0,
-                                                float u1, float (&d)[4])
+__device__ __forceinline__ void nn_layer0(const float (&A)[MfmaNet<H, NHID>::nA], int g, float s3,
+                                          float s4, float s5, float s6, float u0, float u1,
+                                          f32x4 (&acc)[MfmaNet<H, NHID>::MT])
 {
-  using N = MfmaNet<H, NHID>;
-  constexpr int MT = N::MT, KSH = N::KSH;
-  // layer-0 B operands: k-step 0 = [s3,s4,s5,s6][g], k-step 1 = [u0,u1,0,0][g]
+  constexpr int MT = MfmaNet<H, NHID>::MT;
   const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
   const float b1 = (g == 0) ? u0 : (g == 1) ? u1 : 0.0f;
-  f32x4 acc[MT];
-  float act[MT * 4];
 #pragma unroll
   for (int m = 0; m < MT; m++) {
     f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
     z = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m * 2 + 0], b0, z, 0, 0, 0);
     acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m * 2 + 1], b1, z, 0, 0, 0);
   }
-#pragma unroll
-  for (int m = 0; m < MT; m++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_fast(acc[m][r] + Bi[m * 4 + r]);
+}
 
+// piece 2: tanh(layer-0 output) and the hidden->hidden layers; leaves the pre-activation of the
+// last hidden layer in acc.
+template <int H, int NHID>
+__device__ __forceinline__ void nn_hidden(const float (&A)[MfmaNet<H, NHID>::nA],
+                                          const float (&Bi)[MfmaNet<H, NHID>::nBias],
+                                          f32x4 (&acc)[MfmaNet<H, NHID>::MT])
+{
+  using N = MfmaNet<H, NHID>;
+  constexpr int MT = N::MT, KSH = N::KSH;
 #pragma unroll
   for (int l = 1; l < NHID; l++) {
     const int aoff = N::nA0 + (l - 1) * N::nAH;
-    const int boff = l * MT * 4;
+    const int boff = (l - 1) * MT * 4;
+    float act[MT * 4];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_fast(acc[m][r] + Bi[boff + m * 4 + r]);
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -69,24 +78,46 @@ __device__ __forceinline__ void nn_forward_mfma(const float (&A)[MfmaNet<H, NHID
 #pragma unroll
       for (int m = 0; m < MT; m++)
         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[aoff + m * KSH + s], act[s], acc[m], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_fast(acc[m][r] + Bi[boff + m * 4 + r]);
-  }
-  {
-    const int aoff = N::nA0 + (NHID - 1) * N::nAH;
-    const int boff = NHID * MT * 4;
-    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < KSH; s++)
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(A[aoff + s], act[s], o, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; r++) d[r] = o[r] + Bi[boff + r];  // last layer: no non-linearity
   }
 }
 
+// piece 3: tanh(last hidden pre-activation), output layer (no non-linearity), bias.
 template <int H, int NHID>
+__device__ __forceinline__ void nn_last(const float (&A)[MfmaNet<H, NHID>::nA],
+                                        const float (&Bi)[MfmaNet<H, NHID>::nBias],
+                                        const f32x4 (&acc)[MfmaNet<H, NHID>::MT], float (&d)[4])
+{
+  using N = MfmaNet<H, NHID>;
+  constexpr int MT = N::MT, KSH = N::KSH;
+  const int aoff = N::nA0 + (NHID - 1) * N::nAH;
+  const int boff = (NHID - 1) * MT * 4, bl = NHID * MT * 4;
+  float act[MT * 4];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_fast(acc[m][r] + Bi[boff + m * 4 + r]);
+  f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < KSH; s++)
+    o = __builtin_amdgcn_mfma_f32_16x16x4f32(A[aoff + s], act[s], o, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) d[r] = o[r] + Bi[bl + r];
+}
+
+// d[0..3] = NN(s3..s6, u0, u1) for the lane's rollout; every lane of the rollout gets all four.
+template <int H, int NHID>
+__device__ __forceinline__ void nn_forward_mfma(const float (&A)[MfmaNet<H, NHID>::nA],
+                                                const float (&Bi)[MfmaNet<H, NHID>::nBias], int g,
+                                                float s3, float s4, float s5, float s6, float u0,
+                                                float u1, float (&d)[4])
+{
+  f32x4 acc[MfmaNet<H, NHID>::MT];
+  nn_layer0<H, NHID>(A, g, s3, s4, s5, s6, u0, u1, acc);
+  nn_hidden<H, NHID>(A, Bi, acc);
+  nn_last<H, NHID>(A, Bi, acc, d);
+}
+
+template <int H, int NHID, bool AFFINE, bool CTRL>
 __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
 {
   using N = MfmaNet<H, NHID>;
@@ -114,42 +145,70 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
   const bool noise_free_k = (k == 0);       // mppi_controller.cu:136
   const bool pure_noise_k = (k >= a.k99);   // :141, k >= .99*NUM_ROLLOUTS in double (host)
 
+  // Everything a step reads from memory is requested ahead of its use (noise line, nominal
+  // control and 1/t one step ahead; the two costmap texels two network layers ahead), so no
+  // load latency sits on the T-step recurrence.  A step is branch-free and cut into four
+  // scheduling regions: in each, the MFMAs of one network piece run next to independent
+  // cost / kinematics arithmetic.
   float2 eps = noise[(size_t)k];            // t = 0
+  float2 Unext = Useq[0];
+  double rt_next = a.inv_t[0];
   for (int t = 0; t < T; t++) {
+    // ---- region 1: controls, layer 0, sin/cos, costmap addresses and fetches ----
     const float2 e = eps;
-    if (t + 1 < T) eps = noise[(size_t)(t + 1) * K + k];  // prefetch next step's line
-    const float2 Ut = Useq[t];
-    float du0, du1, u0, u1;
-    if (noise_free_k || t < a.opt_delay) {
-      du0 = 0.0f; du1 = 0.0f; u0 = Ut.x; u1 = Ut.y;
-    } else {
-      du0 = e.x * a.nu[0];
-      du1 = e.y * a.nu[1];
-      u0 = pure_noise_k ? du0 : Ut.x + du0;
-      u1 = pure_noise_k ? du1 : Ut.y + du1;
-    }
-    if (g == 0) noise[(size_t)t * K + k] = make_float2(u0, u1);  // stored before the clamp (Q3)
+    const float2 Ut = Unext;
+    const double rt = rt_next;
+    const int tn = min(t + 1, T - 1);
+    eps = noise[(size_t)tn * K + k];
+    Unext = Useq[tn];
+    rt_next = a.inv_t[tn];
+    // control perturbation, mppi_controller.cu:136-153
+    const bool nf = noise_free_k | (t < a.opt_delay);
+    const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+    const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+    float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
+    float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
+    // stored before the clamp (Q3); the four lanes of a rollout write the same value
+    noise[(size_t)t * K + k] = make_float2(u0, u1);
     u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
     u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
-
+    f32x4 acc[N::MT];
+    nn_layer0<H, NHID>(A, g, s[3], s[4], s[5], s[6], u0, u1, acc);
     float spsi, cpsi;
-    sincosf(s[2], &spsi, &cpsi);
-    if (t > 0) {  // running mean over t = 1..T-1 of the cost of the state before the update (Q5)
-      const float c = compute_cost(a.cost, a.nu, s, cpsi, spsi, u0, u1, du0, du1, crash);
-      J = running_mean(J, c, t);
-    }
-    // computeKinematics, neural_net_model.cu:346-355
+    sincos_fast(s[2], spsi, cpsi);
+    float tf, tb;
+    track_fetch<AFFINE>(a.cost, s, cpsi, spsi, tf, tb);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- region 2: hidden layers next to kinematics and the texel-free cost terms ----
+    nn_hidden<H, NHID>(A, Bi, acc);
     float sd[kStateDim];
-    sd[0] = fmaf(cpsi, s[4], -(spsi * s[5]));
+    sd[0] = fmaf(cpsi, s[4], -(spsi * s[5]));  // computeKinematics, neural_net_model.cu:346-355
     sd[1] = fmaf(spsi, s[4], cpsi * s[5]);
     sd[2] = a.negate_yaw_der ? -s[6] : s[6];
+    CostTerms ct;
+    cost_terms_a<CTRL>(a.cost, a.nu, s[4], s[5], u0, u1, du0, du1, ct);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- region 3: output layer next to the track / crash terms and the running mean ----
     float d[4];
-    nn_forward_mfma<H, NHID>(A, Bi, g, s[3], s[4], s[5], s[6], u0, u1, d);
+    nn_last<H, NHID>(A, Bi, acc, d);
+    {
+      // running mean over t = 1..T-1 of the cost of the state before the update (Q5); the
+      // t = 0 evaluation is computed and discarded
+      int crash_new = crash;
+      const float c = cost_terms_b(a.cost, ct, tf, tb, crash_new);
+      const float Jn = running_mean(J, c, t, rt);
+      J = (t > 0) ? Jn : J;
+      crash = (t > 0) ? crash_new : crash;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- region 4: incrementState (:334-344) and getCrash (costs.cu:301-305) ----
     sd[3] = d[0]; sd[4] = d[1]; sd[5] = d[2]; sd[6] = d[3];
-    // incrementState, :334-344
 #pragma unroll
     for (int i = 0; i < kStateDim; i++) s[i] = fmaf(sd[i], a.dt, s[i]);
-    if (fabsf(s[3]) >= kRollCrash) crash = 1;  // getCrash, costs.cu:301-305
+    crash |= (int)(fabsf(s[3]) >= kRollCrash);
   }
   if (g == 0) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
 }
@@ -176,7 +235,7 @@ __global__ __launch_bounds__(64) void dynamics_mfma_kernel(const float *wpack, c
   for (int i = 0; i < kStateDim; i++) s[i] = states[src * kStateDim + i];
   const float u0 = controls[src * 2], u1 = controls[src * 2 + 1];
   float spsi, cpsi;
-  sincosf(s[2], &spsi, &cpsi);
+  sincos_fast(s[2], spsi, cpsi);
   float d[4];
   nn_forward_mfma<H, NHID>(A, Bi, g, s[3], s[4], s[5], s[6], u0, u1, d);
   if (g == 0 && idx < n) {
@@ -194,8 +253,12 @@ static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipS
 {
   const int waves = a.K / kRolloutsPerWave;
   const int wpb = block_threads / 64;
-  const int grid = (waves + wpb - 1) / wpb;
-  hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID>), dim3(grid), dim3(block_threads), 0, stream, a);
+  const dim3 grid((waves + wpb - 1) / wpb), block(block_threads);
+  const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
+  if (affine && !ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
+  else if (affine && ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
+  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 

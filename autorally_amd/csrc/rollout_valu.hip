@@ -86,10 +86,11 @@ __global__ __launch_bounds__(kValuLanes) void rollout_valu_kernel(const RolloutA
     u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
     u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
     float spsi, cpsi;
-    sincosf(s[2], &spsi, &cpsi);
+    sincos_fast(s[2], spsi, cpsi);
+    float tf = 0.0f, tb = 0.0f;
     if (t > 0) {
-      const float c = compute_cost(a.cost, a.nu, s, cpsi, spsi, u0, u1, du0, du1, crash);
-      J = running_mean(J, c, t);
+      if (a.cost.affine) track_fetch<true>(a.cost, s, cpsi, spsi, tf, tb);
+      else track_fetch<false>(a.cost, s, cpsi, spsi, tf, tb);
     }
     float sd[kStateDim];
     sd[0] = fmaf(cpsi, s[4], -(spsi * s[5]));
@@ -99,9 +100,15 @@ __global__ __launch_bounds__(kValuLanes) void rollout_valu_kernel(const RolloutA
     float d[4];
     nn_forward_valu(net, theta_s, act0, act1, lane, in, d);
     sd[3] = d[0]; sd[4] = d[1]; sd[5] = d[2]; sd[6] = d[3];
+    if (t > 0) {
+      const float c = a.cost.need_control_cost
+                          ? cost_finish<true>(a.cost, a.nu, s[4], s[5], tf, tb, u0, u1, du0, du1, crash)
+                          : cost_finish<false>(a.cost, a.nu, s[4], s[5], tf, tb, u0, u1, du0, du1, crash);
+      J = running_mean(J, c, t, a.inv_t[t]);
+    }
 #pragma unroll
     for (int i = 0; i < kStateDim; i++) s[i] = fmaf(sd[i], a.dt, s[i]);
-    if (fabsf(s[3]) >= kRollCrash) crash = 1;
+    crash |= (int)(fabsf(s[3]) >= kRollCrash);
   }
   a.costs[k] = J + 0.0f;
 }
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(kValuLanes) void dynamics_valu_kernel(const NetDev 
   for (int i = 0; i < kStateDim; i++) s[i] = states[src * kStateDim + i];
   const float in[kNetIn] = {s[3], s[4], s[5], s[6], controls[src * 2], controls[src * 2 + 1]};
   float spsi, cpsi;
-  sincosf(s[2], &spsi, &cpsi);
+  sincos_fast(s[2], spsi, cpsi);
   float d[4];
   nn_forward_valu(net, theta_s, act0, act1, lane, in, d);
   if (idx < n) {
