@@ -66,5 +66,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+BIN = os.path.join(HERE, "bin")
+
+
+def build_host(force=False):
+    """C++ host layer above the C ABI (the reference's controller surface, ROS-free binary).
+    Plain g++: the host code only sees include/mppi_hip.h and links libmppi_hip.so."""
+    os.makedirs(BIN, exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    hdrs = [os.path.join(HOST, h) for h in ("npz.hpp", "param_getter.hpp", "mppi_controller_hip.hpp",
+                                            "run_control_loop.hpp")] + [os.path.join(HERE, "..", "include", "mppi_hip.h")]
+    outs = []
+    for name, libs in (("host_selftest", []), ("path_integral_nn", ["-L" + HERE, "-lmppi_hip", "-Wl,-rpath,$ORIGIN/.."])):
+        src = os.path.join(HOST, name + ".cpp")
+        out = os.path.join(BIN, name)
+        outs.append(out)
+        if force or _stale(out, [src] + hdrs + ([LIB] if libs else [])):
+            cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-DMPPI_NPZ_ZLIB", src, "-o", out] + libs + ["-lz", "-lpthread"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("host build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return outs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

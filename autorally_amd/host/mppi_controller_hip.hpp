@@ -1,0 +1,386 @@
+// mppi_controller_hip.hpp -- the reference's controller surface over the libmppi_hip C ABI.
+//
+// Header-only C++ mirror of the three classes the path's callers touch
+// (src/path_integral/path_integral_main.cu:94-122, PI/run_control_loop.cuh:148-300):
+//   NeuralNetModel  (PI/neural_net_model.cuh:64-116)  -> mppi_host::NeuralNetModel
+//   MPPICosts       (PI/costs.cuh:87-266)             -> mppi_host::MPPICosts
+//   MPPIController  (PI/mppi_controller.cuh:52-217)   -> mppi_host::MPPIController
+// Same method names and argument meaning.  Differences forced by the environment: Eigen is not
+// available, so states are `const float*` / std::array<float,7> instead of Eigen::Matrix<float,7,1>;
+// K, BDIM and the layer list are runtime values instead of template constants (the reference must be
+// recompiled to change them, path_integral_main.cu:65-78).  DDP feedback gains are not part of the
+// hot path: computeFeedbackGains() is a documented no-op here.
+//
+// All compute goes through the C ABI; there is no CPU fallback.  The only host arithmetic is what the
+// reference also does on the host: computeNominalTraj / model->updateState (mppi_nominal_traj).
+#pragma once
+
+#include <array>
+#include <cfloat>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mppi_hip.h"
+#include "npz.hpp"
+#include "param_getter.hpp"
+
+namespace mppi_host {
+
+struct float2_ { float x, y; };
+
+// ------------------------------------------------------------------------------------------
+class NeuralNetModel {
+ public:
+  static const int STATE_DIM = 7, CONTROL_DIM = 2, DYNAMICS_DIM = 4;
+  std::vector<int> net_structure_;          // e.g. {6,32,32,4} (template pack in the reference)
+  std::vector<float2_> control_rngs_;       // public in the reference (neural_net_model.cuh:76)
+  bool negate_yaw_der = true;               // neural_net_model.cuh:84
+
+  // NeuralNetModel(float delta_t, float2* control_rngs = NULL), neural_net_model.cu:38-67
+  NeuralNetModel(const std::vector<int> &layers, float delta_t, const float2_ *control_rngs = nullptr)
+      : net_structure_(layers), dt_(delta_t)
+  {
+    control_rngs_.resize(CONTROL_DIM);
+    for (int i = 0; i < CONTROL_DIM; i++)
+      control_rngs_[i] = control_rngs ? control_rngs[i] : float2_{-FLT_MAX, FLT_MAX};
+    int n = 0;
+    for (size_t i = 0; i + 1 < layers.size(); i++) n += (layers[i] + 1) * layers[i + 1];
+    net_params_.assign((size_t)n, 0.0f);
+  }
+
+  int numParams() const { return (int)net_params_.size(); }
+  float dt() const { return dt_; }
+  const std::vector<float> &packedParams() const { return net_params_; }
+
+  // loadParams(model_path), neural_net_model.cu:73-106: keys dynamics_W{i} (out,in) and
+  // dynamics_b{i}, float64 in the shipped files, cast to float, packed [W1|b1|W2|b2|...] (:120-141)
+  void loadParams(const std::string &model_path)
+  {
+    if (!file_exists(model_path)) throw std::runtime_error("Could not load neural net model at path: " + model_path);
+    npz_t d = npz_load(model_path);
+    size_t off = 0;
+    for (size_t i = 1; i < net_structure_.size(); i++) {
+      const std::string wn = "dynamics_W" + std::to_string(i), bn = "dynamics_b" + std::to_string(i);
+      if (!d.count(wn) || !d.count(bn)) throw std::runtime_error("model file lacks " + wn + "/" + bn);
+      const NpyArray &W = d[wn], &b = d[bn];
+      const size_t nout = (size_t)net_structure_[i], nin = (size_t)net_structure_[i - 1];
+      if (W.num_vals() != nout * nin || b.num_vals() != nout)
+        throw std::runtime_error("model file shape does not match the network structure");
+      for (size_t j = 0; j < nout * nin; j++) net_params_[off + j] = (float)W.at(j);
+      off += nout * nin;
+      for (size_t j = 0; j < nout; j++) net_params_[off + j] = (float)b.at(j);
+      off += nout;
+    }
+    version_++;
+  }
+
+  // updateModel(description, data), neural_net_model.cu:152-180: data = [W1|W2|..|b1|b2|..]
+  void updateModel(const std::vector<int> &description, const std::vector<float> &data)
+  {
+    for (size_t i = 0; i < description.size(); i++)
+      if (i >= net_structure_.size() || description[i] != net_structure_[i]) return;  // invalid: ignored
+    if (data.size() != net_params_.size()) return;
+    size_t woff = 0, boff = 0, poff = 0;
+    for (size_t l = 0; l + 1 < net_structure_.size(); l++) boff += (size_t)net_structure_[l] * net_structure_[l + 1];
+    for (size_t l = 0; l + 1 < net_structure_.size(); l++) {
+      const size_t nw = (size_t)net_structure_[l] * net_structure_[l + 1], nb = (size_t)net_structure_[l + 1];
+      for (size_t j = 0; j < nw; j++) net_params_[poff + j] = data[woff + j];
+      for (size_t j = 0; j < nb; j++) net_params_[poff + nw + j] = data[boff + j];
+      woff += nw; boff += nb; poff += nw + nb;
+    }
+    version_++;
+  }
+
+  // host twin of updateState (neural_net_model.cu:280-288): clamp, kinematics, NN, Euler step
+  void updateState(float *state, float *control) const
+  {
+    for (int i = 0; i < CONTROL_DIM; i++) {
+      if (control[i] < control_rngs_[i].x) control[i] = control_rngs_[i].x;
+      else if (control[i] > control_rngs_[i].y) control[i] = control_rngs_[i].y;
+    }
+    float sd[STATE_DIM];
+    const float c = cosf(state[2]), s = sinf(state[2]);
+    sd[0] = fmaf(c, state[4], -(s * state[5]));
+    sd[1] = fmaf(s, state[4], c * state[5]);
+    sd[2] = negate_yaw_der ? -state[6] : state[6];
+    std::vector<float> a(maxWidth()), b(maxWidth());
+    a[0] = state[3]; a[1] = state[4]; a[2] = state[5]; a[3] = state[6]; a[4] = control[0]; a[5] = control[1];
+    size_t off = 0;
+    for (size_t l = 0; l + 1 < net_structure_.size(); l++) {
+      const int nin = net_structure_[l], nout = net_structure_[l + 1];
+      const float *W = &net_params_[off], *bias = &net_params_[off + (size_t)nin * nout];
+      for (int j = 0; j < nout; j++) {
+        float tmp = 0.0f;
+        for (int k = 0; k < nin; k++) tmp = fmaf(W[j * nin + k], a[k], tmp);
+        tmp += bias[j];
+        if (l + 2 < net_structure_.size()) tmp = tanhf(tmp);
+        b[j] = tmp;
+      }
+      off += (size_t)nin * nout + nout;
+      a.swap(b);
+    }
+    for (int i = 0; i < DYNAMICS_DIM; i++) sd[3 + i] = a[i];
+    for (int i = 0; i < STATE_DIM; i++) state[i] = fmaf(sd[i], dt_, state[i]);
+  }
+
+  // paramsToDevice(), neural_net_model.cu:120-150 -- pushed into a controller's handle
+  void paramsToDevice(mppi_handle *h)
+  {
+    check(mppi_set_nn_params(h, net_params_.data(), net_params_.size()), h);
+    float lo[2] = {control_rngs_[0].x, control_rngs_[1].x}, hi[2] = {control_rngs_[0].y, control_rngs_[1].y};
+    check(mppi_set_control_limits(h, lo, hi), h);
+  }
+  // bumped whenever host-side parameters change; controllers re-upload when they see a new value
+  unsigned version_ = 0;
+  void touch() { version_++; }
+
+  static void check(int rc, mppi_handle *h)
+  {
+    if (rc != MPPI_OK)
+      throw std::runtime_error(std::string("libmppi_hip: ") + mppi_strerror(rc) + " (" + (h ? mppi_last_error(h) : "") + ")");
+  }
+
+ private:
+  size_t maxWidth() const
+  {
+    int m = 0;
+    for (int v : net_structure_) m = v > m ? v : m;
+    return (size_t)m;
+  }
+  float dt_;
+  std::vector<float> net_params_;
+};
+
+// ------------------------------------------------------------------------------------------
+class MPPICosts {
+ public:
+  // CostParams, costs.cuh:67-85
+  struct CostParams {
+    float desired_speed, speed_coeff, track_coeff, max_slip_ang, slip_penalty, track_slop, crash_coeff,
+        steering_coeff, throttle_coeff, boundary_threshold, discount;
+    int num_timesteps, grid_res;
+    float r_c1[3], r_c2[3], trs[3];
+  };
+  CostParams params_{};  // public in the reference
+  bool l1_cost_ = false;
+  int width_ = 0, height_ = 0;
+  std::vector<float> track_costs_;  // float4[H][W]
+
+  // MPPICosts(std::map<std::string,XmlRpcValue>* params), costs.cu:52-66
+  explicit MPPICosts(ParamMap *params)
+  {
+    loadTrackData((std::string)(*params)["map_path"]);
+    updateParams(params);
+  }
+  // MPPICosts(int width, int height), costs.cu:43-50: zero costmap
+  MPPICosts(int width, int height) : width_(width), height_(height)
+  {
+    track_costs_.assign((size_t)4 * width * height, 0.0f);
+    const float r1[3] = {1, 0, 0}, r2[3] = {0, 1, 0}, t[3] = {0, 0, 1};
+    for (int i = 0; i < 3; i++) { params_.r_c1[i] = r1[i]; params_.r_c2[i] = r2[i]; params_.trs[i] = t[i]; }
+  }
+
+  // updateParams, costs.cu:156-173
+  void updateParams(ParamMap *params)
+  {
+    l1_cost_ = (bool)(*params)["l1_cost"];
+    params_.desired_speed = (float)(double)(*params)["desired_speed"];
+    params_.speed_coeff = (float)(double)(*params)["speed_coefficient"];
+    params_.track_coeff = (float)(double)(*params)["track_coefficient"];
+    params_.max_slip_ang = (float)(double)(*params)["max_slip_angle"];
+    params_.slip_penalty = (float)(double)(*params)["slip_penalty"];
+    params_.track_slop = (float)(double)(*params)["track_slop"];
+    params_.crash_coeff = (float)(double)(*params)["crash_coeff"];
+    params_.steering_coeff = (float)(double)(*params)["steering_coeff"];
+    params_.throttle_coeff = (float)(double)(*params)["throttle_coeff"];
+    params_.boundary_threshold = (float)(double)(*params)["boundary_threshold"];
+    params_.discount = (float)(double)(*params)["discount"];
+    params_.num_timesteps = (int)(*params)["num_timesteps"];
+    version_++;
+  }
+
+  // loadTrackData, costs.cu:190-232: keys xBounds, yBounds, pixelsPerMeter, channel0..3 (float32)
+  void loadTrackData(const std::string &map_path)
+  {
+    if (!file_exists(map_path)) throw std::runtime_error("Could not load costmap at path: " + map_path);
+    npz_t d = npz_load(map_path);
+    for (const char *k : {"xBounds", "yBounds", "pixelsPerMeter", "channel0", "channel1", "channel2", "channel3"})
+      if (!d.count(k)) throw std::runtime_error(std::string("costmap file lacks key ") + k);
+    const float x_min = (float)d["xBounds"].at(0), x_max = (float)d["xBounds"].at(1);
+    const float y_min = (float)d["yBounds"].at(0), y_max = (float)d["yBounds"].at(1);
+    const float ppm = (float)d["pixelsPerMeter"].at(0);
+    width_ = int((x_max - x_min) * ppm);
+    height_ = int((y_max - y_min) * ppm);
+    const size_t n = (size_t)width_ * height_;
+    for (int c = 0; c < 4; c++)
+      if (d["channel" + std::to_string(c)].num_vals() < n) throw std::runtime_error("costmap channel too short");
+    track_costs_.assign(4 * n, 0.0f);
+    for (int c = 0; c < 4; c++) {
+      const NpyArray &ch = d["channel" + std::to_string(c)];
+      for (size_t i = 0; i < n; i++) track_costs_[4 * i + c] = (float)ch.at(i);
+    }
+    // R and trs, :224-229, stored column-wise by updateTransform :175-188
+    params_.r_c1[0] = 1.f / (x_max - x_min); params_.r_c1[1] = 0; params_.r_c1[2] = 0;
+    params_.r_c2[0] = 0; params_.r_c2[1] = 1.f / (y_max - y_min); params_.r_c2[2] = 0;
+    params_.trs[0] = -x_min / (x_max - x_min); params_.trs[1] = -y_min / (y_max - y_min); params_.trs[2] = 1;
+    map_version_++;
+  }
+
+  float getDesiredSpeed() const { return params_.desired_speed; }
+  void setDesiredSpeed(float v) { params_.desired_speed = v; version_++; }
+  // empty bodies in the reference too (costs.cu:297-299)
+  void updateCostmap(const std::vector<int> &, const std::vector<float> &) {}
+  void updateObstacles(const std::vector<int> &, const std::vector<float> &) {}
+
+  // paramsToDevice + costmapToTexture for one controller's handle
+  void paramsToDevice(mppi_handle *h, bool with_map)
+  {
+    if (with_map)
+      NeuralNetModel::check(mppi_set_costmap(h, width_, height_, track_costs_.data(), params_.r_c1, params_.r_c2, params_.trs), h);
+    mppi_cost_params p;
+    p.desired_speed = params_.desired_speed; p.speed_coeff = params_.speed_coeff; p.track_coeff = params_.track_coeff;
+    p.max_slip_ang = params_.max_slip_ang; p.slip_penalty = params_.slip_penalty; p.track_slop = params_.track_slop;
+    p.crash_coeff = params_.crash_coeff; p.steering_coeff = params_.steering_coeff; p.throttle_coeff = params_.throttle_coeff;
+    p.boundary_threshold = params_.boundary_threshold; p.discount = params_.discount; p.l1_cost = l1_cost_ ? 1 : 0;
+    NeuralNetModel::check(mppi_set_cost_params(h, &p), h);
+  }
+  unsigned version_ = 0, map_version_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+class MPPIController {
+ public:
+  static const int BLOCKSIZE_WRX = 64;
+  static const int STATE_DIM = 7, CONTROL_DIM = 2;
+  int NUM_ROLLOUTS;
+  int numTimesteps_, hz_, optimizationStride_;
+  NeuralNetModel *model_;
+  MPPICosts *costs_;
+
+  // MPPIController(model, costs, exploration_var, init_control, hz, num_timesteps,
+  //                optimization_stride, gamma, num_iters, stream), mppi_controller.cuh:101-102.
+  // `rollouts` replaces the ROLLOUTS template argument; rounded down to a multiple of 64 like
+  // NUM_ROLLOUTS (mppi_controller.cuh:58-60).  `device` replaces the cudaStream_t argument: each
+  // controller owns its own stream on that device.
+  MPPIController(NeuralNetModel *model, MPPICosts *costs, const float *exploration_var, const float *init_control,
+                 int hz, int num_timesteps, int optimization_stride, float gamma, int num_iters, int rollouts,
+                 int device = 0, unsigned long long seed = 1234ULL)
+      : NUM_ROLLOUTS((rollouts / BLOCKSIZE_WRX) * BLOCKSIZE_WRX), numTimesteps_(num_timesteps), hz_(hz),
+        optimizationStride_(optimization_stride), model_(model), costs_(costs)
+  {
+    mppi_config c{};
+    c.device = device;
+    c.num_rollouts = NUM_ROLLOUTS;
+    c.num_timesteps = num_timesteps;
+    c.hz = hz;
+    c.optimization_stride = optimization_stride;
+    c.gamma = gamma;
+    c.num_iters = num_iters;
+    c.n_layers = (int)model->net_structure_.size();
+    for (int i = 0; i < c.n_layers; i++) c.layers[i] = model->net_structure_[i];
+    for (int i = 0; i < 2; i++) {
+      c.exploration_std[i] = exploration_var[i];
+      c.init_control[i] = init_control[i];
+      c.control_min[i] = model->control_rngs_[i].x;
+      c.control_max[i] = model->control_rngs_[i].y;
+    }
+    c.negate_yaw_der = model->negate_yaw_der ? 1 : 0;
+    c.seed = seed;  // curandSetPseudoRandomGeneratorSeed(gen_, 1234ULL), mppi_controller.cu:331
+    const int rc = mppi_create(&c, &h_);
+    if (rc != MPPI_OK) throw std::runtime_error(std::string("mppi_create: ") + mppi_strerror(rc));
+    state_solution_.assign((size_t)numTimesteps_ * STATE_DIM, 0.0f);
+    control_solution_.assign((size_t)numTimesteps_ * CONTROL_DIM, 0.0f);
+    syncParams(true);
+  }
+  ~MPPIController() { deallocateCudaMem(); }
+  MPPIController(const MPPIController &) = delete;
+  MPPIController &operator=(const MPPIController &) = delete;
+
+  void deallocateCudaMem()
+  {
+    if (h_) mppi_destroy(h_);
+    h_ = nullptr;
+  }
+  mppi_handle *handle() { return h_; }
+
+  void resetControls() { ck(mppi_reset_controls(h_)); }
+  void cutThrottle()  // mppi_controller.cu:460-466
+  {
+    costs_->params_.desired_speed = 0.0f;
+    costs_->version_++;
+    model_->control_rngs_[1].y = 0.0f;
+    model_->touch();
+  }
+  // DDP feedback gains (mppi_controller.cu:402-445) are outside the hot path.
+  void computeFeedbackGains(const float *) {}
+
+  void slideControlAndStateSeq(int stride)
+  {
+    ck(mppi_slide_control_seq(h_, stride));       // slideControlSeq :527-554
+    for (int i = 0; i < numTimesteps_ - stride; i++)  // slideStateSeq :558-568
+      for (int j = 0; j < STATE_DIM; j++)
+        state_solution_[(size_t)i * STATE_DIM + j] = state_solution_[(size_t)(i + stride) * STATE_DIM + j];
+  }
+  void setState(const float *state)
+  {
+    for (int i = 0; i < STATE_DIM; i++) state_solution_[i] = state[i];  // (Q9's OOB column index not reproduced)
+  }
+  void setStateSequence(const std::vector<float> &s) { state_solution_ = s; }
+  void setControlSequence(const std::vector<float> &c) { control_solution_ = c; }
+
+  // computeControl(state), mppi_controller.cu:600-675
+  void computeControl(const float *state)
+  {
+    syncParams(false);  // costs_->paramsToDevice(); model_->paramsToDevice();  (:605-606), only when changed
+    ck(mppi_compute_control(h_, state));
+    float tc = 0.0f;
+    ck(mppi_get_results(h_, nullptr, &tc, nullptr, nullptr));
+    trajectory_cost_ = tc;
+    computeNominalTraj(state);
+  }
+  // computeControl(), :588-598: start from the predicted state (first entry of the state sequence)
+  void computeControl()
+  {
+    float s[STATE_DIM];
+    for (int i = 0; i < STATE_DIM; i++) s[i] = state_solution_[i];
+    computeControl(s);
+  }
+  void computeNominalTraj(const float *state)  // :501-519
+  {
+    ck(mppi_nominal_traj(h_, state, state_solution_.data(), control_solution_.data()));
+  }
+  std::vector<float> getControlSeq() { return control_solution_; }
+  std::vector<float> getStateSeq() { return state_solution_; }
+  float getComputedTrajectoryCost() { return trajectory_cost_; }
+  std::vector<float> getNominalControls()  // U_ after smoothing (what the next solve perturbs)
+  {
+    std::vector<float> U((size_t)numTimesteps_ * 2);
+    ck(mppi_get_control_seq(h_, U.data(), U.size()));
+    return U;
+  }
+
+ private:
+  void ck(int rc) { NeuralNetModel::check(rc, h_); }
+  void syncParams(bool force)
+  {
+    if (force || model_seen_ != model_->version_) {
+      model_->paramsToDevice(h_);
+      model_seen_ = model_->version_;
+      first_model_ = false;
+    }
+    if (force || cost_seen_ != costs_->version_ || map_seen_ != costs_->map_version_) {
+      costs_->paramsToDevice(h_, force || map_seen_ != costs_->map_version_);
+      cost_seen_ = costs_->version_;
+      map_seen_ = costs_->map_version_;
+    }
+  }
+  mppi_handle *h_ = nullptr;
+  float trajectory_cost_ = 0.0f;
+  std::vector<float> state_solution_, control_solution_;
+  unsigned model_seen_ = 0, cost_seen_ = 0, map_seen_ = 0;
+  bool first_model_ = true;
+};
+
+}  // namespace mppi_host

@@ -1,0 +1,148 @@
+// run_control_loop.hpp -- ROS-free runControlLoop (PI/run_control_loop.cuh:84-321).
+//
+// Same structure as the reference loop: two controllers (actual-state / predicted-state), slide by
+// the stride, computeControl(state) / computeControl(), arbitration by getComputedTrajectoryCost(),
+// hand the chosen solution to the plant, debug-mode self-simulation, profiler_max_iter stop.
+// The plant is a template parameter with the subset of AutorallyPlant the loop uses; SimPlant is the
+// headless stand-in (no pose source => status 1 => fixed stride, exactly the reference's debug_mode).
+#pragma once
+
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <thread>
+
+#include "mppi_controller_hip.hpp"
+
+namespace mppi_host {
+
+enum class ControllerType { NONE, ACTUAL_STATE, PREDICTED_STATE };
+
+struct SimPlant {
+  struct FullState { float x_pos = 0, y_pos = 0, yaw = 0, roll = 0, u_x = 0, u_y = 0, yaw_mder = 0; };
+  FullState fs;
+  std::vector<float> last_state_seq, last_control_seq;
+  ControllerType last_used = ControllerType::NONE;
+  int n_solutions = 0, n_actual = 0;
+  double avgLoop = 0, avgTick = 0, avgSleep = 0;
+  FullState getState() const { return fs; }
+  void setTimingInfo(double a, double b, double c) { avgLoop = a; avgTick = b; avgSleep = c; }
+  void setSolution(const std::vector<float> &ss, const std::vector<float> &cs, ControllerType used)
+  {
+    last_state_seq = ss;
+    last_control_seq = cs;
+    last_used = used;
+    n_solutions++;
+    if (used == ControllerType::ACTUAL_STATE) n_actual++;
+  }
+  int checkStatus() const { return 1; }  // no pose estimate: autorally_plant.cpp:443-459 returns 1
+};
+
+struct LoopStats {
+  int iterations = 0;
+  double avg_tick_ms = 0, avg_sleep_ms = 0;
+  std::array<float, 7> final_state{};
+};
+
+template <class CONTROLLER_T, class PLANT_T>
+LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T *actual_state_controller,
+                         PLANT_T *robot, ParamMap *params, std::atomic<bool> *is_alive, bool sleep_to_rate = true,
+                         FILE *trace = nullptr)
+{
+  const float x_pos = (float)(double)(*params)["x_pos"];
+  const float y_pos = (float)(double)(*params)["y_pos"];
+  const float heading = (float)(double)(*params)["heading"];
+  const int hz = (int)(*params)["hz"];
+  const int optimization_stride = (int)(*params)["optimization_stride"];
+  const int num_timesteps = (int)(*params)["num_timesteps"];
+  const bool debug_mode = (bool)(*params)["debug_mode"];
+  const bool only_actual = (bool)(*params)["use_only_actual_state_controller"];
+  const bool only_predicted = (bool)(*params)["use_only_predicted_state_controller"];
+  const int max_iter = params->count("profiler_max_iter") ? (int)(*params)["profiler_max_iter"] : INT_MAX;
+
+  float state[7] = {x_pos, y_pos, heading, 0, 0, 0, 0};
+  if (!debug_mode) {
+    const typename PLANT_T::FullState fs = robot->getState();
+    const float s[7] = {fs.x_pos, fs.y_pos, fs.yaw, fs.roll, fs.u_x, fs.u_y, fs.yaw_mder};
+    for (int i = 0; i < 7; i++) state[i] = s[i];
+  }
+  std::vector<float> controlSolution, stateSolution;
+  int num_iter = 0, status = 1;
+  double avgTick = 0, avgSleep = 0;
+  const std::chrono::duration<double, std::milli> period(optimization_stride * 1000.0 / hz);
+
+  actual_state_controller->setState(state);
+  predicted_state_controller->setState(state);
+  actual_state_controller->resetControls();
+  predicted_state_controller->resetControls();
+
+  while (is_alive->load() && num_iter < max_iter) {
+    const auto loop_start = std::chrono::steady_clock::now();
+    robot->setTimingInfo(0.0, avgTick, avgSleep);
+    num_iter++;
+    const int stride = optimization_stride;  // status != 0 => fixed stride (run_control_loop.cuh:208-211)
+    if (stride >= 0 && stride < num_timesteps) {
+      actual_state_controller->slideControlAndStateSeq(stride);
+      predicted_state_controller->slideControlAndStateSeq(stride);
+    }
+    actual_state_controller->computeControl(state);
+    predicted_state_controller->computeControl();
+
+    ControllerType to_use = ControllerType::NONE;
+    if (only_actual && !only_predicted) to_use = ControllerType::ACTUAL_STATE;
+    else if (!only_actual && only_predicted) to_use = ControllerType::PREDICTED_STATE;
+    ControllerType used = ControllerType::NONE;
+    if (to_use == ControllerType::ACTUAL_STATE ||
+        (to_use == ControllerType::NONE &&
+         actual_state_controller->getComputedTrajectoryCost() < predicted_state_controller->getComputedTrajectoryCost())) {
+      controlSolution = actual_state_controller->getControlSeq();
+      stateSolution = actual_state_controller->getStateSeq();
+      if (to_use == ControllerType::NONE) {  // :255-258
+        predicted_state_controller->setStateSequence(stateSolution);
+        predicted_state_controller->setControlSequence(controlSolution);
+      }
+      used = ControllerType::ACTUAL_STATE;
+    } else {
+      controlSolution = predicted_state_controller->getControlSeq();
+      stateSolution = predicted_state_controller->getStateSeq();
+      used = ControllerType::PREDICTED_STATE;
+    }
+    robot->setSolution(stateSolution, controlSolution, used);
+    status = robot->checkStatus();
+    if (status != 0 && debug_mode) {
+      // :296-302 -- both controllers share ONE model object, so the reference advances `state`
+      // twice per executed control (model_->updateState is called through each controller)
+      for (int t = 0; t < optimization_stride; t++) {
+        float u[2] = {controlSolution[2 * t], controlSolution[2 * t + 1]};
+        actual_state_controller->model_->updateState(state, u);
+        predicted_state_controller->model_->updateState(state, u);
+      }
+    }
+    if (trace)
+      fprintf(trace, "%d %s %.6f %.6f | %.5f %.5f %.5f %.5f %.5f | %.5f %.5f\n", num_iter,
+              used == ControllerType::ACTUAL_STATE ? "actual" : "predicted",
+              actual_state_controller->getComputedTrajectoryCost(),
+              predicted_state_controller->getComputedTrajectoryCost(), state[0], state[1], state[2], state[4],
+              state[5], controlSolution[0], controlSolution[1]);
+    std::chrono::duration<double, std::milli> fp_ms = std::chrono::steady_clock::now() - loop_start;
+    const double tick = fp_ms.count();
+    while (sleep_to_rate && is_alive->load() && fp_ms < period) {
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+      fp_ms = std::chrono::steady_clock::now() - loop_start;
+    }
+    const double sleep = fp_ms.count() - tick;
+    avgTick = (num_iter - 1.0) / num_iter * avgTick + tick / num_iter;
+    avgSleep = (num_iter - 1.0) / num_iter * avgSleep + sleep / num_iter;
+  }
+  LoopStats st;
+  st.iterations = num_iter;
+  st.avg_tick_ms = avgTick;
+  st.avg_sleep_ms = avgSleep;
+  for (int i = 0; i < 7; i++) st.final_state[i] = state[i];
+  return st;
+}
+
+}  // namespace mppi_host

@@ -1,0 +1,100 @@
+"""C++ host layer above the C ABI: cnpy-format .npz reader, launch-XML loader (CPU), and the
+ROS-free path_integral_nn binary checked against the same loop driven from Python (GPU)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from autorally_amd import build as B
+from autorally_amd import params as P
+from autorally_amd import synthetic as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAUNCH = os.path.join(ROOT, "autorally_amd", "host", "launch", "path_integral_nn.launch")
+
+
+@pytest.fixture(scope="module")
+def bins():
+    B.build()
+    return dict((os.path.basename(p), p) for p in B.build_host())
+
+
+def test_host_selftest(bins, golden_dir, tmp_path):
+    r = subprocess.run([bins["host_selftest"], os.path.join(golden_dir, "models", "autorally_nnet_09_12_2018.npz"),
+                        LAUNCH, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert "host selftest OK" in r.stdout
+    # the value the C++ reader printed equals numpy's view of the same file
+    z = np.load(os.path.join(golden_dir, "models", "autorally_nnet_09_12_2018.npz"))
+    assert "W1[0,0]=%.17g" % z["dynamics_W1"][0, 0] in r.stdout
+    # and the map the C++ writer produced loads with numpy (cnpy/numpy interoperability)
+    m = np.load(os.path.join(str(tmp_path), "selftest_map.npz"))
+    assert m["channel0"].dtype == np.float32 and m["channel0"].shape == (96,)
+    assert m["xBounds"].tolist() == [-3.0, 3.0]
+
+
+def _params_dir(tmp_path, golden_dir):
+    d = os.path.join(str(tmp_path), "params")
+    os.makedirs(os.path.join(d, "models"))
+    os.makedirs(os.path.join(d, "maps"))
+    src = os.path.join(golden_dir, "models", "autorally_nnet_09_12_2018.npz")
+    with open(src, "rb") as f, open(os.path.join(d, "models", "autorally_nnet_09_12_2018.npz"), "wb") as g:
+        g.write(f.read())
+    ch0, xb, yb, ppm = S.oval_track_map()
+    P.save_costmap_npz(os.path.join(d, "maps", "ccrf_costmap_09_29_2017.npz"), ch0, xb, yb, ppm)
+    return d
+
+
+@pytest.mark.gpu
+def test_path_integral_nn_binary_matches_python_loop(bins, golden_dir, tmp_path):
+    """20 ticks of the two-controller loop (debug-mode self-simulation): the C++ binary (launch XML
+    -> .npz files -> controller classes) and a Python loop over the same C ABI must agree."""
+    from autorally_amd import capi
+    d = _params_dir(tmp_path, golden_dir)
+    K, iters = 1024, 20
+    start = (0.0, -10.0, 0.0)
+    env = dict(os.environ, AR_MPPI_PARAMS_PATH=d)
+    r = subprocess.run([bins["path_integral_nn"], LAUNCH, "--rollouts", str(K), "--max-iter", str(iters), "--no-sleep",
+                        "--set", "x_pos=%r" % start[0], "--set", "y_pos=%r" % start[1], "--set", "heading=%r" % start[2],
+                        "--trace", os.path.join(str(tmp_path), "trace.txt")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["iterations"] == iters and out["rollouts"] == K
+
+    # the same loop from Python
+    layers, theta = P.load_model_npz(os.path.join(d, "models", "autorally_nnet_09_12_2018.npz"))
+    m, r_c1, r_c2, trs = P.load_costmap_npz(os.path.join(d, "maps", "ccrf_costmap_09_29_2017.npz"))
+    cfg = dict(K=K, T=100, layers=layers, theta=theta, map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs,
+               cost=dict(P.DEFAULT_COST), seed=1234)
+    cfg.update(P.DEFAULT_CTRL)
+    actual, predicted = capi.Solver(cfg), capi.Solver(cfg)
+    state = np.array([start[0], start[1], start[2], 0, 0, 0, 0], np.float32)
+    pred_state_seq = np.zeros((100, 7), np.float32)
+    pred_state_seq[0] = state
+    from oracle import oracle as O  # host twin of model->updateState for the debug-mode self-simulation
+    orc = O.Oracle(dict(cfg, start_state=state), fma_mode=1)
+    n_actual = 0
+    for it in range(iters):
+        actual.slide_control_seq(1)
+        predicted.slide_control_seq(1)
+        pred_state_seq[:-1] = pred_state_seq[1:].copy()
+        actual.compute_control(state)
+        a_ss, a_cs = actual.nominal_traj(state)
+        ps = pred_state_seq[0].copy()
+        predicted.compute_control(ps)
+        p_ss, p_cs = predicted.nominal_traj(ps)
+        ca, cp = actual.get_results(False)["traj_cost"], predicted.get_results(False)["traj_cost"]
+        if ca < cp:
+            cs, pred_state_seq = a_cs, a_ss.copy()
+            n_actual += 1
+        else:
+            cs, pred_state_seq = p_cs, p_ss.copy()
+        u = cs[0].copy()
+        state, _ = orc.update_state(state, u)   # the reference advances the state twice per tick
+        state, _ = orc.update_state(state, u)   # (shared model object, run_control_loop.cuh:299-300)
+    np.testing.assert_allclose(out["final_state"], state, atol=2e-4, rtol=1e-4)
+    assert out["actual_state_used"] == n_actual
+    assert abs(state[4]) > 0.5  # the car actually drove
