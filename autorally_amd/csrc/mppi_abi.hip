@@ -10,8 +10,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -71,8 +73,17 @@ struct mppi_handle {
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 64;
+  int block_threads = 128;  // 128: split (dynamics wave + cost wave), 64/256: single-wave form
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // side stream: noise of the NEXT iteration, beside the rollout
+  hipEvent_t ev_main_pos = nullptr, ev_noise_done = nullptr;
+  bool prefetch_enabled = true;
+  bool prefetch_valid = false;  // noise slot `prefetch_slot` holds the next iteration's draws
+  int prefetch_slot = 0, cur_slot = 0, n_slots = 2;
+  bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
+  unsigned seq = 0;             // sequence number of the last enqueued solve (published in h_res[3])
+  unsigned *d_counter = nullptr;
+  float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
 
   std::vector<float> U, hist, theta, map_rgba;
   int map_w = 0, map_h = 0;
@@ -92,7 +103,6 @@ struct mppi_handle {
   int noise_L = 1, noise_C = 1;
   float *h_in = nullptr, *h_res = nullptr;
   int explicit_iters = 0;  // >0: d_noise holds that many explicit iterations for the next solve
-  int last_noise_slot = 0;
   bool pending = false;       // a solve is enqueued, results not yet collected
   bool pending_timed = false;
   float traj_cost = 0.0f, baseline = 0.0f, eta = 0.0f;
@@ -310,14 +320,6 @@ int upload_rng_tables(mppi_handle *h)
   return MPPI_OK;
 }
 
-int enqueue_noise(mppi_handle *h, float *dst)
-{
-  HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T,
-                         h->noise_L, h->noise_C, dst, h->stream));
-  h->rng_cur = 1 - h->rng_cur;
-  return MPPI_OK;
-}
-
 int check_ready(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
@@ -327,74 +329,135 @@ int check_ready(mppi_handle *h)
   return MPPI_OK;
 }
 
-int collect(mppi_handle *h)
+// Makes `slot` hold the draws of the next solve iteration and orders the main stream behind them.
+int acquire_noise(mppi_handle *h, int *slot_out)
 {
-  // after the stream is idle: adopt the results of the pending solve
+  if (h->prefetch_valid) {
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_noise_done, 0));
+    *slot_out = h->prefetch_slot;
+    h->prefetch_valid = false;
+    return MPPI_OK;
+  }
+  const int slot = h->cur_slot ^ 1;
+  const size_t sz = (size_t)h->K * h->T * 2;
+  HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
+                         h->noise_C, h->d_noise + (size_t)slot * sz, h->stream));
+  h->rng_cur = 1 - h->rng_cur;
+  *slot_out = slot;
+  return MPPI_OK;
+}
+
+// Generates the draws of the iteration AFTER the one that is about to run, on the side stream,
+// into the other slot.  Call right before launching the rollout that consumes `busy_slot`.
+int prefetch_noise(mppi_handle *h, int busy_slot)
+{
+  if (!h->prefetch_enabled) return MPPI_OK;
+  const int slot = busy_slot ^ 1;
+  const size_t sz = (size_t)h->K * h->T * 2;
+  // the other slot was last read by the previous iteration's tail kernel, which precedes this
+  // point of the main stream
+  HIPCHK(h, hipEventRecord(h->ev_main_pos, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_main_pos, 0));
+  HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
+                         h->noise_C, h->d_noise + (size_t)slot * sz, h->stream2));
+  h->rng_cur = 1 - h->rng_cur;
+  HIPCHK(h, hipEventRecord(h->ev_noise_done, h->stream2));
+  h->prefetch_valid = true;
+  h->prefetch_slot = slot;
+  return MPPI_OK;
+}
+
+int upload_controls_if_dirty(mppi_handle *h)
+{
+  if (!h->u_dirty) return MPPI_OK;
+  memcpy(h->h_in, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
+  memcpy(h->h_in + 2 * h->T, h->hist.data(), sizeof(float) * 4);
+  HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipMemcpyHostToDevice,
+                           h->stream));
+  h->u_dirty = false;
+  return MPPI_OK;
+}
+
+// Waits for the pending solve: polls the sequence number the tail kernel publishes (system-scope
+// release) in the host-mapped result block; no stream synchronise on the fast path.
+int wait_pending(mppi_handle *h)
+{
   if (!h->pending) return MPPI_OK;
+  volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(h->h_res) + 3;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != h->seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {
+      if (hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != h->seq)
+        return fail(h, MPPI_ERR_HIP, "solve finished without publishing its result block");
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+        return fail(h, MPPI_ERR_HIP, "timed out waiting for the solve");
+    }
+  }
   h->pending = false;
   h->baseline = h->h_res[0];
   h->eta = h->h_res[1];
   h->traj_cost = h->h_res[2];
-  memcpy(h->U.data(), h->h_res + 4, sizeof(float) * 2 * (size_t)h->T);
+  memcpy(h->U.data(), h->h_res + 4, sizeof(float) * 2 * (size_t)h->T);  // device U == host U again
   if (h->pending_timed) {
     h->pending_timed = false;
     for (size_t it = 0; it < h->ev.size(); it++) {
-      float ms[5] = {0, 0, 0, 0, 0};
-      for (int i = 0; i < 5; i++) hipEventElapsedTime(&ms[i], h->ev[it].e[i], h->ev[it].e[i + 1]);
+      HIPCHK(h, hipEventSynchronize(h->ev[it].e[3]));
+      float ms[3] = {0, 0, 0};
+      for (int i = 0; i < 3; i++) (void)hipEventElapsedTime(&ms[i], h->ev[it].e[i], h->ev[it].e[i + 1]);
       h->acc.noise_ms += ms[0];
       h->acc.rollout_ms += ms[1];
-      h->acc.weights_ms += ms[2];
-      h->acc.reduction_ms += ms[3] + ms[4];
-      h->acc.total_ms += ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+      h->acc.reduction_ms += ms[2];
+      h->acc.total_ms += ms[0] + ms[1] + ms[2];
     }
     h->acc.n_solves += 1;
   }
   return MPPI_OK;
 }
 
+int collect(mppi_handle *h) { return wait_pending(h); }
+
 int enqueue_solve(mppi_handle *h, const float *state)
 {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!state) return fail(h, MPPI_ERR_INVALID, "state is NULL");
-  if (h->pending) {  // finish the previous asynchronous solve first
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    collect(h);
-  }
+  rc = wait_pending(h);  // finish a previous asynchronous solve first
+  if (rc) return rc;
   const int K = h->K, T = h->T, iters = h->cfg.num_iters;
   if (h->explicit_iters > 0 && h->explicit_iters != iters)
     return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
-  memcpy(h->h_in, h->U.data(), sizeof(float) * 2 * (size_t)T);
-  memcpy(h->h_in + 2 * T, h->hist.data(), sizeof(float) * 4);
-  HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_in, sizeof(float) * (2 * (size_t)T + 4), hipMemcpyHostToDevice,
-                           h->stream));
+  rc = upload_controls_if_dirty(h);
+  if (rc) return rc;
   const bool timed = h->timing;
-  const size_t slot = (size_t)K * T * 2;
+  const bool explicit_noise = h->explicit_iters > 0;
+  const size_t slot_sz = (size_t)K * T * 2;
+  h->seq++;
   for (int it = 0; it < iters; it++) {
-    float *noise = h->d_noise + (h->explicit_iters > 0 ? (size_t)it * slot : 0);
-    h->last_noise_slot = (h->explicit_iters > 0) ? it : 0;
     Events *ev = timed ? &h->ev[it] : nullptr;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[0], h->stream));
-    if (h->explicit_iters == 0) {
-      rc = enqueue_noise(h, noise);
+    int slot = it;
+    if (!explicit_noise) {
+      rc = acquire_noise(h, &slot);
       if (rc) return rc;
     }
+    float *noise = h->d_noise + (size_t)slot * slot_sz;
+    h->cur_slot = slot;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], h->stream));
+    if (!explicit_noise) {
+      rc = prefetch_noise(h, slot);
+      if (rc) return rc;
+    }
     RolloutArgs a;
     fill_rollout_args(h, state, noise, a);
     rc = launch_rollout(h, a);
     if (rc) return rc;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
-    HIPCHK(h, launch_weights(h->d_costs, K, h->cfg.gamma, h->d_w, h->d_wn, h->d_scal, h->stream));
+    HIPCHK(h, launch_solve_tail(h->d_costs, noise, h->d_in, h->d_in + 2 * T, h->d_w, h->d_scal, h->d_res_map,
+                                h->d_counter, K, T, h->cfg.gamma, it == iters - 1 ? 1 : 0, h->seq, h->stream));
     if (ev) HIPCHK(h, hipEventRecord(ev->e[3], h->stream));
-    HIPCHK(h, launch_weighted_reduction(h->d_wn, noise, K, T, h->d_in, h->stream));
-    if (ev) HIPCHK(h, hipEventRecord(ev->e[4], h->stream));
-    if (it == iters - 1)
-      HIPCHK(h, launch_savgol(h->d_in, h->d_in + 2 * T, T, h->d_scal, h->d_res, 1, h->stream));
-    if (ev) HIPCHK(h, hipEventRecord(ev->e[5], h->stream));
   }
-  HIPCHK(h, hipMemcpyAsync(h->h_res, h->d_res, sizeof(float) * (4 + 2 * (size_t)T), hipMemcpyDeviceToHost,
-                           h->stream));
   h->explicit_iters = 0;
   h->pending = true;
   h->pending_timed = timed;
@@ -409,6 +472,10 @@ void free_all(mppi_handle *h)
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
+  if (h->d_counter) (void)hipFree(h->d_counter);
+  if (h->ev_main_pos) (void)hipEventDestroy(h->ev_main_pos);
+  if (h->ev_noise_done) (void)hipEventDestroy(h->ev_noise_done);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
   for (uint32_t *p : up)
     if (p) (void)hipFree(p);
@@ -521,10 +588,20 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     }                                                                   \
   } while (0)
   CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CR(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  CR(hipEventCreateWithFlags(&h->ev_main_pos, hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&h->ev_noise_done, hipEventDisableTiming));
+  // Generating the next iteration's noise beside the rollout hides ~7 us of kernel time but the
+  // extra waves slow the latency-critical dynamics wavefronts by more (measured, K=4096): off by
+  // default, MPPI_NOISE_PREFETCH=1 turns it on.
+  h->prefetch_enabled = getenv("MPPI_NOISE_PREFETCH") != nullptr;
+  h->n_slots = std::max(2, cfg->num_iters);
   CR(hipMalloc(&h->d_in, sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_res, sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_scal, sizeof(float) * 4));
-  CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)cfg->num_iters));
+  CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)h->n_slots));
+  CR(hipMalloc(&h->d_counter, sizeof(unsigned)));
+  CR(hipMemset(h->d_counter, 0, sizeof(unsigned)));
   CR(hipMalloc(&h->d_stage, sizeof(float) * KT2));
   CR(hipMalloc(&h->d_costs, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_w, sizeof(float) * h->K));
@@ -538,7 +615,13 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_sub, sizeof(uint32_t) * 18 * 32));
   CR(hipMalloc(&h->d_one, sizeof(uint32_t) * 18 * 64));
   CR(hipHostMalloc(&h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
-  CR(hipHostMalloc(&h->h_res, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
+  CR(hipHostMalloc(&h->h_res, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocMapped));
+  memset(h->h_res, 0, sizeof(float) * (2 * (size_t)h->T + 4));
+  {
+    void *dp = nullptr;
+    CR(hipHostGetDevicePointer(&dp, h->h_res, 0));
+    h->d_res_map = static_cast<float *>(dp);
+  }
   CR(hipMalloc(&h->d_invt, sizeof(double) * (size_t)h->T));
   {
     std::vector<double> invt((size_t)h->T, 0.0);
@@ -567,6 +650,7 @@ int mppi_destroy(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
   (void)hipSetDevice(h->cfg.device);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_all(h);
   return MPPI_OK;
@@ -676,17 +760,27 @@ int mppi_set_cost_params(mppi_handle *h, const mppi_cost_params *p)
 int mppi_reset_controls(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
   for (int t = 0; t < h->T; t++) {
     h->U[2 * t] = h->cfg.init_control[0];
     h->U[2 * t + 1] = h->cfg.init_control[1];
   }
+  h->u_dirty = true;
   return MPPI_OK;
 }
 
 int mppi_set_control_seq(mppi_handle *h, const float *U, size_t n)
 {
   if (!h || !U || n != 2 * (size_t)h->T) return MPPI_ERR_INVALID;
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
   memcpy(h->U.data(), U, n * sizeof(float));
+  h->u_dirty = true;
   return MPPI_OK;
 }
 
@@ -705,6 +799,7 @@ int mppi_set_control_hist(mppi_handle *h, const float hist[4])
 {
   if (!h || !hist) return MPPI_ERR_INVALID;
   memcpy(h->hist.data(), hist, 4 * sizeof(float));
+  h->u_dirty = true;
   return MPPI_OK;
 }
 
@@ -738,6 +833,11 @@ int mppi_slide_control_seq(mppi_handle *h, int stride)
     for (int j = 0; j < 2; j++) U[i * 2 + j] = U[(i + stride) * 2 + j];
   for (int j = 1; j <= stride; j++)
     for (int i = 0; i < 2; i++) U[(T - j) * 2 + i] = h->cfg.init_control[i];
+  // the same slide on the device copy, so that solve -> slide -> solve never re-uploads U
+  if (!h->u_dirty) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, launch_slide(h->d_in, T, stride, h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
+  }
   return MPPI_OK;
 }
 
@@ -745,7 +845,12 @@ int mppi_seed(mppi_handle *h, uint64_t seed, uint64_t offset)
 {
   if (!h) return MPPI_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  int rc = seed_device(h, seed, offset);
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream2));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->prefetch_valid = false;  // prefetched draws belong to the old stream position
+  rc = seed_device(h, seed, offset);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
@@ -757,6 +862,17 @@ int mppi_set_noise(mppi_handle *h, const float *eps, size_t n)
   const size_t slot = (size_t)h->K * h->T * 2;
   if (n != slot * (size_t)h->cfg.num_iters) return fail(h, MPPI_ERR_INVALID, "noise size != num_iters*K*T*2");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream2));
+    if (h->prefetch_valid) {
+      // explicit slots overwrite the prefetched draws: rewind the generator by one iteration is not
+      // possible, so keep them by regenerating later from the saved stream position
+      h->prefetch_valid = false;
+      h->rng_cur = 1 - h->rng_cur;  // the state before the prefetch is still in the other buffer
+    }
+  }
   for (int it = 0; it < h->cfg.num_iters; it++) {
     HIPCHK(h, hipMemcpyAsync(h->d_stage, eps + (size_t)it * slot, slot * sizeof(float),
                              hipMemcpyHostToDevice, h->stream));
@@ -770,13 +886,17 @@ int mppi_set_noise(mppi_handle *h, const float *eps, size_t n)
 int mppi_generate_noise(mppi_handle *h, float *eps_out, size_t n)
 {
   if (!h || !eps_out) return MPPI_ERR_INVALID;
-  const size_t slot = (size_t)h->K * h->T * 2;
-  if (n != slot) return fail(h, MPPI_ERR_INVALID, "n != K*T*2");
+  const size_t slot_sz = (size_t)h->K * h->T * 2;
+  if (n != slot_sz) return fail(h, MPPI_ERR_INVALID, "n != K*T*2");
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  int rc = enqueue_noise(h, h->d_noise);
+  int rc = mppi_synchronize(h);
   if (rc) return rc;
-  HIPCHK(h, launch_tk_to_kt(h->d_noise, h->d_stage, h->K, h->T, h->stream));
-  HIPCHK(h, hipMemcpyAsync(eps_out, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  int slot = 0;
+  rc = acquire_noise(h, &slot);
+  if (rc) return rc;
+  h->cur_slot = slot;
+  HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)slot * slot_sz, h->d_stage, h->K, h->T, h->stream));
+  HIPCHK(h, hipMemcpyAsync(eps_out, h->d_stage, slot_sz * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
 }
@@ -791,9 +911,7 @@ int mppi_compute_control_async(mppi_handle *h, const float state[MPPI_STATE_DIM]
 int mppi_synchronize(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->cfg.device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return collect(h);
+  return wait_pending(h);
 }
 
 int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM])
@@ -810,6 +928,10 @@ int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, f
   if (rc) return rc;
   if (U) memcpy(U, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
   if (traj_cost) *traj_cost = h->traj_cost;
+  if (costs || weights) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   if (costs) HIPCHK(h, hipMemcpy(costs, h->d_costs, sizeof(float) * h->K, hipMemcpyDeviceToHost));
   if (weights) HIPCHK(h, hipMemcpy(weights, h->d_w, sizeof(float) * h->K, hipMemcpyDeviceToHost));
   return MPPI_OK;
@@ -822,7 +944,8 @@ int mppi_get_applied_controls(mppi_handle *h, float *V, size_t n)
   if (n != slot) return fail(h, MPPI_ERR_INVALID, "n != K*T*2");
   int rc = mppi_synchronize(h);
   if (rc) return rc;
-  HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)h->last_noise_slot * slot, h->d_stage, h->K, h->T, h->stream));
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)h->cur_slot * slot, h->d_stage, h->K, h->T, h->stream));
   HIPCHK(h, hipMemcpyAsync(V, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
@@ -836,18 +959,17 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   HIPCHK(h, hipSetDevice(h->cfg.device));
   rc = mppi_synchronize(h);
   if (rc) return rc;
-  memcpy(h->h_in, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
-  memcpy(h->h_in + 2 * h->T, h->hist.data(), sizeof(float) * 4);
-  HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipMemcpyHostToDevice,
-                           h->stream));
+  rc = upload_controls_if_dirty(h);
+  if (rc) return rc;
+  int slot = 0;
   if (h->explicit_iters == 0) {
-    rc = enqueue_noise(h, h->d_noise);
+    rc = acquire_noise(h, &slot);
     if (rc) return rc;
   }
   h->explicit_iters = 0;
-  h->last_noise_slot = 0;
+  h->cur_slot = slot;
   RolloutArgs a;
-  fill_rollout_args(h, state, h->d_noise, a);
+  fill_rollout_args(h, state, h->d_noise + (size_t)slot * h->K * h->T * 2, a);
   rc = launch_rollout(h, a);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(costs, h->d_costs, sizeof(float) * h->K, hipMemcpyDeviceToHost, h->stream));
@@ -933,7 +1055,8 @@ const char *mppi_rollout_variant(const mppi_handle *h)
   if (!h) return "";
   if (!use_mfma(h)) return "valu_lds";
   static thread_local char buf[64];
-  snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_b%d", h->hidden, h->n_hidden, h->block_threads);
+  snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
+           h->block_threads == 128 ? "split2w" : (h->block_threads == 256 ? "fused_b256" : "fused_b64"));
   return buf;
 }
 
@@ -945,7 +1068,8 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     if (!h->mfma_ok) return fail(h, MPPI_ERR_UNSUPPORTED, "MFMA variant needs 6-HxN-4 with H in {32,64}, N in {2,4}");
     h->variant_pref = 1;
   } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
-  else if (strcmp(name, "block64") == 0) h->block_threads = 64;
+  else if (strcmp(name, "split") == 0) h->block_threads = 128;
+  else if (strcmp(name, "fused") == 0 || strcmp(name, "block64") == 0) h->block_threads = 64;
   else if (strcmp(name, "block256") == 0) h->block_threads = 256;
   else return fail(h, MPPI_ERR_INVALID, "unknown variant");
   return MPPI_OK;

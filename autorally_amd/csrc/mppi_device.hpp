@@ -70,7 +70,24 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
 // saturates correctly (+-1) for large |x|, keeps NaN.
 __device__ __forceinline__ float tanh_fast(float x)
 {
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 12
+  return x * 0.25f;
+#endif
   const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);  // exp(2x)
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return fmaf(-2.0f, r, 1.0f);
+}
+
+// tanh(z + b) with the bias pre-scaled on the host side of the loop: bs = b * 2*log2(e), so that the
+// exp2 argument is ONE fma of the layer's dot product (z + b is never rounded separately; the
+// difference to tanh_fast(z + b) is one rounding of the exp2 argument, below its own error).
+constexpr float kTanhScale = 2.88539008177792681472f;
+__device__ __forceinline__ float tanh_bias(float z, float bs)
+{
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 12
+  return (z + bs) * 0.25f;
+#endif
+  const float e = __builtin_amdgcn_exp2f(fmaf(z, kTanhScale, bs));
   const float r = __builtin_amdgcn_rcpf(e + 1.0f);
   return fmaf(-2.0f, r, 1.0f);
 }

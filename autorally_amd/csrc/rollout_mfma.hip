@@ -33,6 +33,21 @@ struct MfmaNet {
   static constexpr int nPack = nA + nBias;  // floats per lane in wpack
 };
 
+// Loads a lane's A-operand and bias slices; hidden-layer biases are pre-scaled for tanh_bias.
+template <int H, int NHID>
+__device__ __forceinline__ void load_weights(const float *wpack, int lane, float (&A)[MfmaNet<H, NHID>::nA],
+                                             float (&Bi)[MfmaNet<H, NHID>::nBias])
+{
+  using N = MfmaNet<H, NHID>;
+#pragma unroll
+  for (int i = 0; i < N::nA; i++) A[i] = wpack[i * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < N::nBias; i++) {
+    const float b = wpack[(N::nA + i) * 64 + lane];
+    Bi[i] = (i < NHID * N::MT * 4) ? b * kTanhScale : b;
+  }
+}
+
 // The network is evaluated in three pieces so that the rollout step can place independent
 // cost / kinematics arithmetic next to each piece (they execute in the shadow of the MFMAs).
 //
@@ -70,7 +85,7 @@ __device__ __forceinline__ void nn_hidden(const float (&A)[MfmaNet<H, NHID>::nA]
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_fast(acc[m][r] + Bi[boff + m * 4 + r]);
+      for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_bias(acc[m][r], Bi[boff + m * 4 + r]);
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -95,7 +110,7 @@ __device__ __forceinline__ void nn_last(const float (&A)[MfmaNet<H, NHID>::nA],
 #pragma unroll
   for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_fast(acc[m][r] + Bi[boff + m * 4 + r]);
+    for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_bias(acc[m][r], Bi[boff + m * 4 + r]);
   f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < KSH; s++)
@@ -128,10 +143,7 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
   const int k = wave * kRolloutsPerWave + j;
 
   float A[N::nA], Bi[N::nBias];
-#pragma unroll
-  for (int i = 0; i < N::nA; i++) A[i] = a.wpack[i * 64 + lane];
-#pragma unroll
-  for (int i = 0; i < N::nBias; i++) Bi[i] = a.wpack[(N::nA + i) * 64 + lane];
+  load_weights<H, NHID>(a.wpack, lane, A, Bi);
 
   float s[kStateDim];
 #pragma unroll
@@ -213,6 +225,131 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
   if (g == 0) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
 }
 
+// ---------------------------------------------------------------------------------------------
+// rollout_split_kernel: the same rollout with the work of a 16-rollout group split over TWO
+// wavefronts of one workgroup (they land on two SIMDs of a CU; at K = 4096 three quarters of the
+// chip's SIMDs are idle anyway):
+//   wave 0 "dynamics": controls + clamp + network + Euler update of [roll, u_x, u_y, yaw_mder].
+//          The learned dynamics do not depend on x, y, yaw, so this wave IS the T-step recurrence
+//          and nothing else sits on it.
+//   wave 1 "cost":     x, y, yaw kinematics, sin/cos, the two costmap fetches, MPPICosts::computeCost,
+//          the running mean and the crash flags -- consuming the per-step record
+//          (s3..s6 before the update, clamped u, du) that wave 0 leaves in an LDS ring.
+// The ring holds two phases of kPhaseSteps steps; one workgroup barrier per phase (not per step)
+// hands a phase over, so both waves run concurrently, wave 1 one phase behind.  Arithmetic and its
+// order are exactly those of rollout_mfma_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPhaseSteps = 10;
+
+template <int H, int NHID, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(128) void rollout_split_kernel(const RolloutArgs a)
+{
+  using N = MfmaNet<H, NHID>;
+  __shared__ __attribute__((aligned(16))) float ring[2][kPhaseSteps][kRolloutsPerWave][8];
+  const int lane = threadIdx.x & 63;
+  const int role = threadIdx.x >> 6;  // wave-uniform
+  const int j = lane & 15, g = lane >> 4;
+  const int k = blockIdx.x * kRolloutsPerWave + j;
+  const int K = a.K, T = a.T;
+  const int phases = (T + kPhaseSteps - 1) / kPhaseSteps;
+
+  if (role == 0) {
+    // ------------------------------ dynamics wave ------------------------------
+    float A[N::nA], Bi[N::nBias];
+  load_weights<H, NHID>(a.wpack, lane, A, Bi);
+    float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
+    float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+    const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+    const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
+    const bool pure_noise_k = (k >= a.k99);  // :141
+    float2 eps = noise[(size_t)k];
+    float2 Unext = Useq[0];
+    for (int p = 0; p < phases; p++) {
+      const int t0 = p * kPhaseSteps, nq = min(kPhaseSteps, T - t0);
+      for (int q = 0; q < nq; q++) {
+        const int t = t0 + q;
+        const float2 e = eps;
+        const float2 Ut = Unext;
+        const int tn = min(t + 1, T - 1);
+        eps = noise[(size_t)tn * K + k];
+        Unext = Useq[tn];
+        // control perturbation, mppi_controller.cu:136-153
+        const bool nf = noise_free_k | (t < a.opt_delay);
+        const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+        const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+        float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
+        float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
+        noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+        // pin the two prefetches above: issued here, first used at the top of the NEXT step, so
+        // their latency never sits on the recurrence (the scheduler otherwise sinks them)
+        __builtin_amdgcn_sched_barrier(0);
+        u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+        u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+        // record for the cost wave: state BEFORE this step's update, clamped u, du
+        float2 rec;
+        rec.x = (g == 0) ? s3 : (g == 1) ? s5 : (g == 2) ? u0 : du0;
+        rec.y = (g == 0) ? s4 : (g == 1) ? s6 : (g == 2) ? u1 : du1;
+        *reinterpret_cast<float2 *>(&ring[p & 1][q][j][2 * g]) = rec;
+        float d[4];
+        nn_forward_mfma<H, NHID>(A, Bi, g, s3, s4, s5, s6, u0, u1, d);
+        s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
+        s4 = fmaf(d[1], a.dt, s4);
+        s5 = fmaf(d[2], a.dt, s5);
+        s6 = fmaf(d[3], a.dt, s6);
+      }
+#if !defined(MPPI_ABLATE) || MPPI_ABLATE < 10
+      __syncthreads();  // phase p is complete in LDS
+#endif
+    }
+#if defined(MPPI_ABLATE) && MPPI_ABLATE >= 10
+    a.costs[k] = s3 + s4 + s5 + s6;
+#endif
+  } else {
+#if defined(MPPI_ABLATE) && MPPI_ABLATE >= 10
+    return;
+#endif
+    // -------------------------------- cost wave --------------------------------
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int crash = 0;
+    float J = 0.0f;
+    double rt_next = a.inv_t[0];
+    for (int p = 0; p < phases; p++) {
+      __syncthreads();  // wait for phase p
+      const int t0 = p * kPhaseSteps, nq = min(kPhaseSteps, T - t0);
+      for (int q = 0; q < nq; q++) {
+        const int t = t0 + q;
+        const double rt = rt_next;
+        rt_next = a.inv_t[min(t + 1, T - 1)];
+        const float4 r0 = *reinterpret_cast<const float4 *>(&ring[p & 1][q][j][0]);  // s3 s4 s5 s6
+        const float4 r1 = *reinterpret_cast<const float4 *>(&ring[p & 1][q][j][4]);  // u0 u1 du0 du1
+        // getCrash of the previous step's update (costs.cu:301-305): r0.x is s3 after update t-1
+        crash |= (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));
+        float spsi, cpsi;
+        sincos_fast(yaw, spsi, cpsi);
+        const float st[3] = {x, y, yaw};
+        float tf, tb;
+        track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
+        CostTerms ct;
+        cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+        // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
+        const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
+        const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
+        const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
+        x = fmaf(sd0, a.dt, x);
+        y = fmaf(sd1, a.dt, y);
+        yaw = fmaf(sd2, a.dt, yaw);
+        // running mean over t = 1..T-1 (Q5); the t = 0 evaluation is discarded
+        int crash_new = crash;
+        const float c = cost_terms_b(a.cost, ct, tf, tb, crash_new);
+        const float Jn = running_mean(J, c, t, rt);
+        J = (t > 0) ? Jn : J;
+        crash = (t > 0) ? crash_new : crash;
+      }
+    }
+    a.costs[k] = J + 0.0f;  // + terminalCost (= 0); the 4 lanes of a rollout write the same value
+  }
+}
+
 // Debug/test entry: state derivative of n independent (state, control) pairs through the
 // same device functions as the rollout (used to check the golden vectors on the GPU).
 template <int H, int NHID>
@@ -224,10 +361,7 @@ __global__ __launch_bounds__(64) void dynamics_mfma_kernel(const float *wpack, c
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
   float A[N::nA], Bi[N::nBias];
-#pragma unroll
-  for (int i = 0; i < N::nA; i++) A[i] = wpack[i * 64 + lane];
-#pragma unroll
-  for (int i = 0; i < N::nBias; i++) Bi[i] = wpack[(N::nA + i) * 64 + lane];
+  load_weights<H, NHID>(wpack, lane, A, Bi);
   const int idx = blockIdx.x * kRolloutsPerWave + j;
   const int src = idx < n ? idx : n - 1;
   float s[kStateDim];
@@ -251,10 +385,18 @@ __global__ __launch_bounds__(64) void dynamics_mfma_kernel(const float *wpack, c
 template <int H, int NHID>
 static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipStream_t stream)
 {
+  const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
+  if (block_threads == 128) {  // split form: one dynamics wave + one cost wave per 16 rollouts
+    const dim3 grid(a.K / kRolloutsPerWave), block(128);
+    if (affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
+    else if (affine && ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
+    else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rollout_split_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   const int waves = a.K / kRolloutsPerWave;
   const int wpb = block_threads / 64;
   const dim3 grid((waves + wpb - 1) / wpb), block(block_threads);
-  const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   if (affine && !ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
   else if (affine && ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
   else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, false, false>), grid, block, 0, stream, a);

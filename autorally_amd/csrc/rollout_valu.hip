@@ -36,8 +36,8 @@ __device__ __forceinline__ void nn_forward_valu(const NetDev &net, const float *
       float tmp = 0.0f;
       const float *Wr = W + jn * nin;
       for (int kk = 0; kk < nin; kk++) tmp = fmaf(Wr[kk], cur[kk * kValuLanes + lane], tmp);
-      tmp += b[jn];
-      if (hidden) tmp = tanh_fast(tmp);
+      // same formula as the MFMA kernel (tanh_bias) so that the two arms stay bit-identical
+      tmp = hidden ? tanh_bias(tmp, b[jn] * kTanhScale) : tmp + b[jn];
       nxt[jn * kValuLanes + lane] = tmp;
     }
     off += nout * nin + nout;

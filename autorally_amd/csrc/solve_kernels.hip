@@ -6,13 +6,28 @@
 namespace mppi {
 
 // ---------------------------------------------------------------------------------------------
-// weights: beta = min_k J_k ; w_k = expf(-gamma (J_k - beta)) ; eta = sum w ; traj = sum w^2/eta
-// Reference: host loops + normExpKernel, mppi_controller.cu:627-652, 193-203 (two D2H round
-// trips and two stream syncs there; one single-workgroup kernel here, results stay in HBM).
-// Sums are pairwise (LDS tree) instead of the host's sequential fp32 loop: same value to ~1e-7.
-// scal[0]=beta scal[1]=eta scal[2]=trajectory_cost
+// solve_tail_kernel: everything of one solve iteration after the rollout, in ONE launch.
+//
+//   beta = min_k J_k ; w_k = expf(-gamma (J_k - beta)) ; eta = sum_k w_k ; traj = sum_k w_k^2/eta
+//       reference: host loops + normExpKernel, mppi_controller.cu:627-652, 193-203 (two D2H round
+//       trips and two stream syncs there)
+//   Unew[t][j] = sum_m ( sum_{k=64m..64m+63} (w_k/eta) * V[t][k][j] )
+//       reference: weightedReductionKernel, mppi_controller.cu:219-267 -- block t, thread m walks 64
+//       rollouts in order with an fma per step, thread 0 adds the partials in order.  Same order
+//       here, so U is bit-identical to the reference order given the same weights.
+//   U = SavitzkyGolay([hist | Unew | pad])   (last iteration only), mppi_controller.cu:468-499
+//
+// Grid = T workgroups (one per timestep).  Every workgroup recomputes beta and eta from the K
+// costs (16 KB at K=4096, L2 resident; same code in every workgroup => the same bits), stages its
+// row V[t][*][*] (K*8 contiguous bytes of the time-major buffer) through LDS with 16-B loads and runs
+// the (m, j) chains.  The workgroup that finishes last (agent-scope release / acquire around an
+// arrival counter, MI355X guide G16) smooths the sequence and writes the single result block --
+// (beta, eta, trajectory cost, sequence number) + U -- straight into host-mapped memory, so the
+// host needs no D2H copy and no stream synchronise: it polls the sequence number.
+// Sums over k are pairwise (LDS tree) instead of the host's sequential loop: same value to ~1e-7.
 // ---------------------------------------------------------------------------------------------
-constexpr int kWeightsThreads = 1024;
+constexpr int kTailThreads = 256;
+constexpr int kRedChunk = 4096;  // rollouts staged per pass: 32 KiB of LDS (+ pad)
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -26,103 +41,101 @@ __device__ __forceinline__ float wave_sum(float v)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-
-__global__ __launch_bounds__(kWeightsThreads) void weights_kernel(const float *__restrict__ costs,
-                                                                   int K, float gamma,
-                                                                   float *__restrict__ w,
-                                                                   float *__restrict__ wn,
-                                                                   float *__restrict__ scal)
+__device__ __forceinline__ float block_min(float v, float *red, float *bc)
 {
-  __shared__ float red[kWeightsThreads / 64];
-  __shared__ float bcast;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float m = INFINITY;
-  for (int k = tid; k < K; k += kWeightsThreads) m = fminf(m, costs[k]);
-  m = wave_min(m);
-  if (lane == 0) red[wv] = m;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  v = wave_min(v);
+  if (lane == 0) red[wv] = v;
   __syncthreads();
-  if (wv == 0) {
-    float v = (lane < kWeightsThreads / 64) ? red[lane] : INFINITY;
-    v = wave_min(v);
-    if (lane == 0) bcast = v;
+  if (threadIdx.x == 0) {
+    float m = red[0];
+    for (int i = 1; i < kTailThreads / 64; i++) m = fminf(m, red[i]);
+    *bc = m;
   }
   __syncthreads();
-  const float beta = bcast;
+  const float r = *bc;
   __syncthreads();
-  float part = 0.0f;
-  for (int k = tid; k < K; k += kWeightsThreads) {
-    const float cost2go = costs[k] - beta;
-    const float e = expf(-gamma * cost2go);  // normExpKernel :201
-    w[k] = e;
-    part += e;
-  }
-  part = wave_sum(part);
-  if (lane == 0) red[wv] = part;
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float *red, float *bc)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) red[wv] = v;
   __syncthreads();
-  if (wv == 0) {
-    float v = (lane < kWeightsThreads / 64) ? red[lane] : 0.0f;
-    v = wave_sum(v);
-    if (lane == 0) bcast = v;
+  if (threadIdx.x == 0) {
+    float m = red[0];
+    for (int i = 1; i < kTailThreads / 64; i++) m += red[i];
+    *bc = m;
   }
   __syncthreads();
-  const float eta = bcast;
+  const float r = *bc;
   __syncthreads();
-  float tc = 0.0f;
-  for (int k = tid; k < K; k += kWeightsThreads) {
-    const float e = w[k];  // written by this same thread above
-    tc += e * e / eta;     // :651 (Q8)
-    wn[k] = e / eta;       // the per-use divide of weightedReductionKernel :244, hoisted
-  }
-  tc = wave_sum(tc);
-  if (lane == 0) red[wv] = tc;
-  __syncthreads();
-  if (wv == 0) {
-    float v = (lane < kWeightsThreads / 64) ? red[lane] : 0.0f;
-    v = wave_sum(v);
-    if (lane == 0) {
-      scal[0] = beta;
-      scal[1] = eta;
-      scal[2] = v;
-    }
-  }
+  return r;
 }
 
-// ---------------------------------------------------------------------------------------------
-// weighted reduction: Unew[t][j] = sum_m ( sum_{k=64m..64m+63} wn[k] * V[t][k][j] )
-// Reference: weightedReductionKernel, mppi_controller.cu:219-267 -- block t, thread m walks 64
-// rollouts in order with an fma per step, thread 0 adds the partials in order.  Same summation
-// order here, so the result is bit-identical to the reference order given the same wn.
-// One workgroup per timestep; the row V[t][*][*] (K*2 contiguous floats in the time-major
-// buffer) is staged through LDS in coalesced 16-B loads, then each lane runs one (m, j) chain.
-// ---------------------------------------------------------------------------------------------
-constexpr int kRedThreads = 256;
-constexpr int kRedChunk = 4096;  // rollouts staged per pass: 32 KiB of LDS (+ pad)
+struct TailArgs {
+  const float *costs;   // [K]
+  const float *V;       // [T][K][2] applied controls of this iteration
+  float *U;             // [T][2] in/out: receives Unew, smoothed in place on the last iteration
+  const float *hist;    // [4]
+  float *w;             // [K] exp weights (for mppi_get_results)
+  float *scal;          // [3] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup)
+  float *res;           // host-mapped result block: [beta, eta, traj, seq-bits | U(2T)]
+  unsigned *counter;    // arrival counter, zero on entry, reset by the last workgroup
+  int K, T;
+  float gamma;
+  int last_iter;        // smooth + publish results
+  unsigned seq;         // sequence number published in res[3] once everything else is visible
+};
 
-__global__ __launch_bounds__(kRedThreads) void weighted_reduction_kernel(
-    const float *__restrict__ wn, const float *__restrict__ V, int K, float *__restrict__ Unew)
+__global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs a)
 {
   // chunk rows padded by 2 floats per 64-rollout group: lanes of one wave (m varies) hit
   // distinct banks when they walk their chains in lock step.
   __shared__ __attribute__((aligned(16))) float tile[kRedChunk * 2 + (kRedChunk / 64) * 2];
   __shared__ float wtile[kRedChunk];
-  extern __shared__ float partial[];  // [K/64][2]
+  __shared__ float red[kTailThreads / 64];
+  __shared__ float bc;
+  __shared__ int is_last;
+  extern __shared__ float dyn[];  // partial[K/64][2], then X[(T+4)*2] for the smoothing
+  float *partial = dyn;
   const int t = blockIdx.x, tid = threadIdx.x;
-  const float *row = V + (size_t)t * K * 2;
-  const int groups = K / 64;
+  const int K = a.K, T = a.T;
+
+  // ---- weights: beta, eta (every workgroup), w[] and the trajectory cost (workgroup 0) ----
+  float m = INFINITY;
+  for (int k = tid; k < K; k += kTailThreads) m = fminf(m, a.costs[k]);
+  const float beta = block_min(m, red, &bc);
+  float part = 0.0f;
+  for (int k = tid; k < K; k += kTailThreads) part += expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
+  const float eta = block_sum(part, red, &bc);
+  float traj = 0.0f;
+  if (t == 0) {
+    float tc = 0.0f;
+    for (int k = tid; k < K; k += kTailThreads) {
+      const float e = expf(-a.gamma * (a.costs[k] - beta));
+      a.w[k] = e;
+      tc += e * e / eta;  // :651 (Q8)
+    }
+    traj = block_sum(tc, red, &bc);
+  }
+
+  // ---- weighted reduction of row t ----
+  const float *row = a.V + (size_t)t * K * 2;
   for (int base = 0; base < K; base += kRedChunk) {
     const int n = min(kRedChunk, K - base);  // multiple of 64
-    // stage: n*2 floats, float4 per lane
     const float4 *src = reinterpret_cast<const float4 *>(row + (size_t)base * 2);
-    for (int q = tid; q < n / 2; q += kRedThreads) {
+    for (int q = tid; q < n / 2; q += kTailThreads) {
       const float4 v = src[q];  // rollouts base+2q, base+2q+1
       const int kk = 2 * q;
       const int o = kk * 2 + (kk >> 6) * 2;
       tile[o + 0] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
     }
-    for (int q = tid; q < n; q += kRedThreads) wtile[q] = wn[base + q];
+    for (int q = tid; q < n; q += kTailThreads)
+      wtile[q] = expf(-a.gamma * (a.costs[base + q] - beta)) / eta;  // weight = w/normalizer, :244
     __syncthreads();
-    // chains: c = (m_local, j)
-    for (int c = tid; c < (n / 64) * 2; c += kRedThreads) {
+    for (int c = tid; c < (n / 64) * 2; c += kTailThreads) {
       const int ml = c >> 1, j = c & 1;
       const float *p = tile + ml * 130 + j;
       const float *wp = wtile + ml * 64;
@@ -135,34 +148,46 @@ __global__ __launch_bounds__(kRedThreads) void weighted_reduction_kernel(
   }
   if (tid < 2) {
     float u = 0.0f;
-    for (int m = 0; m < groups; m++) u += partial[m * 2 + tid];  // :256-260
-    Unew[t * 2 + tid] = u;
+    for (int mm = 0; mm < K / 64; mm++) u += partial[mm * 2 + tid];  // :256-260
+    a.U[t * 2 + tid] = u;
   }
-}
+  if (t == 0 && tid == 0) {  // scalars travel with workgroup 0's release below
+    a.scal[0] = beta;
+    a.scal[1] = eta;
+    a.scal[2] = traj;
+  }
 
-// ---------------------------------------------------------------------------------------------
-// savitskyGolay, mppi_controller.cu:468-499. In place on U[T][2]; hist[4]; one workgroup.
-// res[0..2] <- scal (beta, eta, traj cost) and res[4 ..] <- smoothed U so that ONE D2H copy
-// returns everything the host needs.
-// ---------------------------------------------------------------------------------------------
-__global__ void savgol_kernel(float *__restrict__ U, const float *__restrict__ hist, int T,
-                              const float *__restrict__ scal, float *__restrict__ res, int smooth)
-{
-  extern __shared__ float X[];  // [(T+4)][2]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (T + 4) * 2; i += blockDim.x) {
-    const int r = i >> 1, j = i & 1;
-    float v;
-    if (r < 2) v = hist[2 * r + j];
-    else if (r < T + 2) v = U[2 * (r - 2) + j];
-    else v = U[2 * (T - 1) + j];
-    X[i] = v;
+  // ---- arrival: the last workgroup smooths and publishes (G16: stores -> barrier -> lane-0
+  // agent release -> counter; last arriver: agent acquire -> barrier -> loads) ----
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = atomicAdd(a.counter, 1u);
+    is_last = (ticket == (unsigned)T - 1u) ? 1 : 0;
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
-  const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
-  for (int i = tid; i < T * 2; i += blockDim.x) {
-    float out;
-    if (smooth) {
+  if (!is_last) return;
+  if (tid == 0) *a.counter = 0u;  // ready for the next launch on this stream
+  if (!a.last_iter) return;       // more iterations follow: U stays the raw weighted mean
+  float *X = dyn + (K / 64) * 2;  // [(T+4)][2]
+  for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
+    const int r = i >> 1, j = i & 1;
+    float v;
+    if (r < 2) v = a.hist[2 * r + j];
+    else if (r < T + 2) v = __builtin_nontemporal_load(&a.U[2 * (r - 2) + j]);
+    else v = __builtin_nontemporal_load(&a.U[2 * (T - 1) + j]);
+    X[i] = v;
+  }
+  if (tid < 3) a.res[tid] = __builtin_nontemporal_load(&a.scal[tid]);
+  __syncthreads();
+  {
+    const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
+    for (int i = tid; i < T * 2; i += kTailThreads) {
       float acc = f0 * X[i];
       float p = f1 * X[i + 2];
       acc = acc + p;
@@ -172,14 +197,42 @@ __global__ void savgol_kernel(float *__restrict__ U, const float *__restrict__ h
       acc = acc + p;
       p = f0 * X[i + 8];
       acc = acc + p;
-      out = acc;
-    } else {
-      out = X[i + 4];
+      a.U[i] = acc;
+      a.res[4 + i] = acc;
     }
-    U[i] = out;
-    res[4 + i] = out;
   }
-  if (tid < 3) res[tid] = scal[tid];
+  __syncthreads();  // every wave's result stores have completed (vmcnt(0) precedes the barrier)
+  if (tid == 0) {
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned *>(a.res) + 3, a.seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
+// solve -> slide -> solve loop never re-uploads the sequence.  One workgroup; mirrors the host code.
+__global__ void slide_kernel(float *__restrict__ in, int T, int stride, float init0, float init1)
+{
+  extern __shared__ float buf[];  // old U
+  float *U = in, *hist = in + 2 * T;
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) buf[i] = U[i];
+  float hold = 0.0f;
+  if (threadIdx.x < 4) hold = hist[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int i = threadIdx.x;
+    float hv;
+    if (stride == 1) hv = (i < 2) ? __shfl(hold, i + 2) : buf[i - 2];
+    else hv = buf[(stride - 2) + i];  // flat-index quirk (Q15)
+    hist[i] = hv;
+  }
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {
+    const int r = i >> 1, j = i & 1;
+    float v;
+    if (r < T - stride) v = buf[(r + stride) * 2 + j];
+    else v = j ? init1 : init0;
+    U[i] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -219,28 +272,22 @@ __global__ void tk_to_kt_kernel(const float2 *__restrict__ src, float2 *__restri
 }
 
 // ---- launchers ----
-hipError_t launch_weights(const float *costs, int K, float gamma, float *w, float *wn, float *scal,
-                          hipStream_t stream)
+hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
+                             float *scal, float *res, unsigned *counter, int K, int T, float gamma,
+                             int last_iter, unsigned seq, hipStream_t stream)
 {
-  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightsThreads), 0, stream, costs, K, gamma, w,
-                     wn, scal);
+  TailArgs a;
+  a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter;
+  a.K = K; a.T = T; a.gamma = gamma; a.last_iter = last_iter; a.seq = seq;
+  const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2) * sizeof(float);
+  hipLaunchKernelGGL(solve_tail_kernel, dim3(T), dim3(kTailThreads), dyn, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_weighted_reduction(const float *wn, const float *V, int K, int T, float *Unew,
-                                     hipStream_t stream)
+hipError_t launch_slide(float *in, int T, int stride, float init0, float init1, hipStream_t stream)
 {
-  const size_t dyn = (size_t)(K / 64) * 2 * sizeof(float);
-  hipLaunchKernelGGL(weighted_reduction_kernel, dim3(T), dim3(kRedThreads), dyn, stream, wn, V, K,
-                     Unew);
-  return hipGetLastError();
-}
-
-hipError_t launch_savgol(float *U, const float *hist, int T, const float *scal, float *res, int smooth,
-                         hipStream_t stream)
-{
-  const size_t dyn = (size_t)(T + 4) * 2 * sizeof(float);
-  hipLaunchKernelGGL(savgol_kernel, dim3(1), dim3(256), dyn, stream, U, hist, T, scal, res, smooth);
+  hipLaunchKernelGGL(slide_kernel, dim3(1), dim3(256), (size_t)2 * T * sizeof(float), stream, in, T, stride,
+                     init0, init1);
   return hipGetLastError();
 }
 

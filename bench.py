@@ -3,10 +3,15 @@
 
 A "step" is one full MPPI solve through the C ABI (mppi_compute_control: device noise generation,
 rollout, weighting, weighted reduction, Savitzky-Golay; blocking, incl. the small H2D/D2H of
-U/state/results) followed by the control-loop's slideControlSeq(1) warm start.
+U/state/results) followed by the control loop's slideControlSeq(1) warm start.
 N=1 workload = BASELINE.json configs[2]: K=4096, T=100, 6-32-32-4 shipped weights, CCRF-like oval
 costmap written to / loaded from .npz.  N>1 = configs[4]: independent instances, one per GPU
-(distinct costmaps + start states), no collective on the data path ("replicas only").
+(distinct costmaps + start states), no collective on the data path ("replicas only"); the process
+group is used for the barrier and the max-over-ranks time only.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
@@ -20,29 +25,62 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-FLOP_PER_UPDATE = {(32, 2): 2756, (64, 2): 9604}   # MAC=2, bias add=1
-BYTES_PER_UPDATE = 32                              # SURVEY 8(d) algorithmic HBM bytes
-PEAK_F32_MFMA_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense f32 MFMA/vector
+BYTES_PER_UPDATE = 32            # algorithmic HBM bytes per state update (whole solve)
+ROLLOUT_BYTES_PER_UPDATE = 16    # of which the rollout kernel: read 8 + write back 8
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
 
 
 def flops_per_update(layers):
-    f = 0
-    for a, b in zip(layers[:-1], layers[1:]):
-        f += 2 * a * b + b
-    return f
+    """MAC = 2, bias add = 1, no transcendentals: 2756 for 6-32-32-4, 9604 for 6-64-64-4."""
+    return sum(2 * a * b + b for a, b in zip(layers[:-1], layers[1:]))
+
+
+def init_dist(backend):
+    """(rank, local_rank, world, dist-or-None); one process per GPU, env from torch.distributed.run."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return rank, local_rank, world, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return rank, local_rank, world, dist
+
+
+def rank_workload(args, rank):
+    """Instance `rank` of BASELINE configs[4]: its own costmap (rotated/offset oval), start state
+    and RNG seed.  Rank 0 alone is configs[2]."""
+    from autorally_amd import synthetic as S
+    layers = [int(x) for x in args.layers.split("-")] if args.layers else None
+    return S.make_config(args.K, args.T, layers=layers, track="oval", instance=rank, seed=1234 + rank)
+
+
+def max_over_ranks(dist, value, cuda):
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def cpu_baseline(cfg, budget_s=12.0):
-    """The CPU oracle (a C port of the reference kernels, OpenMP over rollouts) timed on this
-    host on the SAME workload: a bounded sample of whole solves."""
+    """The CPU oracle (C port of the reference kernels, OpenMP over rollouts) timed on this host on
+    the SAME workload: a bounded sample of whole solves."""
     from oracle import oracle as O
-    # the GPU box gives one GPU's share of host cores (16); never oversubscribe
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))
+    threads = max(1, min(avail, 16))  # one GPU's share of the box's host cores
     orc = O.Oracle(cfg, fma_mode=1, nthreads=threads)
     K, T = cfg["K"], cfg["T"]
     U = np.zeros((T, 2), np.float32)
@@ -55,11 +93,36 @@ def cpu_baseline(cfg, budget_s=12.0):
         U = r["U"]
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 200:
+        if el >= budget_s or n >= 400:
             break
     return {"value": K * n / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
-            "sample": "%d full solves (rollout+weights+reduction+SG, explicit noise) of K=%d T=%d in %.1f s"
+            "sample": "%d full solves (rollout+weights+reduction+SG on pre-generated noise) of K=%d T=%d in %.1f s"
                       % (n, K, T, el)}
+
+
+class _OracleStandIn:
+    """--selftest-cpu only: stands in for the HIP solver so that the multi-process driver logic
+    (rank workloads, barrier, max-over-ranks, aggregation) can be exercised with gloo on a CPU-only
+    machine.  Never used for a reported number."""
+
+    def __init__(self, cfg):
+        from oracle import oracle as O
+        self.O, self.cfg = O, cfg
+        self.orc = O.Oracle(cfg, fma_mode=1, nthreads=1)
+        self.U = np.zeros((cfg["T"], 2), np.float32)
+        self.hist = np.zeros(4, np.float32)
+        self.n = 0
+
+    def compute_control(self, state):
+        eps = self.O.generate_noise(self.cfg["seed"], 2 * self.cfg["T"] * self.n, self.cfg["K"], self.cfg["T"])[None]
+        self.U = self.orc.compute_control(state, self.U, self.hist, eps)["U"]
+        self.n += 1
+
+    def slide_control_seq(self, stride):
+        self.U, self.hist = self.orc.slide_control_seq(self.U, self.hist, self.cfg["init_u"], stride)
+
+    def get_control_seq(self):
+        return self.U
 
 
 def main():
@@ -73,38 +136,40 @@ def main():
     ap.add_argument("--variant", type=str, default="auto")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="exercise the multi-process driver with gloo and the CPU oracle (no GPU, not a benchmark)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    selftest = args.selftest_cpu
+    rank, local_rank, world, dist = init_dist("gloo" if selftest else "nccl")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    cuda = not selftest
+    if cuda:
+        import torch
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from autorally_amd import build as B
+        if rank == 0:
+            B.build()
+        if dist is not None:
+            dist.barrier()
+        from autorally_amd import capi
+
+    cfg = rank_workload(args, rank)
+    if selftest:
+        sol = _OracleStandIn(cfg)
     else:
-        torch.cuda.set_device(local_rank)
-
-    from autorally_amd import build as B
-    if rank == 0:
-        B.build()
-    if dist is not None:
-        dist.barrier()
-    from autorally_amd import capi
-    from autorally_amd import synthetic as S
-
-    layers = [int(x) for x in args.layers.split("-")] if args.layers else None
-    cfg = S.make_config(args.K, args.T, layers=layers, track="oval", instance=rank, seed=1234 + rank)
-    sol = capi.Solver(cfg, device=local_rank)
-    if args.variant != "auto":
-        sol.set_rollout_variant(args.variant)
-    if args.block:
-        sol.set_rollout_variant("block%d" % args.block)
+        sol = capi.Solver(cfg, device=local_rank)  # raises without the HIP library / a gfx950 device
+        if args.variant != "auto":
+            sol.set_rollout_variant(args.variant)
+        if args.block:
+            sol.set_rollout_variant("block%d" % args.block)
     state = cfg["start_state"].copy()
+
+    def sync():
+        if cuda:
+            torch.cuda.synchronize()
 
     def step():
         sol.compute_control(state)
@@ -112,54 +177,68 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sol.enable_stage_timing(True)
-    sol.reset_stage_times()
+    if cuda:
+        sol.enable_stage_timing(True)
+        sol.reset_stage_times()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    st = sol.get_stage_times()
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0, cuda)
+
+    # what every rank ran (proves the instances are distinct), gathered off the timed region
+    mine = {"rank": rank, "start_state": [round(float(x), 4) for x in cfg["start_state"]],
+            "map_checksum": float(np.asarray(cfg["map_rgba"], dtype=np.float64).sum()),
+            "U0": [round(float(x), 5) for x in sol.get_control_seq()[0]]}
+    instances = [mine]
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        instances = [None] * world
+        dist.all_gather_object(instances, mine)
 
     if rank == 0:
         K, T = cfg["K"], cfg["T"]
         iters = cfg.get("num_iters", 1)
         value = K * iters * args.steps * world / elapsed
-        rollout_s = st["rollout_ms"] * 1e-3 / max(1, st["n_solves"]) / iters
-        fl = flops_per_update(cfg["layers"])
-        ach_tflops = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
         out = {
             "metric": "trajectory rollouts/s per MPPI solve",
             "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if cuda else "selftest-cpu (oracle stand-in, NOT a benchmark)",
             "config": {"workload": "K=%d T=%d %s NN dynamics, CCRF-like oval costmap via .npz, "
                                    "one independent MPPI instance per GPU" % (K, T, "-".join(map(str, cfg["layers"]))),
                        "K": K, "T": T, "layers": cfg["layers"], "num_iters": iters,
-                       "rollout_variant": sol.rollout_variant(), "parallelism": "replicas x%d (no collective)" % world},
+                       "rollout_variant": sol.rollout_variant() if cuda else "none",
+                       "parallelism": "replicas x%d (no collective)" % world},
             "state_updates_per_s": value * T,
-            "stage_ms": {k: (st[k] / max(1, st["n_solves"])) for k in
-                         ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")},
-            "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "rollout", "kernel_ms": rollout_s * 1e3,
-                         "flop_per_state_update": fl,
-                         "hbm_algorithmic_GBps": BYTES_PER_UPDATE * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0},
+            "instances": instances,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+        if cuda:
+            st = sol.get_stage_times()
+            n = max(1, st["n_solves"])
+            rollout_s = st["rollout_ms"] * 1e-3 / n / iters
+            fl = flops_per_update(cfg["layers"])
+            ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
+            out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
+            out["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "rollout (%s)" % sol.rollout_variant(), "kernel_ms": rollout_s * 1e3,
+                "flop_per_state_update": fl, "state_updates_per_launch": K * T,
+                "algorithmic_bytes_per_launch": ROLLOUT_BYTES_PER_UPDATE * K * T,
+                "algorithmic_GBps": ROLLOUT_BYTES_PER_UPDATE * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
+                "hbm_peak_GBps": PEAK_HBM_GBPS,
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    sol.close()
+    if cuda:
+        sol.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

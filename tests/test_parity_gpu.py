@@ -113,7 +113,7 @@ def test_rollout_costs_and_controls(K, T, track, layers, variant):
     # neighbouring texel (the oracle's own FMA / no-FMA builds disagree on the same rollouts).
     # Such rollouts must be few and the weight they move must be negligible.
     assert bad <= K // 200, (bad, float(err.max()))
-    assert float(np.max(err[err <= 1e-4])) < 2e-5
+    assert float(np.percentile(err, 99)) < 5e-6  # away from the discontinuities the agreement is tight
     wsum = float(ref["w"].sum())
     assert float(np.abs(got["w"] - ref["w"]).sum()) / wsum < 1e-4
     assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
@@ -136,6 +136,20 @@ def test_mfma_and_valu_variants_agree_bitwise():
     _, b = _solve_both(cfg, U0=U0, variant="valu")
     assert a["variant"].startswith("mfma") and b["variant"].startswith("valu")
     np.testing.assert_array_equal(a["costs"].view(np.uint32), b["costs"].view(np.uint32))
+    np.testing.assert_array_equal(a["U"].view(np.uint32), b["U"].view(np.uint32))
+
+
+@pytest.mark.parametrize("K,T,track,layers", [(512, 43, "oval", None), (256, 30, "ring", [6, 64, 64, 4])])
+def test_split_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
+    """The two-wave (dynamics + cost) form does the same arithmetic in the same order as the
+    single-wave form; T is not a multiple of the LDS ring's phase length on purpose."""
+    cfg = S.make_config(K, T, layers=layers, track=track)
+    U0 = warm_U(cfg)
+    _, a = _solve_both(cfg, U0=U0, variant="fused")
+    _, b = _solve_both(cfg, U0=U0, variant="split")
+    assert "fused" in a["variant"] and "split" in b["variant"]
+    np.testing.assert_array_equal(a["costs"].view(np.uint32), b["costs"].view(np.uint32))
+    np.testing.assert_array_equal(a["V"].view(np.uint32), b["V"].view(np.uint32))
     np.testing.assert_array_equal(a["U"].view(np.uint32), b["U"].view(np.uint32))
 
 
