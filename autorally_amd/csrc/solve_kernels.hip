@@ -5,6 +5,10 @@
 
 namespace mppi {
 
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 23
+#define expf(x) (1.0f + (x))
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // solve_tail_kernel: everything of one solve iteration after the rollout, in ONE launch.
 //
@@ -17,7 +21,7 @@ namespace mppi {
 //       here, so U is bit-identical to the reference order given the same weights.
 //   U = SavitzkyGolay([hist | Unew | pad])   (last iteration only), mppi_controller.cu:468-499
 //
-// Grid = T workgroups (one per timestep).  Every workgroup recomputes beta and eta from the K
+// Grid = T workgroups (one per timestep) + one that publishes the weights and scalars.  Every workgroup recomputes beta and eta from the K
 // costs (16 KB at K=4096, L2 resident; same code in every workgroup => the same bits), stages its
 // row V[t][*][*] (K*8 contiguous bytes of the time-major buffer) through LDS with 16-B loads and runs
 // the (m, j) chains.  The workgroup that finishes last (agent-scope release / acquire around an
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   // chunk rows padded by 2 floats per 64-rollout group: lanes of one wave (m varies) hit
   // distinct banks when they walk their chains in lock step.
   __shared__ __attribute__((aligned(16))) float tile[kRedChunk * 2 + (kRedChunk / 64) * 2];
-  __shared__ float wtile[kRedChunk];
+  __shared__ float wtile[kRedChunk + kRedChunk / 64];  // +1 float per 64-rollout group: see the chain loop
   __shared__ float red[kTailThreads / 64];
   __shared__ float bc;
   __shared__ int is_last;
@@ -104,86 +108,144 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   const int K = a.K, T = a.T;
 
   // ---- weights: beta, eta (every workgroup), w[] and the trajectory cost (workgroup 0) ----
+  // When all K weights fit the LDS tile (K <= kRedChunk) each exp is evaluated once per workgroup
+  // and kept there; otherwise it is re-evaluated per chunk (same bits either way).
+  const bool cached = (K <= kRedChunk);
+  // The first chunk of row t is requested NOW, before anything else, so that its HBM latency
+  // overlaps the latency of the cost vector and the weight arithmetic below (the row was written by
+  // the rollout kernel on other XCDs: it comes from HBM / Infinity Cache, not from this L2).
+  const bool extra = (t == T);  // the (T+1)-th workgroup: publishes w[], beta, eta, trajectory cost
+  const float *row = a.V + (size_t)(extra ? 0 : t) * K * 2;
+  constexpr int kPre = kRedChunk / 2 / kTailThreads;  // float4 per thread in a full chunk
+  float4 pre[kPre];
+  {
+    const int n0 = min(kRedChunk, K);
+    const float4 *src0 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+    for (int i = 0; i < kPre; i++) {
+      const int q = tid + i * kTailThreads;
+      pre[i] = (q < n0 / 2) ? src0[q] : make_float4(0, 0, 0, 0);
+    }
+  }
   float m = INFINITY;
   for (int k = tid; k < K; k += kTailThreads) m = fminf(m, a.costs[k]);
   const float beta = block_min(m, red, &bc);
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 20
+  if (tid == 0) a.U[t * 2] = beta + pre[0].x; return;
+#endif
   float part = 0.0f;
-  for (int k = tid; k < K; k += kTailThreads) part += expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
+  for (int k = tid; k < K; k += kTailThreads) {
+    const float e = expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
+    if (cached) wtile[k + (k >> 6)] = e;
+    part += e;
+  }
   const float eta = block_sum(part, red, &bc);
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 21
+  if (tid == 0) a.U[t * 2] = eta + pre[0].x; return;
+#endif
   float traj = 0.0f;
-  if (t == 0) {
+  if (extra) {
     float tc = 0.0f;
     for (int k = tid; k < K; k += kTailThreads) {
-      const float e = expf(-a.gamma * (a.costs[k] - beta));
+      const float e = cached ? wtile[k + (k >> 6)] : expf(-a.gamma * (a.costs[k] - beta));
       a.w[k] = e;
       tc += e * e / eta;  // :651 (Q8)
     }
     traj = block_sum(tc, red, &bc);
+    if (tid == 0) {
+      __hip_atomic_store(&a.scal[0], beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.scal[1], eta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.scal[2], traj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 
   // ---- weighted reduction of row t ----
-  const float *row = a.V + (size_t)t * K * 2;
-  for (int base = 0; base < K; base += kRedChunk) {
+  for (int base = 0; base < (extra ? 0 : K); base += kRedChunk) {
     const int n = min(kRedChunk, K - base);  // multiple of 64
     const float4 *src = reinterpret_cast<const float4 *>(row + (size_t)base * 2);
-    for (int q = tid; q < n / 2; q += kTailThreads) {
-      const float4 v = src[q];  // rollouts base+2q, base+2q+1
-      const int kk = 2 * q;
-      const int o = kk * 2 + (kk >> 6) * 2;
-      tile[o + 0] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+    if (base == 0) {
+#pragma unroll
+      for (int i = 0; i < kPre; i++) {
+        const int q = tid + i * kTailThreads;
+        if (q < n / 2) {
+          const int kk = 2 * q;
+          const int o = kk * 2 + (kk >> 6) * 2;
+          tile[o + 0] = pre[i].x; tile[o + 1] = pre[i].y; tile[o + 2] = pre[i].z; tile[o + 3] = pre[i].w;
+        }
+      }
+    } else {
+      for (int q = tid; q < n / 2; q += kTailThreads) {
+        const float4 v = src[q];  // rollouts base+2q, base+2q+1
+        const int kk = 2 * q;
+        const int o = kk * 2 + (kk >> 6) * 2;
+        tile[o + 0] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+      }
     }
-    for (int q = tid; q < n; q += kTailThreads)
-      wtile[q] = expf(-a.gamma * (a.costs[base + q] - beta)) / eta;  // weight = w/normalizer, :244
+    for (int q = tid; q < n; q += kTailThreads) {  // weight = w/normalizer, :244
+      const float e = cached ? wtile[q + (q >> 6)] : expf(-a.gamma * (a.costs[base + q] - beta));
+      wtile[q + (q >> 6)] = e / eta;
+    }
     __syncthreads();
     for (int c = tid; c < (n / 64) * 2; c += kTailThreads) {
       const int ml = c >> 1, j = c & 1;
       const float *p = tile + ml * 130 + j;
-      const float *wp = wtile + ml * 64;
+      const float *wp = wtile + ml * 65;  // row stride 65: the 16 groups of a half-wave hit 16 banks
       float acc = 0.0f;
-#pragma unroll 8
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 24
+      acc = wp[0] * p[0];
+#else
+#pragma unroll
       for (int i = 0; i < 64; i++) acc = fmaf(wp[i], p[2 * i], acc);  // u_system += weight*u :246
+#endif
       partial[(base / 64 + ml) * 2 + j] = acc;
     }
     __syncthreads();
   }
-  if (tid < 2) {
+  if (tid < 2 && !extra) {
     float u = 0.0f;
-    for (int mm = 0; mm < K / 64; mm++) u += partial[mm * 2 + tid];  // :256-260
-    a.U[t * 2 + tid] = u;
-  }
-  if (t == 0 && tid == 0) {  // scalars travel with workgroup 0's release below
-    a.scal[0] = beta;
-    a.scal[1] = eta;
-    a.scal[2] = traj;
-  }
-
-  // ---- arrival: the last workgroup smooths and publishes (G16: stores -> barrier -> lane-0
-  // agent release -> counter; last arriver: agent acquire -> barrier -> loads) ----
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = atomicAdd(a.counter, 1u);
-    is_last = (ticket == (unsigned)T - 1u) ? 1 : 0;
-    if (is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int groups = K / 64;
+    int mm = 0;
+    for (; mm + 16 <= groups; mm += 16) {  // partials fetched 16 at a time, added in order (:256-260)
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = partial[(mm + i) * 2 + tid];
+#pragma unroll
+      for (int i = 0; i < 16; i++) u += v[i];
     }
+    for (; mm < groups; mm++) u += partial[mm * 2 + tid];
+    // write-through (sc1) store: the hand-off to the last workgroup below needs no L2 write-back
+    __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#if defined(MPPI_ABLATE) && MPPI_ABLATE == 22
+  return;
+#endif
+  // ---- arrival: the last workgroup smooths and publishes.  Hand-off form R1 of the MI355X guide
+  // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
+  // (s_waitcnt vmcnt(0)) and only then one lane bumps the agent-scope counter; the last arriver
+  // reads every handed-off word with sc1 loads.  No buffer_wbl2 / buffer_inv on this path. ----
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (ticket == (unsigned)T) ? 1 : 0;  // T row workgroups + the extra one
   }
   __syncthreads();
   if (!is_last) return;
-  if (tid == 0) *a.counter = 0u;  // ready for the next launch on this stream
+  if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
   if (!a.last_iter) return;       // more iterations follow: U stays the raw weighted mean
   float *X = dyn + (K / 64) * 2;  // [(T+4)][2]
   for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
     const int r = i >> 1, j = i & 1;
     float v;
     if (r < 2) v = a.hist[2 * r + j];
-    else if (r < T + 2) v = __builtin_nontemporal_load(&a.U[2 * (r - 2) + j]);
-    else v = __builtin_nontemporal_load(&a.U[2 * (T - 1) + j]);
+    else if (r < T + 2) v = __hip_atomic_load(&a.U[2 * (r - 2) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else v = __hip_atomic_load(&a.U[2 * (T - 1) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     X[i] = v;
   }
-  if (tid < 3) a.res[tid] = __builtin_nontemporal_load(&a.scal[tid]);
+  // result block in host-mapped memory: relaxed system-scope stores (uncached, straight to PCIe)
+  if (tid < 3) {
+    const float v = __hip_atomic_load(&a.scal[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.res[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __syncthreads();
   {
     const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
@@ -198,15 +260,15 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
       p = f0 * X[i + 8];
       acc = acc + p;
       a.U[i] = acc;
-      a.res[4 + i] = acc;
+      __hip_atomic_store(&a.res[4 + i], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  __syncthreads();  // every wave's result stores have completed (vmcnt(0) precedes the barrier)
-  if (tid == 0) {
-    __threadfence_system();
-    __hip_atomic_store(reinterpret_cast<unsigned *>(a.res) + 3, a.seq, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  // every wave drains its result stores (vmcnt(0) precedes the barrier); posted PCIe writes keep
+  // their order, so the sequence number written afterwards is seen last by the polling host
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned *>(a.res) + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
@@ -280,7 +342,7 @@ hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const
   a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter;
   a.K = K; a.T = T; a.gamma = gamma; a.last_iter = last_iter; a.seq = seq;
   const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2) * sizeof(float);
-  hipLaunchKernelGGL(solve_tail_kernel, dim3(T), dim3(kTailThreads), dyn, stream, a);
+  hipLaunchKernelGGL(solve_tail_kernel, dim3(T + 1), dim3(kTailThreads), dyn, stream, a);
   return hipGetLastError();
 }
 
