@@ -75,11 +75,7 @@ struct mppi_handle {
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
   int block_threads = 128;  // 128: split (dynamics wave + cost wave), 64/256: single-wave form
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // side stream: noise of the NEXT iteration, beside the rollout
-  hipEvent_t ev_main_pos = nullptr, ev_noise_done = nullptr;
-  bool prefetch_enabled = true;
-  bool prefetch_valid = false;  // noise slot `prefetch_slot` holds the next iteration's draws
-  int prefetch_slot = 0, cur_slot = 0, n_slots = 2;
+  int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
   unsigned seq = 0;             // sequence number of the last enqueued solve (published in h_res[3])
   unsigned *d_counter = nullptr;
@@ -93,6 +89,9 @@ struct mppi_handle {
   bool have_nn = false, have_map = false, have_cost = false;
 
   float *d_in = nullptr, *d_res = nullptr, *d_scal = nullptr;
+  float *d_in_buf[2] = {nullptr, nullptr};  // d_in points at one of them; the tail kernel leaves the
+  int in_cur = 0;                            // stride-slid copy of [U | hist] in the other one
+  bool slid_valid = false;
   float *d_noise = nullptr, *d_stage = nullptr;
   float *d_costs = nullptr, *d_w = nullptr, *d_wn = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
@@ -203,6 +202,13 @@ bool use_mfma(const mppi_handle *h)
   return h->mfma_ok;
 }
 
+// the split MFMA kernel carries its own noise wavefront
+bool has_noise_wave(const mppi_handle *h)
+{
+  static const bool off = getenv("MPPI_NO_INLINE_NOISE") != nullptr;  // developer A/B switch
+  return !off && use_mfma(h) && h->block_threads == 128;
+}
+
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
 {
   const mppi_cost_params &p = h->cost;
@@ -252,6 +258,9 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   }
   a.dt = h->dt;
   a.negate_yaw_der = h->cfg.negate_yaw_der ? 1 : 0;
+  a.rng_in = nullptr;
+  a.rng_out = nullptr;
+  a.inline_noise = 0;
   fill_cost_args(h, a.cost);
 }
 
@@ -329,41 +338,16 @@ int check_ready(mppi_handle *h)
   return MPPI_OK;
 }
 
-// Makes `slot` hold the draws of the next solve iteration and orders the main stream behind them.
+// Stand-alone generator launch (mppi_generate_noise, and solves with a rollout variant that has no
+// noise wavefront): fills `slot` with the draws of the next solve iteration.
 int acquire_noise(mppi_handle *h, int *slot_out)
 {
-  if (h->prefetch_valid) {
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_noise_done, 0));
-    *slot_out = h->prefetch_slot;
-    h->prefetch_valid = false;
-    return MPPI_OK;
-  }
-  const int slot = h->cur_slot ^ 1;
+  const int slot = 0;
   const size_t sz = (size_t)h->K * h->T * 2;
   HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
                          h->noise_C, h->d_noise + (size_t)slot * sz, h->stream));
   h->rng_cur = 1 - h->rng_cur;
   *slot_out = slot;
-  return MPPI_OK;
-}
-
-// Generates the draws of the iteration AFTER the one that is about to run, on the side stream,
-// into the other slot.  Call right before launching the rollout that consumes `busy_slot`.
-int prefetch_noise(mppi_handle *h, int busy_slot)
-{
-  if (!h->prefetch_enabled) return MPPI_OK;
-  const int slot = busy_slot ^ 1;
-  const size_t sz = (size_t)h->K * h->T * 2;
-  // the other slot was last read by the previous iteration's tail kernel, which precedes this
-  // point of the main stream
-  HIPCHK(h, hipEventRecord(h->ev_main_pos, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_main_pos, 0));
-  HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
-                         h->noise_C, h->d_noise + (size_t)slot * sz, h->stream2));
-  h->rng_cur = 1 - h->rng_cur;
-  HIPCHK(h, hipEventRecord(h->ev_noise_done, h->stream2));
-  h->prefetch_valid = true;
-  h->prefetch_slot = slot;
   return MPPI_OK;
 }
 
@@ -437,25 +421,34 @@ int enqueue_solve(mppi_handle *h, const float *state)
   for (int it = 0; it < iters; it++) {
     Events *ev = timed ? &h->ev[it] : nullptr;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[0], h->stream));
-    int slot = it;
-    if (!explicit_noise) {
+    int slot = explicit_noise ? it : 0;
+    const bool inline_noise = !explicit_noise && has_noise_wave(h);
+    if (!explicit_noise && !inline_noise) {
       rc = acquire_noise(h, &slot);
       if (rc) return rc;
     }
     float *noise = h->d_noise + (size_t)slot * slot_sz;
     h->cur_slot = slot;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], h->stream));
-    if (!explicit_noise) {
-      rc = prefetch_noise(h, slot);
-      if (rc) return rc;
-    }
     RolloutArgs a;
     fill_rollout_args(h, state, noise, a);
+    if (inline_noise) {  // the rollout kernel's noise wavefront draws eps itself
+      a.inline_noise = 1;
+      a.rng_in = h->d_rng[h->rng_cur];
+      a.rng_out = h->d_rng[1 - h->rng_cur];
+      h->rng_cur = 1 - h->rng_cur;
+    }
     rc = launch_rollout(h, a);
     if (rc) return rc;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
+    const bool last = (it == iters - 1);
+    const int sstride = h->cfg.optimization_stride;
+    const bool want_slid = last && sstride >= 1 && sstride < T;
     HIPCHK(h, launch_solve_tail(h->d_costs, noise, h->d_in, h->d_in + 2 * T, h->d_w, h->d_scal, h->d_res_map,
-                                h->d_counter, K, T, h->cfg.gamma, it == iters - 1 ? 1 : 0, h->seq, h->stream));
+                                h->d_counter, K, T, h->cfg.gamma, last ? 1 : 0, h->seq,
+                                want_slid ? h->d_in_buf[1 - h->in_cur] : nullptr, sstride,
+                                h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
+    if (last) h->slid_valid = want_slid;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[3], h->stream));
   }
   h->explicit_iters = 0;
@@ -467,15 +460,12 @@ int enqueue_solve(mppi_handle *h, const float *state)
 void free_all(mppi_handle *h)
 {
   if (!h) return;
-  float *fp[] = {h->d_in, h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
+  float *fp[] = {h->d_in_buf[0], h->d_in_buf[1], h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
                  h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
   if (h->d_counter) (void)hipFree(h->d_counter);
-  if (h->ev_main_pos) (void)hipEventDestroy(h->ev_main_pos);
-  if (h->ev_noise_done) (void)hipEventDestroy(h->ev_noise_done);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
   for (uint32_t *p : up)
     if (p) (void)hipFree(p);
@@ -588,15 +578,10 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     }                                                                   \
   } while (0)
   CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CR(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-  CR(hipEventCreateWithFlags(&h->ev_main_pos, hipEventDisableTiming));
-  CR(hipEventCreateWithFlags(&h->ev_noise_done, hipEventDisableTiming));
-  // Generating the next iteration's noise beside the rollout hides ~7 us of kernel time but the
-  // extra waves slow the latency-critical dynamics wavefronts by more (measured, K=4096): off by
-  // default, MPPI_NOISE_PREFETCH=1 turns it on.
-  h->prefetch_enabled = getenv("MPPI_NOISE_PREFETCH") != nullptr;
-  h->n_slots = std::max(2, cfg->num_iters);
-  CR(hipMalloc(&h->d_in, sizeof(float) * (2 * (size_t)h->T + 4)));
+  h->n_slots = std::max(1, cfg->num_iters);
+  CR(hipMalloc(&h->d_in_buf[0], sizeof(float) * (2 * (size_t)h->T + 4)));
+  CR(hipMalloc(&h->d_in_buf[1], sizeof(float) * (2 * (size_t)h->T + 4)));
+  h->d_in = h->d_in_buf[0];
   CR(hipMalloc(&h->d_res, sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_scal, sizeof(float) * 4));
   CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)h->n_slots));
@@ -650,7 +635,6 @@ int mppi_destroy(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
   (void)hipSetDevice(h->cfg.device);
-  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_all(h);
   return MPPI_OK;
@@ -769,6 +753,7 @@ int mppi_reset_controls(mppi_handle *h)
     h->U[2 * t + 1] = h->cfg.init_control[1];
   }
   h->u_dirty = true;
+  h->slid_valid = false;
   return MPPI_OK;
 }
 
@@ -781,6 +766,7 @@ int mppi_set_control_seq(mppi_handle *h, const float *U, size_t n)
   }
   memcpy(h->U.data(), U, n * sizeof(float));
   h->u_dirty = true;
+  h->slid_valid = false;
   return MPPI_OK;
 }
 
@@ -800,6 +786,7 @@ int mppi_set_control_hist(mppi_handle *h, const float hist[4])
   if (!h || !hist) return MPPI_ERR_INVALID;
   memcpy(h->hist.data(), hist, 4 * sizeof(float));
   h->u_dirty = true;
+  h->slid_valid = false;
   return MPPI_OK;
 }
 
@@ -833,11 +820,18 @@ int mppi_slide_control_seq(mppi_handle *h, int stride)
     for (int j = 0; j < 2; j++) U[i * 2 + j] = U[(i + stride) * 2 + j];
   for (int j = 1; j <= stride; j++)
     for (int i = 0; i < 2; i++) U[(T - j) * 2 + i] = h->cfg.init_control[i];
-  // the same slide on the device copy, so that solve -> slide -> solve never re-uploads U
+  // the same slide on the device copy, so that solve -> slide -> solve never re-uploads U: the
+  // last solve's tail kernel already left the copy slid by optimization_stride in the other buffer
   if (!h->u_dirty) {
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, launch_slide(h->d_in, T, stride, h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
+    if (h->slid_valid && stride == h->cfg.optimization_stride) {
+      h->in_cur = 1 - h->in_cur;
+      h->d_in = h->d_in_buf[h->in_cur];
+    } else {
+      HIPCHK(h, hipSetDevice(h->cfg.device));
+      HIPCHK(h, launch_slide(h->d_in, T, stride, h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
+    }
   }
+  h->slid_valid = false;
   return MPPI_OK;
 }
 
@@ -847,9 +841,7 @@ int mppi_seed(mppi_handle *h, uint64_t seed, uint64_t offset)
   HIPCHK(h, hipSetDevice(h->cfg.device));
   int rc = mppi_synchronize(h);
   if (rc) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream2));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->prefetch_valid = false;  // prefetched draws belong to the old stream position
   rc = seed_device(h, seed, offset);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -865,13 +857,6 @@ int mppi_set_noise(mppi_handle *h, const float *eps, size_t n)
   {
     int rc = mppi_synchronize(h);
     if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream2));
-    if (h->prefetch_valid) {
-      // explicit slots overwrite the prefetched draws: rewind the generator by one iteration is not
-      // possible, so keep them by regenerating later from the saved stream position
-      h->prefetch_valid = false;
-      h->rng_cur = 1 - h->rng_cur;  // the state before the prefetch is still in the other buffer
-    }
   }
   for (int it = 0; it < h->cfg.num_iters; it++) {
     HIPCHK(h, hipMemcpyAsync(h->d_stage, eps + (size_t)it * slot, slot * sizeof(float),
@@ -962,7 +947,8 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   rc = upload_controls_if_dirty(h);
   if (rc) return rc;
   int slot = 0;
-  if (h->explicit_iters == 0) {
+  const bool inline_noise = h->explicit_iters == 0 && has_noise_wave(h);
+  if (h->explicit_iters == 0 && !inline_noise) {
     rc = acquire_noise(h, &slot);
     if (rc) return rc;
   }
@@ -970,6 +956,12 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   h->cur_slot = slot;
   RolloutArgs a;
   fill_rollout_args(h, state, h->d_noise + (size_t)slot * h->K * h->T * 2, a);
+  if (inline_noise) {
+    a.inline_noise = 1;
+    a.rng_in = h->d_rng[h->rng_cur];
+    a.rng_out = h->d_rng[1 - h->rng_cur];
+    h->rng_cur = 1 - h->rng_cur;
+  }
   rc = launch_rollout(h, a);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(costs, h->d_costs, sizeof(float) * h->K, hipMemcpyDeviceToHost, h->stream));

@@ -41,6 +41,11 @@ struct RolloutArgs {
   float *costs;     // [K]
   const float *wpack;  // MFMA-ordered weights (see pack_mfma_weights) or packed theta (VALU kernel)
   const double *inv_t; // inv_t[t] = RN(1.0 / t) in double, t = 1..T-1 (running-mean division)
+  // in-kernel noise (split kernel only): per-rollout MRG32k3a states [6][K], read from rng_in and
+  // written (advanced by 2T draws) to rng_out; inline_noise == 0 => eps is read from `noise`
+  const uint32_t *rng_in;
+  uint32_t *rng_out;
+  int inline_noise;
   int K, T, opt_delay, k99;
   float nu[2], u_lo[2], u_hi[2], dt;
   int negate_yaw_der;
@@ -70,9 +75,6 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
 // saturates correctly (+-1) for large |x|, keeps NaN.
 __device__ __forceinline__ float tanh_fast(float x)
 {
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 12
-  return x * 0.25f;
-#endif
   const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);  // exp(2x)
   const float r = __builtin_amdgcn_rcpf(e + 1.0f);
   return fmaf(-2.0f, r, 1.0f);
@@ -84,9 +86,6 @@ __device__ __forceinline__ float tanh_fast(float x)
 constexpr float kTanhScale = 2.88539008177792681472f;
 __device__ __forceinline__ float tanh_bias(float z, float bs)
 {
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 12
-  return (z + bs) * 0.25f;
-#endif
   const float e = __builtin_amdgcn_exp2f(fmaf(z, kTanhScale, bs));
   const float r = __builtin_amdgcn_rcpf(e + 1.0f);
   return fmaf(-2.0f, r, 1.0f);

@@ -16,6 +16,7 @@
 //   * noise/control buffer is time-major [T][K][2]: a wave's 16 rollouts read/write one
 //     contiguous 128-B line per step; the weighted reduction later streams it row by row.
 #include "mppi_device.hpp"
+#include "noise_device.hpp"
 
 namespace mppi {
 
@@ -226,53 +227,87 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// rollout_split_kernel: the same rollout with the work of a 16-rollout group split over TWO
-// wavefronts of one workgroup (they land on two SIMDs of a CU; at K = 4096 three quarters of the
-// chip's SIMDs are idle anyway):
+// rollout_split_kernel: the same rollout with the work of a 16-rollout group split over THREE
+// wavefronts of one workgroup (they land on three SIMDs of a CU; at K = 4096 most of the chip's
+// SIMDs are idle anyway):
 //   wave 0 "dynamics": controls + clamp + network + Euler update of [roll, u_x, u_y, yaw_mder].
 //          The learned dynamics do not depend on x, y, yaw, so this wave IS the T-step recurrence
 //          and nothing else sits on it.
 //   wave 1 "cost":     x, y, yaw kinematics, sin/cos, the two costmap fetches, MPPICosts::computeCost,
 //          the running mean and the crash flags -- consuming the per-step record
 //          (s3..s6 before the update, clamped u, du) that wave 0 leaves in an LDS ring.
-// The ring holds two phases of kPhaseSteps steps; one workgroup barrier per phase (not per step)
-// hands a phase over, so both waves run concurrently, wave 1 one phase behind.  Arithmetic and its
-// order are exactly those of rollout_mfma_kernel: results are bit-identical.
+//   wave 2 "noise":    the control noise of the group's 16 rollouts (MRG32k3a + Box-Muller, one lane
+//          per rollout, the generator state goes HBM -> registers -> HBM once per launch), one phase
+//          ahead of wave 0, through a second LDS ring: eps never touches HBM.  With explicit noise
+//          (parity tests) this wave idles and wave 0 reads eps from the buffer.
+// Both rings hold two phases of kPhaseSteps steps; one workgroup barrier per phase (not per step)
+// hands a phase over, so the three waves run concurrently.  Arithmetic and its order are exactly
+// those of rollout_mfma_kernel and noise_kernel: results are bit-identical.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPhaseSteps = 10;
 
 template <int H, int NHID, bool AFFINE, bool CTRL>
-__global__ __launch_bounds__(128) void rollout_split_kernel(const RolloutArgs a)
+__global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
 {
   using N = MfmaNet<H, NHID>;
   __shared__ __attribute__((aligned(16))) float ring[2][kPhaseSteps][kRolloutsPerWave][8];
+  __shared__ __attribute__((aligned(16))) float2 eps_ring[2][kPhaseSteps][kRolloutsPerWave];
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;  // wave-uniform
   const int j = lane & 15, g = lane >> 4;
   const int k = blockIdx.x * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
   const int phases = (T + kPhaseSteps - 1) / kPhaseSteps;
+  // Barrier schedule (every wave executes exactly phases + 1 barriers):
+  //   noise:    produce eps(p) ; barrier #(p+1)            ... then one trailing barrier
+  //   dynamics: barrier #1 ; [eps(p) -> rec(p)] ; barrier #(p+2)
+  //   cost:     barrier #1 ; barrier #(p+2) ; consume rec(p)
 
-  if (role == 0) {
+  if (role == 2) {
+    // -------------------------------- noise wave --------------------------------
+    const bool active = a.inline_noise && lane < kRolloutsPerWave;
+    Mrg gsta{0, 0, 0, 0, 0, 0};
+    if (active) {
+      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
+      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
+    }
+    for (int p = 0; p < phases; p++) {
+      const int nq = min(kPhaseSteps, T - p * kPhaseSteps);
+      if (active)
+        for (int q = 0; q < nq; q++) eps_ring[p & 1][q][lane] = noise_pair(gsta);
+      __syncthreads();
+    }
+    if (active) {
+      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
+      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+    }
+    __syncthreads();
+  } else if (role == 0) {
     // ------------------------------ dynamics wave ------------------------------
     float A[N::nA], Bi[N::nBias];
-  load_weights<H, NHID>(a.wpack, lane, A, Bi);
+    load_weights<H, NHID>(a.wpack, lane, A, Bi);
     float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
     float2 *const noise = reinterpret_cast<float2 *>(a.noise);
     const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
     const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
     const bool pure_noise_k = (k >= a.k99);  // :141
+    const bool inl = a.inline_noise != 0;
     float2 eps = noise[(size_t)k];
     float2 Unext = Useq[0];
+    __syncthreads();  // barrier #1: eps(0) is in the ring
+    float2 el_next = eps_ring[0][0][j];  // ring value of the step about to run (read one step ahead)
     for (int p = 0; p < phases; p++) {
       const int t0 = p * kPhaseSteps, nq = min(kPhaseSteps, T - t0);
       for (int q = 0; q < nq; q++) {
         const int t = t0 + q;
-        const float2 e = eps;
+        const float2 eg = eps;  // explicit-noise path: requested one step ahead from the buffer
+        const float2 el = el_next;
         const float2 Ut = Unext;
         const int tn = min(t + 1, T - 1);
         eps = noise[(size_t)tn * K + k];
         Unext = Useq[tn];
+        if (q + 1 < nq) el_next = eps_ring[p & 1][q + 1][j];
+        const float2 e = inl ? el : eg;
         // control perturbation, mppi_controller.cu:136-153
         const bool nf = noise_free_k | (t < a.opt_delay);
         const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
@@ -297,24 +332,18 @@ __global__ __launch_bounds__(128) void rollout_split_kernel(const RolloutArgs a)
         s5 = fmaf(d[2], a.dt, s5);
         s6 = fmaf(d[3], a.dt, s6);
       }
-#if !defined(MPPI_ABLATE) || MPPI_ABLATE < 10
-      __syncthreads();  // phase p is complete in LDS
-#endif
+      __syncthreads();  // barrier #(p+2): rec(p) is complete, eps(p+1) is in the ring
+      el_next = eps_ring[(p + 1) & 1][0][j];
     }
-#if defined(MPPI_ABLATE) && MPPI_ABLATE >= 10
-    a.costs[k] = s3 + s4 + s5 + s6;
-#endif
   } else {
-#if defined(MPPI_ABLATE) && MPPI_ABLATE >= 10
-    return;
-#endif
     // -------------------------------- cost wave --------------------------------
     float x = a.state[0], y = a.state[1], yaw = a.state[2];
     int crash = 0;
     float J = 0.0f;
     double rt_next = a.inv_t[0];
+    __syncthreads();  // barrier #1
     for (int p = 0; p < phases; p++) {
-      __syncthreads();  // wait for phase p
+      __syncthreads();  // barrier #(p+2): rec(p) is complete
       const int t0 = p * kPhaseSteps, nq = min(kPhaseSteps, T - t0);
       for (int q = 0; q < nq; q++) {
         const int t = t0 + q;
@@ -387,7 +416,7 @@ static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipS
 {
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   if (block_threads == 128) {  // split form: one dynamics wave + one cost wave per 16 rollouts
-    const dim3 grid(a.K / kRolloutsPerWave), block(128);
+    const dim3 grid(a.K / kRolloutsPerWave), block(192);
     if (affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
     else if (affine && ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
     else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, false, false>), grid, block, 0, stream, a);

@@ -5,9 +5,6 @@
 
 namespace mppi {
 
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 23
-#define expf(x) (1.0f + (x))
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // solve_tail_kernel: everything of one solve iteration after the rollout, in ONE launch.
@@ -89,6 +86,9 @@ struct TailArgs {
   unsigned *counter;    // arrival counter, zero on entry, reset by the last workgroup
   int K, T;
   float gamma;
+  float *slid;          // optional [2T + 4]: receives [U | hist] slid by slide_stride (or nullptr)
+  int slide_stride;
+  float init0, init1;
   int last_iter;        // smooth + publish results
   unsigned seq;         // sequence number published in res[3] once everything else is visible
 };
@@ -130,9 +130,6 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   float m = INFINITY;
   for (int k = tid; k < K; k += kTailThreads) m = fminf(m, a.costs[k]);
   const float beta = block_min(m, red, &bc);
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 20
-  if (tid == 0) a.U[t * 2] = beta + pre[0].x; return;
-#endif
   float part = 0.0f;
   for (int k = tid; k < K; k += kTailThreads) {
     const float e = expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
@@ -140,9 +137,6 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     part += e;
   }
   const float eta = block_sum(part, red, &bc);
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 21
-  if (tid == 0) a.U[t * 2] = eta + pre[0].x; return;
-#endif
   float traj = 0.0f;
   if (extra) {
     float tc = 0.0f;
@@ -191,12 +185,8 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
       const float *p = tile + ml * 130 + j;
       const float *wp = wtile + ml * 65;  // row stride 65: the 16 groups of a half-wave hit 16 banks
       float acc = 0.0f;
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 24
-      acc = wp[0] * p[0];
-#else
 #pragma unroll
       for (int i = 0; i < 64; i++) acc = fmaf(wp[i], p[2 * i], acc);  // u_system += weight*u :246
-#endif
       partial[(base / 64 + ml) * 2 + j] = acc;
     }
     __syncthreads();
@@ -216,9 +206,6 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     // write-through (sc1) store: the hand-off to the last workgroup below needs no L2 write-back
     __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-#if defined(MPPI_ABLATE) && MPPI_ABLATE == 22
-  return;
-#endif
   // ---- arrival: the last workgroup smooths and publishes.  Hand-off form R1 of the MI355X guide
   // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
   // (s_waitcnt vmcnt(0)) and only then one lane bumps the agent-scope counter; the last arriver
@@ -269,6 +256,28 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   __syncthreads();
   if (tid == 0)
     __hip_atomic_store(reinterpret_cast<unsigned *>(a.res) + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
+  // Off the host's critical path (the result is already published): leave a copy of [U | hist]
+  // slid by the controller's optimization stride (slideControlSeq, mppi_controller.cu:527-554) in
+  // the other buffer, so that the control loop's slide -> solve costs no kernel and no upload.
+  if (a.slid != nullptr) {
+    const int st = a.slide_stride;
+    for (int i = tid; i < 2 * T; i += kTailThreads) X[i] = a.U[i];  // smoothed sequence (own stores)
+    float hold = 0.0f;
+    if (tid < 4) hold = a.hist[tid];
+    const float hold2 = __shfl(hold, (tid + 2) & 63);  // all lanes active: lane i gets hist[i + 2]
+    __syncthreads();
+    for (int i = tid; i < 2 * T; i += kTailThreads) {
+      const int r = i >> 1, j = i & 1;
+      a.slid[i] = (r < T - st) ? X[(r + st) * 2 + j] : (j ? a.init1 : a.init0);
+    }
+    if (tid < 4) {
+      float hv;
+      if (st == 1) hv = (tid < 2) ? hold2 : X[tid - 2];
+      else hv = X[(st - 2) + tid];  // flat-index quirk (Q15)
+      a.slid[2 * T + tid] = hv;
+    }
+  }
 }
 
 // slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
@@ -280,11 +289,12 @@ __global__ void slide_kernel(float *__restrict__ in, int T, int stride, float in
   for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) buf[i] = U[i];
   float hold = 0.0f;
   if (threadIdx.x < 4) hold = hist[threadIdx.x];
+  const float hold2 = __shfl(hold, (threadIdx.x + 2) & 63);  // all lanes active: lane i gets hist[i + 2]
   __syncthreads();
   if (threadIdx.x < 4) {
     const int i = threadIdx.x;
     float hv;
-    if (stride == 1) hv = (i < 2) ? __shfl(hold, i + 2) : buf[i - 2];
+    if (stride == 1) hv = (i < 2) ? hold2 : buf[i - 2];
     else hv = buf[(stride - 2) + i];  // flat-index quirk (Q15)
     hist[i] = hv;
   }
@@ -336,9 +346,11 @@ __global__ void tk_to_kt_kernel(const float2 *__restrict__ src, float2 *__restri
 // ---- launchers ----
 hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
                              float *scal, float *res, unsigned *counter, int K, int T, float gamma,
-                             int last_iter, unsigned seq, hipStream_t stream)
+                             int last_iter, unsigned seq, float *slid, int slide_stride, float init0,
+                             float init1, hipStream_t stream)
 {
   TailArgs a;
+  a.slid = slid; a.slide_stride = slide_stride; a.init0 = init0; a.init1 = init1;
   a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter;
   a.K = K; a.T = T; a.gamma = gamma; a.last_iter = last_iter; a.seq = seq;
   const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2) * sizeof(float);

@@ -218,6 +218,42 @@ def test_warm_start_loop_with_slide():
     sol.close()
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_device_resident_loop_matches_oracle(stride):
+    """solve -> slideControlSeq -> solve ... without ever touching U from the host: the control
+    sequence and control history stay on the device (the tail kernel leaves the slid copy), the
+    noise comes from the in-kernel generator.  The oracle runs the same loop on its own state."""
+    cfg = S.make_config(1024, 60, track="ring", opt_stride=stride)
+    orc = O.Oracle(cfg, fma_mode=1, nthreads=8)
+    sol = capi.Solver(cfg)
+    sol.seed(1234, 0)
+    U = np.zeros((cfg["T"], 2), np.float32)
+    hist = np.zeros(4, np.float32)
+    state = cfg["start_state"].copy()
+    for it in range(5):
+        eps = O.generate_noise(1234, 2 * cfg["T"] * it, cfg["K"], cfg["T"])[None]
+        ref = orc.compute_control(state, U, hist, eps)
+        sol.compute_control(state)
+        got = sol.get_results(with_vectors=False)
+        assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4, it
+        assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"]), it
+        ss, _ = orc.nominal_traj(state, ref["U"])
+        state = ss[stride].copy()
+        U, hist = orc.slide_control_seq(ref["U"], hist, cfg["init_u"], stride)
+        sol.slide_control_seq(stride)
+        np.testing.assert_allclose(sol.get_control_seq(), U, atol=1e-4)
+        np.testing.assert_allclose(sol.get_control_hist(), hist, atol=1e-4)
+    # a slide by something else than optimization_stride takes the kernel path; same semantics
+    sol.slide_control_seq(3)
+    U3, h3 = orc.slide_control_seq(U, hist, cfg["init_u"], 3)
+    np.testing.assert_allclose(sol.get_control_seq(), U3, atol=1e-4)
+    sol.compute_control(state)  # consumes the device copy produced by the slide kernel
+    eps = O.generate_noise(1234, 2 * cfg["T"] * 5, cfg["K"], cfg["T"])[None]
+    ref = orc.compute_control(state, U3, h3, eps)
+    assert np.max(np.abs(sol.get_results(False)["U"] - ref["U"])) <= 2e-4
+    sol.close()
+
+
 def test_generator_mode_solve_matches_explicit_noise():
     """Default mode (device generator, seed 1234) == explicit mode fed with the oracle's noise."""
     cfg = S.make_config(1024, 50, track="ring")
