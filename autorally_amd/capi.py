@@ -263,6 +263,17 @@ class Solver:
     def compute_control(self, state):
         self._ck(self.L.mppi_compute_control(self.h, _fp(_f32(state, (7,)))))
 
+    def bind_state(self, state):
+        """Returns a zero-argument callable running mppi_compute_control on a fixed state buffer
+        (skips the per-call numpy/ctypes marshalling; used by bench.py's timed loop)."""
+        buf = _f32(state, (7,)).copy()
+        ptr = _fp(buf)
+        fn, h, ck = self.L.mppi_compute_control, self.h, self._ck
+
+        def run(_keep=buf):
+            ck(fn(h, ptr))
+        return run
+
     def compute_control_async(self, state):
         self._ck(self.L.mppi_compute_control_async(self.h, _fp(_f32(state, (7,)))))
 
@@ -303,7 +314,8 @@ class Solver:
         return out
 
     # --- measurement ---
-    def enable_stage_timing(self, on=True):
+    def enable_stage_timing(self, on=1):
+        """on = 1: every solve, N > 1: every Nth solve, 0: off."""
         self._ck(self.L.mppi_enable_stage_timing(self.h, int(on)))
 
     def reset_stage_times(self):

@@ -107,6 +107,8 @@ struct mppi_handle {
   float traj_cost = 0.0f, baseline = 0.0f, eta = 0.0f;
 
   bool timing = false;
+  int timing_every = 1;      // record stage events on every Nth solve only (events add launch gaps)
+  unsigned timing_count = 0;
   std::vector<Events> ev;  // one set per iteration
   mppi_stage_times acc{};
   std::string err;
@@ -414,7 +416,7 @@ int enqueue_solve(mppi_handle *h, const float *state)
     return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
   rc = upload_controls_if_dirty(h);
   if (rc) return rc;
-  const bool timed = h->timing;
+  const bool timed = h->timing && (h->timing_count++ % (unsigned)h->timing_every) == 0;
   const bool explicit_noise = h->explicit_iters > 0;
   const size_t slot_sz = (size_t)K * T * 2;
   h->seq++;
@@ -1021,6 +1023,8 @@ int mppi_enable_stage_timing(mppi_handle *h, int on)
 {
   if (!h) return MPPI_ERR_INVALID;
   h->timing = on != 0;
+  h->timing_every = on > 1 ? on : 1;  // on = N > 1: sample every Nth solve
+  h->timing_count = 0;
   return MPPI_OK;
 }
 

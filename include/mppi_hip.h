@@ -161,7 +161,9 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
 int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *state_seq,
                       float *control_seq);
 
-/* Measurement hooks. */
+/* Measurement hooks.  on = 1: HIP events around every stage of every solve; on = N > 1: only on
+ * every Nth solve (event packets between kernels lengthen the launch gaps, so sampling keeps the
+ * measured run close to the unmeasured one); on = 0: off. */
 int mppi_enable_stage_timing(mppi_handle *h, int on);
 int mppi_reset_stage_times(mppi_handle *h);
 int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
