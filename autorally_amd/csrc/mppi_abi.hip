@@ -73,7 +73,8 @@ struct mppi_handle {
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 128;  // 128: split (dynamics wave + cost wave), 64/256: single-wave form
+  int block_threads = 0;    // 0: auto; 128: split (dynamics / cost / noise waves); 64, 256: single-wave form
+  int num_simds = 1024;     // 4 per CU
   hipStream_t stream = nullptr;
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
@@ -95,6 +96,8 @@ struct mppi_handle {
   float *d_noise = nullptr, *d_stage = nullptr;
   float *d_costs = nullptr, *d_w = nullptr, *d_wn = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
+  float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
+  bool valu_reg_ok = false;
   double *d_invt = nullptr;
   uint32_t *d_rng[2] = {nullptr, nullptr};
   uint32_t *d_jump = nullptr, *d_sub = nullptr, *d_one = nullptr;
@@ -200,16 +203,24 @@ std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int
 
 bool use_mfma(const mppi_handle *h)
 {
-  if (h->variant_pref == 2) return false;
+  if (h->variant_pref == 2 || h->variant_pref == 3) return false;
   return h->mfma_ok;
 }
 
-// the split MFMA kernel carries its own noise wavefront
-bool has_noise_wave(const mppi_handle *h)
+// "valu" on a standard shape runs the register/scalar-operand kernel; "valu_lds" forces the generic one
+bool use_valu_reg(const mppi_handle *h) { return !use_mfma(h) && h->valu_reg_ok && h->variant_pref != 3; }
+
+// Kernel form for the MFMA path.  The split form spends three wavefronts per 16 rollouts to shorten
+// the T-step recurrence; it wins while those waves each get a SIMD of their own (measured crossover
+// at 3*K/16 ~ number of SIMDs: K=4096 split 104 us vs single-wave 117 us; K=6144 132 vs 120 us).
+int effective_block(const mppi_handle *h)
 {
-  static const bool off = getenv("MPPI_NO_INLINE_NOISE") != nullptr;  // developer A/B switch
-  return !off && use_mfma(h) && h->block_threads == 128;
+  if (h->block_threads != 0) return h->block_threads;
+  return (3 * (h->K / kRolloutsPerWave) <= h->num_simds) ? 128 : 64;
 }
+
+// the split MFMA kernel carries its own noise wavefront
+bool has_noise_wave(const mppi_handle *h) { return use_mfma(h) && effective_block(h) == 128; }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
 {
@@ -247,7 +258,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.U = h->d_in;
   a.noise = noise;
   a.costs = h->d_costs;
-  a.wpack = use_mfma(h) ? h->d_wpack : h->d_theta;
+  a.wpack = use_mfma(h) ? h->d_wpack : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
   a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
@@ -268,8 +279,9 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
 
 int launch_rollout(mppi_handle *h, const RolloutArgs &a)
 {
-  hipError_t e = use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, h->block_threads, h->stream)
-                             : launch_rollout_valu(h->net, a, h->stream);
+  hipError_t e = use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
+                 : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
+                                   : launch_rollout_valu(h->net, a, h->stream);
   if (e != hipSuccess) return fail(h, MPPI_ERR_HIP, "rollout launch", e);
   return MPPI_OK;
 }
@@ -462,7 +474,7 @@ int enqueue_solve(mppi_handle *h, const float *state)
 void free_all(mppi_handle *h)
 {
   if (!h) return;
-  float *fp[] = {h->d_in_buf[0], h->d_in_buf[1], h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
+  float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
                  h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map};
   for (float *p : fp)
     if (p) (void)hipFree(p);
@@ -533,6 +545,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return MPPI_ERR_NO_DEVICE;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MPPI_ERR_NO_DEVICE;
   if (hipSetDevice(cfg->device) != hipSuccess) return MPPI_ERR_HIP;
+  const int n_cus = prop.multiProcessorCount;
 
   mppi_handle *h = new (std::nothrow) mppi_handle();
   if (!h) return MPPI_ERR_HIP;
@@ -540,6 +553,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   h->K = cfg->num_rollouts;
   h->T = cfg->num_timesteps;
   h->dt = (float)(1.0 / cfg->hz);  // path_integral_main.cu:100
+  h->num_simds = 4 * (n_cus > 0 ? n_cus : 256);
   h->net.n_layers = cfg->n_layers;
   h->net.max_width = 0;
   h->net.num_params = 0;
@@ -552,6 +566,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   bool uniform = h->n_hidden > 0;
   for (int i = 1; i <= h->n_hidden; i++) uniform = uniform && (cfg->layers[i] == h->hidden);
   h->mfma_ok = uniform && mfma_variant_supported(h->hidden, h->n_hidden);
+  h->valu_reg_ok = uniform && valu_reg_supported(h->hidden, h->n_hidden);
   for (int i = 0; i < 2; i++) {
     h->u_lo[i] = cfg->control_min[i];
     h->u_hi[i] = cfg->control_max[i];
@@ -594,6 +609,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_w, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_wn, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_theta, sizeof(float) * h->net.num_params));
+  CR(hipMalloc(&h->d_theta_s, sizeof(float) * h->net.num_params));
   if (h->mfma_ok)
     CR(hipMalloc(&h->d_wpack, sizeof(float) * 64 * (size_t)mfma_pack_floats_per_lane(h->hidden, h->n_hidden)));
   CR(hipMalloc(&h->d_rng[0], sizeof(uint32_t) * 6 * h->K));
@@ -650,6 +666,17 @@ int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->theta.assign(theta, theta + n);
   HIPCHK(h, hipMemcpy(h->d_theta, theta, n * sizeof(float), hipMemcpyHostToDevice));
+  {
+    std::vector<float> ts(h->theta);  // hidden-layer biases pre-scaled for tanh_bias
+    size_t off = 0;
+    for (int l = 0; l + 1 < h->net.n_layers; l++) {
+      const size_t nin = h->net.layers[l], nout = h->net.layers[l + 1];
+      if (l + 2 < h->net.n_layers)
+        for (size_t j = 0; j < nout; j++) ts[off + nin * nout + j] = ts[off + nin * nout + j] * kTanhScale;
+      off += nin * nout + nout;
+    }
+    HIPCHK(h, hipMemcpy(h->d_theta_s, ts.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (h->mfma_ok) {
     const std::vector<float> pk = pack_mfma_weights(h->theta, h->hidden, h->n_hidden);
     HIPCHK(h, hipMemcpy(h->d_wpack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1049,21 +1076,26 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out)
 const char *mppi_rollout_variant(const mppi_handle *h)
 {
   if (!h) return "";
-  if (!use_mfma(h)) return "valu_lds";
+  if (!use_mfma(h)) return use_valu_reg(h) ? "valu_reg_lds" : "valu_lds";
   static thread_local char buf[64];
+  const int b = effective_block(h);
   snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
-           h->block_threads == 128 ? "split2w" : (h->block_threads == 256 ? "fused_b256" : "fused_b64"));
+           b == 128 ? "split3w" : (b == 256 ? "fused_b256" : "fused_b64"));
   return buf;
 }
 
 int mppi_set_rollout_variant(mppi_handle *h, const char *name)
 {
   if (!h || !name) return MPPI_ERR_INVALID;
-  if (strcmp(name, "auto") == 0) h->variant_pref = 0;
+  if (strcmp(name, "auto") == 0) {
+    h->variant_pref = 0;
+    h->block_threads = 0;
+  }
   else if (strcmp(name, "mfma") == 0) {
     if (!h->mfma_ok) return fail(h, MPPI_ERR_UNSUPPORTED, "MFMA variant needs 6-HxN-4 with H in {32,64}, N in {2,4}");
     h->variant_pref = 1;
   } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
+  else if (strcmp(name, "valu_lds") == 0) h->variant_pref = 3;
   else if (strcmp(name, "split") == 0) h->block_threads = 128;
   else if (strcmp(name, "fused") == 0 || strcmp(name, "block64") == 0) h->block_threads = 64;
   else if (strcmp(name, "block256") == 0) h->block_threads = 256;

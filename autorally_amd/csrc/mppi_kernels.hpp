@@ -22,6 +22,9 @@ struct NetDesc {
 };
 size_t valu_lds_bytes(const NetDesc &net);
 hipError_t launch_rollout_valu(const NetDesc &net, const RolloutArgs &a, hipStream_t stream);
+// register/scalar-operand vector-ALU kernel for 6 -> H x NHID -> 4 (theta with pre-scaled hidden biases)
+bool valu_reg_supported(int hidden, int n_hidden);
+hipError_t launch_rollout_valu_reg(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
 hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const float *states,
                                 const float *controls, float *ders, int n, int negate_yaw_der,
                                 hipStream_t stream);

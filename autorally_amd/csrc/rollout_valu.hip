@@ -144,6 +144,155 @@ __global__ __launch_bounds__(kValuLanes) void dynamics_valu_kernel(const NetDev 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// rollout_valu_reg_kernel<H, NHID>: the vector-ALU arm of the MFMA-vs-VALU A/B (SURVEY cfg 4) for
+// the standard 6 -> H x NHID -> 4 shapes.  One lane per rollout (64 rollouts per wavefront),
+// activations in registers, the packed weight blob staged once into LDS and read back as 16-byte
+// broadcasts (one ds_read_b128 feeds four v_fmac): a straightforward CDNA vector-ALU
+// implementation of the reference's inner loop (neural_net_model.cu:379-394).
+// Same k-ascending fmaf chain and the same tanh_bias as the MFMA kernels: bit-identical results.
+// `theta_s` is the packed blob with the hidden-layer biases pre-multiplied by kTanhScale (host).
+// ---------------------------------------------------------------------------------------------
+// One dense layer: inputs in registers (the k loop is unrolled), one weight row per iteration of
+// the (rolled) output loop read from LDS as broadcasts, outputs parked in a lane-major LDS tile
+// (bank = lane) and pulled back into registers for the next layer.
+template <int NIN, int NOUT, bool TANH>
+__device__ __forceinline__ void dense_reg(const float *W, const float *b, const float (&in)[NIN],
+                                          float *tile, int lane)
+{
+#pragma unroll 4  // four independent fmaf chains in flight (each chain is k-ascending, hence serial)
+  for (int jn = 0; jn < NOUT; jn++) {
+    const float *row = W + jn * NIN;
+    float acc = 0.0f;
+    if (NIN % 4 == 0) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+      for (int q = 0; q < NIN / 4; q++) {
+        const float4 w = r4[q];
+        acc = fmaf(w.x, in[4 * q + 0], acc);
+        acc = fmaf(w.y, in[4 * q + 1], acc);
+        acc = fmaf(w.z, in[4 * q + 2], acc);
+        acc = fmaf(w.w, in[4 * q + 3], acc);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < NIN; kk++) acc = fmaf(row[kk], in[kk], acc);
+    }
+    tile[jn * kValuLanes + lane] = TANH ? tanh_bias(acc, b[jn]) : acc + b[jn];
+  }
+}
+
+template <int H, int NHID>
+__device__ __forceinline__ void nn_forward_reg(const float *theta_s, float *tile, int lane,
+                                               const float (&in)[kNetIn], float (&d)[kNetOut])
+{
+  float a[H];
+  dense_reg<kNetIn, H, true>(theta_s, theta_s + kNetIn * H, in, tile, lane);
+  int off = kNetIn * H + H;
+#pragma unroll
+  for (int l = 1; l < NHID; l++) {
+#pragma unroll
+    for (int i = 0; i < H; i++) a[i] = tile[i * kValuLanes + lane];
+    dense_reg<H, H, true>(theta_s + off, theta_s + off + H * H, a, tile, lane);
+    off += H * H + H;
+  }
+#pragma unroll
+  for (int i = 0; i < H; i++) a[i] = tile[i * kValuLanes + lane];
+  dense_reg<H, kNetOut, false>(theta_s + off, theta_s + off + H * kNetOut, a, tile, lane);
+#pragma unroll
+  for (int i = 0; i < kNetOut; i++) d[i] = tile[i * kValuLanes + lane];
+}
+
+template <int H, int NHID>
+__global__ __launch_bounds__(kValuLanes) void rollout_valu_reg_kernel(const RolloutArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float theta_lds[];
+  const int lane = threadIdx.x;
+  constexpr int kParams = (kNetIn + 1) * H + (NHID - 1) * (H + 1) * H + (H + 1) * kNetOut;
+  for (int i = lane; i < kParams; i += kValuLanes) theta_lds[i] = a.wpack[i];
+  __syncthreads();
+  const int k = blockIdx.x * kValuLanes + lane;
+  if (k >= a.K) return;
+  const float *theta_s = theta_lds;
+  float *tile = theta_lds + ((kParams + 3) & ~3);  // [H][64] activation tile
+  float s[kStateDim];
+#pragma unroll
+  for (int i = 0; i < kStateDim; i++) s[i] = a.state[i];
+  int crash = 0;
+  float J = 0.0f;
+  const int K = a.K, T = a.T;
+  float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+  const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+  const bool noise_free_k = (k == 0);
+  const bool pure_noise_k = (k >= a.k99);
+  float2 eps = noise[(size_t)k];
+  for (int t = 0; t < T; t++) {
+    const float2 e = eps;
+    eps = noise[(size_t)min(t + 1, T - 1) * K + k];
+    const float2 Ut = Useq[t];
+    const bool nf = noise_free_k | (t < a.opt_delay);
+    const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+    const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+    float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
+    float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
+    noise[(size_t)t * K + k] = make_float2(u0, u1);
+    u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+    u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+    float spsi, cpsi;
+    sincos_fast(s[2], spsi, cpsi);
+    float tf, tb;
+    if (a.cost.affine) track_fetch<true>(a.cost, s, cpsi, spsi, tf, tb);
+    else track_fetch<false>(a.cost, s, cpsi, spsi, tf, tb);
+    float sd[kStateDim];
+    sd[0] = fmaf(cpsi, s[4], -(spsi * s[5]));
+    sd[1] = fmaf(spsi, s[4], cpsi * s[5]);
+    sd[2] = a.negate_yaw_der ? -s[6] : s[6];
+    const float in[kNetIn] = {s[3], s[4], s[5], s[6], u0, u1};
+    float d[kNetOut];
+    nn_forward_reg<H, NHID>(theta_s, tile, lane, in, d);
+    sd[3] = d[0]; sd[4] = d[1]; sd[5] = d[2]; sd[6] = d[3];
+    {
+      int crash_new = crash;
+      const float c = a.cost.need_control_cost
+                          ? cost_finish<true>(a.cost, a.nu, s[4], s[5], tf, tb, u0, u1, du0, du1, crash_new)
+                          : cost_finish<false>(a.cost, a.nu, s[4], s[5], tf, tb, u0, u1, du0, du1, crash_new);
+      const float Jn = running_mean(J, c, t, a.inv_t[t]);
+      J = (t > 0) ? Jn : J;
+      crash = (t > 0) ? crash_new : crash;
+    }
+#pragma unroll
+    for (int i = 0; i < kStateDim; i++) s[i] = fmaf(sd[i], a.dt, s[i]);
+    crash |= (int)(fabsf(s[3]) >= kRollCrash);
+  }
+  a.costs[k] = J + 0.0f;
+}
+
+bool valu_reg_supported(int hidden, int n_hidden)
+{
+  return (hidden == 32 || hidden == 64) && (n_hidden == 2 || n_hidden == 4);
+}
+
+hipError_t launch_rollout_valu_reg(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream)
+{
+  const dim3 grid(a.K / kValuLanes), block(kValuLanes);
+  const int n_params = (kNetIn + 1) * hidden + (n_hidden - 1) * (hidden + 1) * hidden + (hidden + 1) * kNetOut;
+  const size_t lds = ((size_t)((n_params + 3) & ~3) + (size_t)hidden * kValuLanes) * sizeof(float);
+#define MPPI_VR(HH, NN)                                                                             \
+  if (hidden == HH && n_hidden == NN) {                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_valu_reg_kernel<HH, NN>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+    if (e != hipSuccess) return e;                                                                  \
+    hipLaunchKernelGGL((rollout_valu_reg_kernel<HH, NN>), grid, block, lds, stream, a);             \
+    return hipGetLastError();                                                                       \
+  }
+  MPPI_VR(32, 2)
+  MPPI_VR(64, 2)
+  MPPI_VR(32, 4)
+  MPPI_VR(64, 4)
+#undef MPPI_VR
+  return hipErrorInvalidValue;
+}
+
 static NetDev to_dev(const NetDesc &n)
 {
   NetDev d;

@@ -127,6 +127,19 @@ def test_rollout_costs_and_controls(K, T, track, layers, variant):
     assert abs(tc - got["traj_cost"]) <= 1e-5 * abs(tc)
 
 
+@pytest.mark.parametrize("layers,variant", [([6, 16, 8, 4], "auto"), ([6, 24, 4], "auto"), (None, "valu_lds"),
+                                            ([6, 64, 64, 64, 64, 4], "valu")])
+def test_generic_and_register_valu_kernels(layers, variant):
+    """Shapes outside 6-HxN-4 (H in {32,64}) run the generic LDS kernel; 'valu_lds' forces it on a
+    standard shape; 'valu' on a standard shape is the register / LDS-broadcast kernel."""
+    cfg = S.make_config(256, 40, layers=layers, track="ring")
+    ref, got = _solve_both(cfg, U0=warm_U(cfg), variant=variant)
+    assert got["variant"].startswith("valu")
+    np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
+    assert float(np.percentile(rel_err(got["costs"], ref["costs"]), 99)) < 5e-6
+    assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
+
+
 def test_mfma_and_valu_variants_agree_bitwise():
     """Both kernels use the same k-ascending fmaf chain; the f32 MFMA is documented to be exactly
     that chain, so per-rollout costs must be IDENTICAL between the two arms."""
@@ -134,9 +147,11 @@ def test_mfma_and_valu_variants_agree_bitwise():
     U0 = warm_U(cfg)
     _, a = _solve_both(cfg, U0=U0, variant="mfma")
     _, b = _solve_both(cfg, U0=U0, variant="valu")
-    assert a["variant"].startswith("mfma") and b["variant"].startswith("valu")
-    np.testing.assert_array_equal(a["costs"].view(np.uint32), b["costs"].view(np.uint32))
-    np.testing.assert_array_equal(a["U"].view(np.uint32), b["U"].view(np.uint32))
+    _, c = _solve_both(cfg, U0=U0, variant="valu_lds")
+    assert a["variant"].startswith("mfma") and b["variant"] == "valu_reg_lds" and c["variant"] == "valu_lds"
+    for o in (b, c):
+        np.testing.assert_array_equal(a["costs"].view(np.uint32), o["costs"].view(np.uint32))
+        np.testing.assert_array_equal(a["U"].view(np.uint32), o["U"].view(np.uint32))
 
 
 @pytest.mark.parametrize("K,T,track,layers", [(512, 43, "oval", None), (256, 30, "ring", [6, 64, 64, 4])])
