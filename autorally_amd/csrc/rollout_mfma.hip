@@ -292,7 +292,7 @@ __global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
     const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
     const bool pure_noise_k = (k >= a.k99);  // :141
     const bool inl = a.inline_noise != 0;
-    float2 eps = noise[(size_t)k];
+    float2 eps = inl ? make_float2(0.0f, 0.0f) : noise[(size_t)k];
     float2 Unext = Useq[0];
     __syncthreads();  // barrier #1: eps(0) is in the ring
     float2 el_next = eps_ring[0][0][j];  // ring value of the step about to run (read one step ahead)
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
         const float2 el = el_next;
         const float2 Ut = Unext;
         const int tn = min(t + 1, T - 1);
-        eps = noise[(size_t)tn * K + k];
+        if (!inl) eps = noise[(size_t)tn * K + k];  // wave-uniform: no HBM read of eps with in-kernel noise
         Unext = Useq[tn];
         if (q + 1 < nq) el_next = eps_ring[p & 1][q + 1][j];
         const float2 e = inl ? el : eg;

@@ -25,10 +25,30 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-BYTES_PER_UPDATE = 32            # algorithmic HBM bytes per state update (whole solve)
-ROLLOUT_BYTES_PER_UPDATE = 16    # of which the rollout kernel: read 8 + write back 8
+# Algorithmic HBM bytes per state update.  SURVEY 8(d) counts 32 B for the
+# whole solve with a stand-alone generator (noise write 8 + rollout read 8 + write-back 8 +
+# reduction read 8).  The split rollout kernel draws eps in-kernel, so its own share is the 8-B
+# write-back only (whole solve 16 B); the single-wave / VALU forms read eps from HBM (16 B).
+ROLLOUT_BYTES_INLINE_NOISE = 8
+ROLLOUT_BYTES_BUFFERED_NOISE = 16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_pmc_final.json")
+
+
+def measured_traffic(cfg, variant):
+    """HBM bytes per rollout launch from the committed rocprofv3 PMC passes (FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE), if they were taken on this exact workload; else None.
+    PMC counters cannot be read from inside this process, so this is the profiled constant."""
+    try:
+        with open(TRAFFIC_PROFILE) as f:
+            p = json.load(f)
+        w = p["workload"]
+        if (w["K"], w["T"], w["layers"], w["rollout_variant"]) == (cfg["K"], cfg["T"], list(cfg["layers"]), variant):
+            return p["rollout_split_kernel"]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def flops_per_update(layers):
@@ -226,14 +246,17 @@ def main():
             rollout_s = st["rollout_ms"] * 1e-3 / n / iters
             fl = flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
+            variant = sol.rollout_variant()
+            bpu = ROLLOUT_BYTES_INLINE_NOISE if "split" in variant else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "rollout (%s)" % sol.rollout_variant(), "kernel_ms": rollout_s * 1e3,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(cfg, variant),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_e_hbm_traffic_pmc_final.json)",
+                "kernel": "rollout (%s)" % variant, "kernel_ms": rollout_s * 1e3,
                 "flop_per_state_update": fl, "state_updates_per_launch": K * T,
-                "algorithmic_bytes_per_launch": ROLLOUT_BYTES_PER_UPDATE * K * T,
-                "algorithmic_GBps": ROLLOUT_BYTES_PER_UPDATE * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
+                "algorithmic_bytes_per_launch": bpu * K * T,
+                "algorithmic_GBps": bpu * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
             }
             if world == 1 and not args.no_cpu_baseline:
