@@ -1,0 +1,222 @@
+"""C-ABI behaviour on the GPU: error convention, determinism, live updates, concurrent handles,
+edge sizes, and size-independent properties at BASELINE.json's largest configuration."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from autorally_amd import capi
+from autorally_amd import params as P
+from autorally_amd import synthetic as S
+from oracle import oracle as O
+from tests.helpers import noise_for, rel_err, warm_U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from autorally_amd import build as B
+    B.build()
+    assert capi.lib().mppi_device_count() >= 1
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_error_convention_and_call_order():
+    L = capi.lib()
+    cfg = S.make_config(128, 20)
+    c = capi.make_config_struct(cfg)
+    h = C.c_void_p()
+    assert L.mppi_create(C.byref(c), C.byref(h)) == capi.OK
+    state = cfg["start_state"].astype(np.float32)
+    # solve before the model / costmap / cost parameters were set: refused, nothing computed
+    assert L.mppi_compute_control(h, _fp(state)) == capi.ERR_STATE
+    assert b"mppi_set_nn_params" in L.mppi_last_error(h)
+    theta = np.ascontiguousarray(cfg["theta"], np.float32)
+    assert L.mppi_set_nn_params(h, _fp(theta), theta.size - 1) == capi.ERR_INVALID
+    assert L.mppi_set_nn_params(h, _fp(theta), theta.size) == capi.OK
+    assert L.mppi_compute_control(h, _fp(state)) == capi.ERR_STATE
+    U = np.full((20, 2), 7.0, np.float32)
+    assert L.mppi_get_control_seq(h, _fp(U), 39) == capi.ERR_INVALID
+    assert np.all(U == 7.0)  # outputs untouched on error
+    assert L.mppi_set_noise(h, _fp(np.zeros(10, np.float32)), 10) == capi.ERR_INVALID
+    assert L.mppi_slide_control_seq(h, 0) == capi.ERR_INVALID
+    assert L.mppi_set_rollout_variant(h, b"nonsense") == capi.ERR_INVALID
+    assert L.mppi_destroy(h) == capi.OK
+    assert L.mppi_destroy(None) == capi.ERR_INVALID
+
+
+def test_determinism_and_seeds():
+    cfg = S.make_config(1024, 40, track="ring")
+    res = []
+    for seed in (1234, 1234, 99):
+        sol = capi.Solver(dict(cfg, seed=seed))
+        sol.compute_control(cfg["start_state"])
+        sol.slide_control_seq(1)
+        sol.compute_control(cfg["start_state"])
+        res.append(sol.get_results()["U"].copy())
+        sol.close()
+    np.testing.assert_array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+    assert np.max(np.abs(res[0] - res[2])) > 1e-4
+
+
+def test_create_destroy_loop_and_many_handles():
+    cfg = S.make_config(256, 20)
+    sols = [capi.Solver(cfg) for _ in range(6)]
+    for s in sols:
+        s.compute_control(cfg["start_state"])
+    u0 = sols[0].get_results(False)["U"]
+    for s in sols[1:]:
+        np.testing.assert_array_equal(s.get_results(False)["U"], u0)  # identical generators (seed 1234)
+    for s in sols:
+        s.close()
+    for _ in range(20):
+        s = capi.Solver(cfg)
+        s.compute_control(cfg["start_state"])
+        s.close()
+
+
+def test_two_handles_driven_from_two_threads():
+    """Distinct handles may be driven concurrently from distinct host threads (one per controller /
+    per GPU): results equal the sequential ones."""
+    cfgs = [S.make_config(2048, 60, track="oval", instance=i, seed=50 + i) for i in range(2)]
+    seq = []
+    for cfg in cfgs:
+        s = capi.Solver(cfg)
+        for _ in range(3):
+            s.compute_control(cfg["start_state"])
+            s.slide_control_seq(1)
+        seq.append(s.get_control_seq())
+        s.close()
+    out = [None, None]
+
+    def work(i):
+        s = capi.Solver(cfgs[i])
+        for _ in range(3):
+            s.compute_control(cfgs[i]["start_state"])
+            s.slide_control_seq(1)
+        out[i] = s.get_control_seq()
+        s.close()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        np.testing.assert_array_equal(out[i].view(np.uint32), seq[i].view(np.uint32))
+
+
+def test_update_model_and_costmap_and_limits(golden_dir):
+    import os
+    cfg = S.make_config(512, 40, track="ring")
+    eps = noise_for(cfg)
+    U0 = warm_U(cfg)
+    layers2, theta2 = P.load_model_npz(os.path.join(golden_dir, "models", "gazebo_nnet_09_12_2018.npz"))
+    # [W1|W2|W3|b1|b2|b3] layout of updateModel (neural_net_model.cu:152-180)
+    z = np.load(os.path.join(golden_dir, "models", "gazebo_nnet_09_12_2018.npz"))
+    data = np.concatenate([z["dynamics_W%d" % i].astype(np.float32).ravel() for i in (1, 2, 3)] +
+                          [z["dynamics_b%d" % i].astype(np.float32).ravel() for i in (1, 2, 3)])
+
+    def solve(sol):
+        sol.set_control_seq(U0)
+        sol.set_noise(eps)
+        sol.compute_control(cfg["start_state"])
+        return sol.get_results()
+
+    a = capi.Solver(cfg)
+    r0 = solve(a)
+    a.update_model([6, 32, 32, 4], data)
+    r1 = solve(a)
+    b = capi.Solver(dict(cfg, theta=theta2))
+    r2 = solve(b)
+    assert np.max(np.abs(r0["costs"] - r1["costs"])) > 1e-2
+    np.testing.assert_array_equal(r1["costs"].view(np.uint32), r2["costs"].view(np.uint32))
+    with pytest.raises(capi.MppiError):
+        a.update_model([6, 16, 32, 4], data)  # structure mismatch: rejected, model unchanged
+    np.testing.assert_array_equal(solve(a)["costs"].view(np.uint32), r2["costs"].view(np.uint32))
+    # costmap channel 0 swap == fresh solver with that map
+    ch0, xb, yb, ppm = S.gaussian_ring_map(radius=11.0)
+    a.set_costmap_channel(0, ch0)
+    m2 = cfg["map_rgba"].copy()
+    m2[:, :, 0] = ch0
+    c = capi.Solver(dict(cfg, theta=theta2, map_rgba=m2))
+    np.testing.assert_array_equal(solve(a)["costs"].view(np.uint32), solve(c)["costs"].view(np.uint32))
+    # cutThrottle (mppi_controller.cu:460-466): max throttle 0 and desired speed 0
+    a.set_control_limits([-0.99, -0.99], [0.99, 0.0])
+    a.set_cost_params(dict(cfg["cost"], desired_speed=0.0))
+    solve(a)
+    _, cs = a.nominal_traj(cfg["start_state"])
+    assert cs[:, 1].max() <= 0.0
+    orc = O.Oracle(dict(cfg, theta=theta2, map_rgba=m2, u_hi=(0.99, 0.0), cost=dict(cfg["cost"], desired_speed=0.0)))
+    ref = orc.compute_control(cfg["start_state"], U0, np.zeros(4, np.float32), eps)
+    assert np.max(np.abs(a.get_results(False)["U"] - ref["U"])) <= 1e-4
+    for s in (a, b, c):
+        s.close()
+
+
+@pytest.mark.parametrize("K,T", [(64, 2), (64, 11), (128, 10), (192, 29), (64, 203)])
+def test_edge_sizes(K, T):
+    """Smallest K, T = 2, T around the 10-step phase of the LDS rings, T > 2 phases."""
+    cfg = S.make_config(K, T, track="ring")
+    eps = noise_for(cfg)
+    U0 = warm_U(cfg)
+    ref = O.Oracle(cfg).compute_control(cfg["start_state"], U0, np.zeros(4, np.float32), eps)
+    for variant in ("split", "fused", "valu"):
+        sol = capi.Solver(cfg)
+        sol.set_rollout_variant(variant)
+        sol.set_control_seq(U0)
+        sol.set_noise(eps)
+        sol.compute_control(cfg["start_state"])
+        got = sol.get_results()
+        np.testing.assert_array_equal(sol.get_applied_controls().view(np.uint32), ref["V"][-1].view(np.uint32))
+        assert float(np.percentile(rel_err(got["costs"], ref["costs"]), 95)) < 1e-5, variant
+        assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4, variant
+        # generator mode on the same handle (in-kernel noise for split, stand-alone kernel otherwise)
+        sol.seed(1234, 0)
+        sol.set_control_seq(U0)
+        sol.compute_control(cfg["start_state"])
+        np.testing.assert_array_equal(sol.get_results()["costs"].view(np.uint32), got["costs"].view(np.uint32))
+        sol.close()
+
+
+def test_baseline_config4_full_size_properties():
+    """K=16384, T=150, 6-64-64-4 (BASELINE.json configs[3]) is too big for the CPU oracle in a test,
+    so: the first 64 rollouts against an oracle run of K=64 on the same noise rows (rollout cost does
+    not depend on K below the pure-noise threshold), softmax/hull/idempotence properties of the
+    solve, and bitwise agreement of the kernel forms."""
+    K, T = 16384, 150
+    layers, theta = P.synthetic_model([6, 64, 64, 4], seed=4)
+    cfg = S.make_config(K, T, layers=layers, theta=theta, track="oval")
+    small = dict(cfg, K=64)
+    U0 = warm_U(cfg)
+    rng = np.random.RandomState(5)
+    eps = rng.standard_normal((1, K, T, 2)).astype(np.float32)
+    ref_costs, _, _ = O.Oracle(small, nthreads=8).rollouts(cfg["start_state"], U0, eps[0, :64])
+    outs = {}
+    for variant in ("auto", "split"):
+        sol = capi.Solver(cfg)
+        sol.set_rollout_variant(variant)
+        sol.set_control_seq(U0)
+        sol.set_noise(eps)
+        sol.compute_control(cfg["start_state"])
+        outs[variant] = dict(sol.get_results(), V=sol.get_applied_controls(), name=sol.rollout_variant())
+        sol.close()
+    a = outs["auto"]
+    assert "fused" in a["name"] and "split" in outs["split"]["name"]  # auto picks the single-wave form here
+    np.testing.assert_array_equal(a["costs"].view(np.uint32), outs["split"]["costs"].view(np.uint32))
+    np.testing.assert_array_equal(a["U"].view(np.uint32), outs["split"]["U"].view(np.uint32))
+    assert float(np.percentile(rel_err(a["costs"][:64], ref_costs), 90)) < 1e-5
+    w = a["w"]
+    assert w.max() == 1.0 and np.all(w >= 0) and np.all(np.isfinite(a["U"]))
+    eta = float(w.astype(np.float64).sum())
+    # weighted mean in float64 from the GPU's own weights and applied controls, then the oracle's filter
+    Uw = np.einsum("k,ktj->tj", w.astype(np.float64) / eta, a["V"].astype(np.float64))
+    Us = O.Oracle(small).savgol(Uw.astype(np.float32), np.zeros(4, np.float32))
+    assert np.max(np.abs(Us - a["U"])) < 5e-5
+    assert abs(float((w.astype(np.float64) ** 2).sum() / eta) - a["traj_cost"]) < 1e-4 * a["traj_cost"]
+    assert a["V"][..., 0].min() <= a["U"][:, 0].min() and a["U"][:, 0].max() <= a["V"][..., 0].max()
