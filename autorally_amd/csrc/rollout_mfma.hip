@@ -292,7 +292,7 @@ __global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
     const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
     const bool pure_noise_k = (k >= a.k99);  // :141
     const bool inl = a.inline_noise != 0;
-    float2 eps = inl ? make_float2(0.0f, 0.0f) : noise[(size_t)k];
+    float2 eps = *(inl ? Useq : &noise[(size_t)k]);
     float2 Unext = Useq[0];
     __syncthreads();  // barrier #1: eps(0) is in the ring
     float2 el_next = eps_ring[0][0][j];  // ring value of the step about to run (read one step ahead)
@@ -304,7 +304,9 @@ __global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
         const float2 el = el_next;
         const float2 Ut = Unext;
         const int tn = min(t + 1, T - 1);
-        if (!inl) eps = noise[(size_t)tn * K + k];  // wave-uniform: no HBM read of eps with in-kernel noise
+        // always one load (so the compiler can count outstanding loads and never drains the queue): the
+        // buffer with explicit noise, a cache-resident dummy (no HBM read of eps) with in-kernel noise
+        eps = *(inl ? Useq : &noise[(size_t)tn * K + k]);
         Unext = Useq[tn];
         if (q + 1 < nq) el_next = eps_ring[p & 1][q + 1][j];
         const float2 e = inl ? el : eg;
@@ -379,6 +381,235 @@ __global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// rollout_quad_kernel: FOUR wavefronts per 16 rollouts -- the network itself is split over two
+// SIMDs.  Used while 4*K/16 <= number of SIMDs (K <= 4096 on MI355X), where every wave owns a SIMD.
+//
+// Why: the f32 MFMA occupies the f32 vector datapath, so one wave cannot go below
+// (MFMA cycles + VALU cycles) per step.  Halving the recurrence needs a second datapath:
+//   wave 0 / wave 1 "dynamics": each owns half of the 16-row M tiles of every hidden layer (half of
+//          the MFMAs and half of the tanh of layers 0..NHID-1).  Before each following layer the
+//          two waves swap their activations through LDS -- lane l of one wave needs exactly
+//          registers r of lane l of the other (same rollout j, same k-slot g), so the swap is one
+//          16-byte store + one 16-byte load per lane -- and one workgroup barrier.  The output
+//          layer (a single M tile, a serial chain) is computed by both, so both hold the new state.
+//          Every dot product keeps its k-ascending order: bit-identical results.
+//   wave 2 "cost", wave 3 "noise": as in rollout_split_kernel, but in lock step with the NHID
+//          barriers per step; their work is cut at the barriers so that neither delays one.
+// ---------------------------------------------------------------------------------------------
+template <int H, int NHID, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
+{
+  using N = MfmaNet<H, NHID>;
+  constexpr int MT = N::MT, M2 = MT / 2, KSH = N::KSH, NX = M2 * 4;
+  static_assert(MT % 2 == 0 && NHID >= 2, "needs two M tiles and two exchanges per step");
+  __shared__ __attribute__((aligned(16))) float xb[NHID][2][64][NX];
+  __shared__ __attribute__((aligned(16))) float rec[2][kRolloutsPerWave][8];
+  __shared__ __attribute__((aligned(16))) float2 eps_ring[3][kRolloutsPerWave];
+  const int lane = threadIdx.x & 63;
+  const int role = threadIdx.x >> 6;  // wave-uniform
+  const int j = lane & 15, g = lane >> 4;
+  const int k = blockIdx.x * kRolloutsPerWave + j;
+  const int K = a.K, T = a.T;
+  const bool inl = a.inline_noise != 0;
+  // Every wave executes exactly 1 + NHID*T barriers: the prologue barrier, then barriers
+  // B_0(t) .. B_{NHID-1}(t) of step t (one per activation swap).
+
+  if (role == 3) {
+    // -------------------------------- noise wave --------------------------------
+    // eps(t+2) is drawn during step t (generator steps after B_0, Box-Muller after B_1) into a
+    // three-slot ring; the dynamics waves read eps(t+1) after B_0(t).
+    const bool active = inl && lane < kRolloutsPerWave;
+    Mrg gsta{0, 0, 0, 0, 0, 0};
+    if (active) {
+      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
+      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
+      eps_ring[0][lane] = noise_pair(gsta);
+      if (T > 1) eps_ring[1][lane] = noise_pair(gsta);
+    }
+    __syncthreads();  // prologue
+    for (int t = 0; t < T; t++) {
+      const bool draw = active && (t + 2 < T);
+      __syncthreads();  // B_0(t)
+      float u1 = 0.0f, u2 = 0.0f;
+      if (draw) {
+        u1 = (float)mrg_next_z(gsta) * 0x1p-32f;
+        u2 = (float)mrg_next_z(gsta) * 0x1p-32f;
+      }
+      __syncthreads();  // B_1(t)
+      if (draw) {
+        const float r = sqrtf(-2.0f * spec_logf(u1));
+        float sn, cs;
+        spec_sincos2pi(u2, sn, cs);
+        eps_ring[(t + 2) % 3][lane] = make_float2(r * sn, r * cs);
+      }
+#pragma unroll
+      for (int e = 2; e < NHID; e++) __syncthreads();
+    }
+    if (active) {
+      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
+      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+    }
+  } else if (role == 2) {
+    // -------------------------------- cost wave --------------------------------
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int crash = 0;
+    float J = 0.0f;
+    double rt_next = a.inv_t[0];
+    __syncthreads();  // prologue
+    for (int t = 0; t < T; t++) {
+      const double rt = rt_next;
+      rt_next = a.inv_t[min(t + 1, T - 1)];
+      __syncthreads();  // B_0(t): rec(t) is in LDS
+      const float4 r0 = *reinterpret_cast<const float4 *>(&rec[t & 1][j][0]);  // s3 s4 s5 s6
+      const float4 r1 = *reinterpret_cast<const float4 *>(&rec[t & 1][j][4]);  // u0 u1 du0 du1
+      crash |= (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
+      float spsi, cpsi;
+      sincos_fast(yaw, spsi, cpsi);
+      const float st[3] = {x, y, yaw};
+      float tf, tb;
+      track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
+      const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
+      const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
+      const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
+      x = fmaf(sd0, a.dt, x);
+      y = fmaf(sd1, a.dt, y);
+      yaw = fmaf(sd2, a.dt, yaw);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // B_1(t)
+      CostTerms ct;
+      cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+      int crash_new = crash;
+      const float c = cost_terms_b(a.cost, ct, tf, tb, crash_new);
+      const float Jn = running_mean(J, c, t, rt);
+      J = (t > 0) ? Jn : J;
+      crash = (t > 0) ? crash_new : crash;
+#pragma unroll
+      for (int e = 2; e < NHID; e++) __syncthreads();
+    }
+    a.costs[k] = J + 0.0f;
+  } else {
+    // --------------------------- dynamics waves (w = 0, 1) ---------------------------
+    const int w = role;
+    float A0[M2 * 2], AH[(NHID - 1) * M2 * KSH], AL[KSH], Bh[NHID * NX], BL[4];
+#pragma unroll
+    for (int i = 0; i < M2; i++) {
+      const int m = w * M2 + i;
+#pragma unroll
+      for (int s = 0; s < 2; s++) A0[i * 2 + s] = a.wpack[(m * 2 + s) * 64 + lane];
+#pragma unroll
+      for (int l = 1; l < NHID; l++)
+#pragma unroll
+        for (int s = 0; s < KSH; s++)
+          AH[((l - 1) * M2 + i) * KSH + s] = a.wpack[(N::nA0 + (l - 1) * N::nAH + m * KSH + s) * 64 + lane];
+#pragma unroll
+      for (int l = 0; l < NHID; l++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          Bh[l * NX + i * 4 + r] = a.wpack[(N::nA + l * MT * 4 + m * 4 + r) * 64 + lane] * kTanhScale;
+    }
+#pragma unroll
+    for (int s = 0; s < KSH; s++) AL[s] = a.wpack[(N::nA0 + (NHID - 1) * N::nAH + s) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; r++) BL[r] = a.wpack[(N::nA + NHID * MT * 4 + r) * 64 + lane];
+
+    float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
+    float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+    const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+    const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
+    const bool pure_noise_k = (k >= a.k99);  // :141
+    float2 eps = *(inl ? Useq : &noise[(size_t)k]);
+    float2 Unext = Useq[0];
+    __syncthreads();  // prologue: eps(0), eps(1) are in the ring
+    float2 el_next = eps_ring[0][j];
+    for (int t = 0; t < T; t++) {
+      const float2 eg = eps;
+      const float2 el = el_next;
+      const float2 Ut = Unext;
+      const int tn = min(t + 1, T - 1);
+      eps = *(inl ? Useq : &noise[(size_t)tn * K + k]);  // always one load; dummy with in-kernel noise
+      Unext = Useq[tn];
+      const float2 e = inl ? el : eg;
+      // control perturbation, mppi_controller.cu:136-153 (computed by both dynamics waves)
+      const bool nf = noise_free_k | (t < a.opt_delay);
+      const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+      const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+      float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
+      float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
+      if (w == 0) noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above (first used next step)
+      u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+      u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+      if (w == 0) {  // record for the cost wave: state BEFORE this step's update, clamped u, du
+        float2 rc;
+        rc.x = (g == 0) ? s3 : (g == 1) ? s5 : (g == 2) ? u0 : du0;
+        rc.y = (g == 0) ? s4 : (g == 1) ? s6 : (g == 2) ? u1 : du1;
+        *reinterpret_cast<float2 *>(&rec[t & 1][j][2 * g]) = rc;
+      }
+      // layer 0, own M tiles
+      const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
+      const float b1 = (g == 0) ? u0 : (g == 1) ? u1 : 0.0f;
+      f32x4 acc[M2];
+#pragma unroll
+      for (int i = 0; i < M2; i++) {
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        z = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[i * 2 + 0], b0, z, 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[i * 2 + 1], b1, z, 0, 0, 0);
+      }
+      float d[4];
+#pragma unroll
+      for (int e2 = 0; e2 < NHID; e2++) {
+        // own half of the activations of hidden layer e2, swapped with the partner wave
+        float own[NX], oth[NX];
+#pragma unroll
+        for (int i = 0; i < M2; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) own[i * 4 + r] = tanh_bias(acc[i][r], Bh[e2 * NX + i * 4 + r]);
+#pragma unroll
+        for (int q = 0; q < NX / 4; q++)
+          *reinterpret_cast<float4 *>(&xb[e2][w][lane][4 * q]) =
+              make_float4(own[4 * q], own[4 * q + 1], own[4 * q + 2], own[4 * q + 3]);
+        __syncthreads();  // B_e2(t)
+#pragma unroll
+        for (int q = 0; q < NX / 4; q++) {
+          const float4 v = *reinterpret_cast<const float4 *>(&xb[e2][1 - w][lane][4 * q]);
+          oth[4 * q] = v.x; oth[4 * q + 1] = v.y; oth[4 * q + 2] = v.z; oth[4 * q + 3] = v.w;
+        }
+        if (e2 == 0) el_next = eps_ring[(t + 1) % 3][j];  // written during step t-1, visible after B_0(t)
+        // activation of k-step s = 4m + r: from the wave that owns tile m
+        float act[MT * 4];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const bool mine = (m / M2) == 0;  // tile owned by wave 0
+            const int li = (m % M2) * 4 + r;
+            act[m * 4 + r] = (w == 0) ? (mine ? own[li] : oth[li]) : (mine ? oth[li] : own[li]);
+          }
+        if (e2 < NHID - 1) {
+#pragma unroll
+          for (int i = 0; i < M2; i++) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int s = 0; s < KSH; s++)
+#pragma unroll
+            for (int i = 0; i < M2; i++)
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AH[(e2 * M2 + i) * KSH + s], act[s], acc[i], 0, 0, 0);
+        } else {
+          f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int s = 0; s < KSH; s++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(AL[s], act[s], o, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) d[r] = o[r] + BL[r];
+        }
+      }
+      s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
+      s4 = fmaf(d[1], a.dt, s4);
+      s5 = fmaf(d[2], a.dt, s5);
+      s6 = fmaf(d[3], a.dt, s6);
+    }
+  }
+}
+
 // Debug/test entry: state derivative of n independent (state, control) pairs through the
 // same device functions as the rollout (used to check the golden vectors on the GPU).
 template <int H, int NHID>
@@ -415,6 +646,14 @@ template <int H, int NHID>
 static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipStream_t stream)
 {
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
+  if (block_threads == 512) {  // quad form: two dynamics waves + cost wave + noise wave per 16 rollouts
+    const dim3 grid(a.K / kRolloutsPerWave), block(256);
+    if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
+    else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
+    else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   if (block_threads == 128) {  // split form: one dynamics wave + one cost wave per 16 rollouts
     const dim3 grid(a.K / kRolloutsPerWave), block(192);
     if (affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, false>), grid, block, 0, stream, a);

@@ -162,10 +162,12 @@ def test_split_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
     U0 = warm_U(cfg)
     _, a = _solve_both(cfg, U0=U0, variant="fused")
     _, b = _solve_both(cfg, U0=U0, variant="split")
-    assert "fused" in a["variant"] and "split" in b["variant"]
-    np.testing.assert_array_equal(a["costs"].view(np.uint32), b["costs"].view(np.uint32))
-    np.testing.assert_array_equal(a["V"].view(np.uint32), b["V"].view(np.uint32))
-    np.testing.assert_array_equal(a["U"].view(np.uint32), b["U"].view(np.uint32))
+    _, c = _solve_both(cfg, U0=U0, variant="quad")
+    assert "fused" in a["variant"] and "split" in b["variant"] and "quad" in c["variant"]
+    for o in (b, c):
+        np.testing.assert_array_equal(a["costs"].view(np.uint32), o["costs"].view(np.uint32))
+        np.testing.assert_array_equal(a["V"].view(np.uint32), o["V"].view(np.uint32))
+        np.testing.assert_array_equal(a["U"].view(np.uint32), o["U"].view(np.uint32))
 
 
 def test_cold_start_zero_controls():
