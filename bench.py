@@ -27,13 +27,13 @@ import numpy as np
 
 # Algorithmic HBM bytes per state update.  SURVEY 8(d) counts 32 B for the
 # whole solve with a stand-alone generator (noise write 8 + rollout read 8 + write-back 8 +
-# reduction read 8).  The split rollout kernel draws eps in-kernel, so its own share is the 8-B
+# reduction read 8).  The split and quad rollout kernels draw eps in-kernel, so their share is the 8-B
 # write-back only (whole solve 16 B); the single-wave / VALU forms read eps from HBM (16 B).
 ROLLOUT_BYTES_INLINE_NOISE = 8
 ROLLOUT_BYTES_BUFFERED_NOISE = 16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_pmc_final.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_f_hbm_traffic_pmc_quad.json")
 
 
 def measured_traffic(cfg, variant):
@@ -45,7 +45,7 @@ def measured_traffic(cfg, variant):
             p = json.load(f)
         w = p["workload"]
         if (w["K"], w["T"], w["layers"], w["rollout_variant"]) == (cfg["K"], cfg["T"], list(cfg["layers"]), variant):
-            return p["rollout_split_kernel"]["traffic_bytes_per_launch"]
+            return p["rollout_kernel"]["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -247,12 +247,12 @@ def main():
             fl = flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            bpu = ROLLOUT_BYTES_INLINE_NOISE if "split" in variant else ROLLOUT_BYTES_BUFFERED_NOISE
+            bpu = ROLLOUT_BYTES_INLINE_NOISE if ("split" in variant or "quad" in variant) else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(cfg, variant),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_e_hbm_traffic_pmc_final.json)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_f_hbm_traffic_pmc_quad.json)",
                 "kernel": "rollout (%s)" % variant, "kernel_ms": rollout_s * 1e3,
                 "flop_per_state_update": fl, "state_updates_per_launch": K * T,
                 "algorithmic_bytes_per_launch": bpu * K * T,
