@@ -73,7 +73,7 @@ struct mppi_handle {
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 0;    // 0: auto; 512: quad; 128: split (dynamics / cost / noise waves); 64, 256: single-wave form
+  int block_threads = 0;    // 0: auto; 512: quad (2 dynamics + cost + control waves per 16 rollouts); 64, 256: single-wave form
   int num_simds = 1024;     // 4 per CU
   hipStream_t stream = nullptr;
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
@@ -211,23 +211,22 @@ bool use_mfma(const mppi_handle *h)
 bool use_valu_reg(const mppi_handle *h) { return !use_mfma(h) && h->valu_reg_ok && h->variant_pref != 3; }
 
 // Kernel form for the MFMA path.  The quad form spends four wavefronts per 16 rollouts (the network
-// itself on two SIMDs), the split form three; they win while each of those waves gets a SIMD of its
-// own, after that one wave per 16 rollouts is best.  Measured on MI355X (6-32-32-4, T=100, rollout
-// kernel): K=4096 quad 88 us / split 101 us / single-wave 117 us; K=6144 split 132 / single 120 us.
+// itself on two SIMDs, a cost wave, a control/noise wave); it wins while the recurrence is latency
+// bound, i.e. while the SIMDs are not yet full of dynamics waves; after that one wave per 16 rollouts
+// is best.  Measured on MI355X (rollout kernel, T=100): 6-32-32-4 K=4096 quad 71 us / single-wave
+// 117 us; K=8192 114 / 120 us; K=12288 159 / 121 us.  6-64-64-4: K=4096 138 / 217 us; K=8192 247 / 233 us.
 int effective_block(const mppi_handle *h)
 {
   if (h->block_threads != 0) return h->block_threads;
   const int groups = h->K / kRolloutsPerWave;
-  if (4 * groups <= h->num_simds) return 512;
-  if (3 * groups <= h->num_simds) return 128;
-  return 64;
+  const int budget = (h->hidden <= 32) ? 2 * h->num_simds : h->num_simds;
+  return (4 * groups <= budget) ? 512 : 64;
 }
 
-// the split MFMA kernel carries its own noise wavefront
+// the quad MFMA kernel carries its own control/noise wavefront
 bool has_noise_wave(const mppi_handle *h)
 {
-  const int b = effective_block(h);
-  return use_mfma(h) && (b == 128 || b == 512);
+  return use_mfma(h) && effective_block(h) == 512;
 }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
@@ -1088,7 +1087,7 @@ const char *mppi_rollout_variant(const mppi_handle *h)
   static thread_local char buf[64];
   const int b = effective_block(h);
   snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
-           b == 512 ? "quad4w" : b == 128 ? "split3w" : (b == 256 ? "fused_b256" : "fused_b64"));
+           b == 512 ? "quad4w" : (b == 256 ? "fused_b256" : "fused_b64"));
   return buf;
 }
 
@@ -1104,7 +1103,6 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     h->variant_pref = 1;
   } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
   else if (strcmp(name, "valu_lds") == 0) h->variant_pref = 3;
-  else if (strcmp(name, "split") == 0) h->block_threads = 128;
   else if (strcmp(name, "quad") == 0) h->block_threads = 512;
   else if (strcmp(name, "fused") == 0 || strcmp(name, "block64") == 0) h->block_threads = 64;
   else if (strcmp(name, "block256") == 0) h->block_threads = 256;

@@ -41,7 +41,7 @@ struct RolloutArgs {
   float *costs;     // [K]
   const float *wpack;  // MFMA-ordered weights (see pack_mfma_weights) or packed theta (VALU kernel)
   const double *inv_t; // inv_t[t] = RN(1.0 / t) in double, t = 1..T-1 (running-mean division)
-  // in-kernel noise (split kernel only): per-rollout MRG32k3a states [6][K], read from rng_in and
+  // in-kernel noise (quad kernel only): per-rollout MRG32k3a states [6][K], read from rng_in and
   // written (advanced by 2T draws) to rng_out; inline_noise == 0 => eps is read from `noise`
   const uint32_t *rng_in;
   uint32_t *rng_out;
@@ -89,6 +89,23 @@ __device__ __forceinline__ float tanh_bias(float z, float bs)
   const float e = __builtin_amdgcn_exp2f(fmaf(z, kTanhScale, bs));
   const float r = __builtin_amdgcn_rcpf(e + 1.0f);
   return fmaf(-2.0f, r, 1.0f);
+}
+
+// Two at a time: the three multiply-adds become packed instructions (v_pk_fma_f32 / v_pk_add_f32,
+// one issue slot for two values); exp2 and rcp stay scalar (quarter-rate unit).  Same arithmetic per
+// element as tanh_bias.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 tanh_bias2(f32x2 z, f32x2 bs)
+{
+  const f32x2 y = __builtin_elementwise_fma(z, f32x2{kTanhScale, kTanhScale}, bs);
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(y.x);
+  e.y = __builtin_amdgcn_exp2f(y.y);
+  const f32x2 d = e + f32x2{1.0f, 1.0f};
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
 }
 
 // sin/cos for the kinematics and the track-cost look-ahead points (neural_net_model.cu:348-349,

@@ -1,6 +1,6 @@
 // noise_device.hpp -- device functions of the noise spec: MRG32k3a step and
 // jump, and the Box-Muller transform written only in IEEE basic operations.  Shared by the
-// stand-alone generator kernel (noise_mrg32k3a.hip) and the noise wavefront of the split rollout
+// stand-alone generator kernel (noise_mrg32k3a.hip) and the control wavefront of the quad rollout
 // kernel (rollout_mfma.hip); both must produce the same bits as a CPU statement of the spec.
 #pragma once
 

@@ -227,140 +227,373 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// rollout_split_kernel: the same rollout with the work of a 16-rollout group split over THREE
-// wavefronts of one workgroup (they land on three SIMDs of a CU; at K = 4096 most of the chip's
-// SIMDs are idle anyway):
-//   wave 0 "dynamics": controls + clamp + network + Euler update of [roll, u_x, u_y, yaw_mder].
-//          The learned dynamics do not depend on x, y, yaw, so this wave IS the T-step recurrence
-//          and nothing else sits on it.
-//   wave 1 "cost":     x, y, yaw kinematics, sin/cos, the two costmap fetches, MPPICosts::computeCost,
-//          the running mean and the crash flags -- consuming the per-step record
-//          (s3..s6 before the update, clamped u, du) that wave 0 leaves in an LDS ring.
-//   wave 2 "noise":    the control noise of the group's 16 rollouts (MRG32k3a + Box-Muller, one lane
-//          per rollout, the generator state goes HBM -> registers -> HBM once per launch), one phase
-//          ahead of wave 0, through a second LDS ring: eps never touches HBM.  With explicit noise
-//          (parity tests) this wave idles and wave 0 reads eps from the buffer.
-// Both rings hold two phases of kPhaseSteps steps; one workgroup barrier per phase (not per step)
-// hands a phase over, so the three waves run concurrently.  Arithmetic and its order are exactly
-// those of rollout_mfma_kernel and noise_kernel: results are bit-identical.
+// rollout_quad_kernel: FOUR wavefronts per 16 rollouts -- the network itself runs on two SIMDs.
+// Used while 4*K/16 <= number of SIMDs (K <= 4096 on MI355X), where every wave owns a SIMD.
+//
+// Why: the f32 MFMA occupies the f32 vector datapath (DESIGN.md 4.1), so one wave cannot go below
+// (MFMA cycles + VALU cycles) per step; halving the recurrence needs a second datapath.
+//   wave 0 / wave 1 "dynamics": each owns half of the 16-row M tiles of every hidden layer after
+//          the first (half of their MFMAs and tanh) and swaps its activations with the partner
+//          through LDS before the next layer: lane l of one wave needs exactly the registers of
+//          lane l of the other (same rollout j, same k-slot g), so a swap is one 16-byte store and
+//          one 16-byte load per lane.  The output layer (a single M tile, a serial chain) is
+//          computed by both, so both hold the new state.  Every dot product keeps its k-ascending
+//          order: bit-identical results.
+//   wave 2 "cost", wave 3 "control" (below).
+// What keeps synchronisation and everything else off the T-step recurrence:
+//   * layer 0 (two k-steps) is computed by BOTH dynamics waves, so only the layers after it are
+//     split and a step has NHID-1 activation swaps instead of NHID;
+//   * the four waves of a group are always co-resident (one workgroup), so they hand data over
+//     through LDS sequence words instead of s_barrier.  The LDS executes a wave's instructions
+//     in order: a wave writes its data, then its sequence word; a reader that sees the sequence
+//     word in one ds_read sees the data in the ds_read it issued after it.  A swap is then one
+//     store + one load round trip when the partner is already there;
+//   * wave 0 owns the M tiles that feed the first half of the next layer's k-steps, so it runs
+//     those MFMAs while its partner's half is in flight;
+//   * wave 3 is the "control" wave: noise (in-kernel MRG32k3a + Box-Muller, or the explicit eps
+//     buffer), the perturbed control, its write-back to HBM (before the clamp, Q3), the clamp, and
+//     the (u, du) record of the cost wave -- nothing of mppi_controller.cu:136-153 depends on the
+//     state, so it runs kRing steps ahead and the dynamics waves touch no global memory at all:
+//     per step they read one LDS word (their layer-0 B operand [u0,u1,0,0][g]);
+//   * wave 2 is the cost wave, software-pipelined by one step around its two costmap fetches.
+// Rings of kRing steps decouple the waves; in steady state only the two dynamics waves wait, and
+// only for each other.  Every spin loop draws on a per-wave budget; when it is exhausted the wave
+// stops waiting and the costs are poisoned with NaN (a loud failure instead of a hung GPU).
+// Arithmetic and its order are those of the other kernel forms: results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPhaseSteps = 10;
+constexpr int kRing = 16;  // steps in flight between the waves (power of two)
+constexpr int kCtlChunk = 4;  // steps of U / explicit eps the control wave requests at once
+constexpr int kSpinBudget = 1 << 22;
 
-template <int H, int NHID, bool AFFINE, bool CTRL>
-__global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
+// The hand-over instructions are written as ds_* assembly: they must reach the LDS in exactly this
+// order (data, then sequence word / sequence word, then data) and must not carry the waits the
+// compiler attaches to volatile accesses.  "memory" clobbers keep the ordinary LDS accesses
+// (records) on their side of a hand-over.
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ void lds_publish(uint32_t addr, int v)
+{
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_put4(uint32_t addr, f32x4 v)
+{
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// one word, wave-uniform
+__device__ __forceinline__ int lds_peek(uint32_t addr)
+{
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+// partner's sequence word, then its data; the control wave's publication count, then the lane's
+// layer-0 operand of the next step; the cost wave's consumption count
+template <int M2>
+__device__ __forceinline__ void quad_poll(uint32_t a_seq, uint32_t a_x, uint32_t a_pub, uint32_t a_b1,
+                                           uint32_t a_cd, int &f, f32x4 (&oth)[M2], int &cp, float &b1,
+                                           int &cd)
+{
+  static_assert(M2 == 1 || M2 == 2, "one or two M tiles per dynamics wave");
+  if constexpr (M2 == 1) {
+    asm volatile(
+        "ds_read_b32 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b32 %2, %7\n\tds_read_b32 %3, %8\n\t"
+        "ds_read_b32 %4, %9\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(f), "=&v"(oth[0]), "=&v"(cp), "=&v"(b1), "=&v"(cd)
+        : "v"(a_seq), "v"(a_x), "v"(a_pub), "v"(a_b1), "v"(a_cd)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b32 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %7 offset:16\n\tds_read_b32 %3, %8\n\t"
+        "ds_read_b32 %4, %9\n\tds_read_b32 %5, %10\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(f), "=&v"(oth[0]), "=&v"(oth[M2 - 1]), "=&v"(cp), "=&v"(b1), "=&v"(cd)
+        : "v"(a_seq), "v"(a_x), "v"(a_pub), "v"(a_b1), "v"(a_cd)
+        : "memory");
+  }
+  f = __builtin_amdgcn_readfirstlane(f);
+  cp = __builtin_amdgcn_readfirstlane(cp);
+  cd = __builtin_amdgcn_readfirstlane(cd);
+}
+
+template <int H, int NHID>
+struct QuadShared {
+  static constexpr int NX = (H / 32) * 4;  // floats a lane hands to its partner per swap
+  float xb[2][2][64][NX];                  // [swap parity][wave][lane][.]
+  int xseq[2][64];                         // swaps published by dynamics wave w (written per lane, word 0 is read)
+  float rec[kRing][kRolloutsPerWave][4];   // s3..s6 before the update of step t (dynamics wave 0)
+  int cost_done[64];                       // steps consumed by the cost wave
+  float ctl_b1[kRing][64];                 // layer-0 B operand of k-step 1, [u0c, u1c, 0, 0][g] per rollout
+  float ctl_rec[kRing][kRolloutsPerWave][4];  // clamped u0, u1, du0, du1 for the cost wave
+  int ctl_pub[64];                         // steps published by the control wave
+};
+
+template <int H, int NHID, int W>
+__device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H, NHID> &sh)
 {
   using N = MfmaNet<H, NHID>;
-  __shared__ __attribute__((aligned(16))) float ring[2][kPhaseSteps][kRolloutsPerWave][8];
-  __shared__ __attribute__((aligned(16))) float2 eps_ring[2][kPhaseSteps][kRolloutsPerWave];
+  constexpr int MT = N::MT, M2 = MT / 2, KSH = N::KSH, KS2 = KSH / 2, NX = M2 * 4, NSW = NHID - 1;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int T = a.T;
+
+  float A0[MT * 2], B0[MT * 4], AH[NSW * M2 * KSH], Bh[NSW * NX], AL[KSH], BL[4];
+#pragma unroll
+  for (int i = 0; i < MT * 2; i++) A0[i] = a.wpack[i * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < MT * 4; i++) B0[i] = a.wpack[(N::nA + i) * 64 + lane] * kTanhScale;
+#pragma unroll
+  for (int l = 1; l < NHID; l++)
+#pragma unroll
+    for (int i = 0; i < M2; i++) {
+      const int m = W * M2 + i;
+#pragma unroll
+      for (int s = 0; s < KSH; s++)
+        AH[((l - 1) * M2 + i) * KSH + s] = a.wpack[(N::nA0 + (l - 1) * N::nAH + m * KSH + s) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        Bh[(l - 1) * NX + i * 4 + r] = a.wpack[(N::nA + l * MT * 4 + m * 4 + r) * 64 + lane] * kTanhScale;
+    }
+#pragma unroll
+  for (int s = 0; s < KSH; s++) AL[s] = a.wpack[(N::nA0 + NSW * N::nAH + s) * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 4; r++) BL[r] = a.wpack[(N::nA + NHID * MT * 4 + r) * 64 + lane];
+
+  const uint32_t a_myseq = lds_addr(&sh.xseq[W][lane]);
+  const uint32_t a_seq = lds_addr(&sh.xseq[1 - W][0]);
+  const uint32_t a_pub = lds_addr(&sh.ctl_pub[0]);
+  const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+  const uint32_t a_xmine = lds_addr(&sh.xb[0][W][lane][0]);
+  const uint32_t a_xoth = lds_addr(&sh.xb[0][1 - W][lane][0]);
+  const uint32_t a_b1 = lds_addr(&sh.ctl_b1[0][lane]);
+  constexpr uint32_t kXbParity = 2 * 64 * NX * 4, kB1Slot = 64 * 4;
+
+  float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
+  int budget = kSpinBudget;
+  while (lds_peek(a_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+  float b1_next = sh.ctl_b1[0][lane];
+  int cd = 0;  // last value seen of the cost wave's consumption counter
+  for (int t = 0; t < T; t++) {
+    const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
+    const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
+    if (W == 0) {  // record for the cost wave: the state BEFORE this step's update
+      while (cd < t - kRing + 1 && --budget > 0) cd = lds_peek(a_cd);
+      sh.rec[t & (kRing - 1)][j][g] = b0;
+    }
+    // layer 0, all M tiles (both waves)
+    float act[MT * 4];
+    {
+      f32x4 acc0[MT];
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        z = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[m * 2 + 0], b0, z, 0, 0, 0);
+        acc0[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[m * 2 + 1], b1, z, 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 v = tanh_bias2(f32x2{acc0[m][r], acc0[m][r + 1]}, f32x2{B0[m * 4 + r], B0[m * 4 + r + 1]});
+          act[m * 4 + r] = v.x;
+          act[m * 4 + r + 1] = v.y;
+        }
+    }
+    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[M2];
+#pragma unroll
+    for (int l = 1; l < NHID; l++) {
+      // own M tiles of hidden layer l; after the first swap wave 0 arrives with k-steps 0..KS2-1
+      // already accumulated
+      if (!(W == 0 && l > 1)) {
+#pragma unroll
+        for (int i = 0; i < M2; i++) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int s = (W == 0 && l > 1) ? KS2 : 0; s < KSH; s++)
+#pragma unroll
+        for (int i = 0; i < M2; i++)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AH[((l - 1) * M2 + i) * KSH + s], act[s], acc[i], 0, 0, 0);
+      const int n = t * NSW + l;  // 1-based swap count
+      const uint32_t par = (uint32_t)(n & 1) * kXbParity;
+      f32x4 own[M2], oth[M2];
+#pragma unroll
+      for (int i = 0; i < M2; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 v = tanh_bias2(f32x2{acc[i][r], acc[i][r + 1]},
+                                     f32x2{Bh[(l - 1) * NX + i * 4 + r], Bh[(l - 1) * NX + i * 4 + r + 1]});
+          own[i][r] = v.x;
+          own[i][r + 1] = v.y;
+        }
+        lds_put4(a_xmine + par + 16 * i, own[i]);
+      }
+      lds_publish(a_myseq, n);
+      if (W == 0) {
+        // k-steps 0..KS2-1 of the next layer read wave 0's own tiles: run them while the partner's half
+        // is in flight
+#pragma unroll
+        for (int m = 0; m < M2; m++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) act[m * 4 + r] = own[m][r];
+        if (l == NHID - 1) {
+#pragma unroll
+          for (int s = 0; s < KS2; s++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(AL[s], act[s], o, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < M2; i++) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int s = 0; s < KS2; s++)
+#pragma unroll
+            for (int i = 0; i < M2; i++)
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AH[(l * M2 + i) * KSH + s], act[s], acc[i], 0, 0, 0);
+        }
+      }
+      // with every swap: the lane's layer-0 operand of step t+1 and the cost wave's progress (used
+      // after the first swap of a step only)
+      const uint32_t a_b1n = a_b1 + (uint32_t)((t + 1) & (kRing - 1)) * kB1Slot;
+      const int want_ctl = (l == 1) ? min(t + 2, T) : 0;
+      int f, cp, cdn;
+      float b1n;
+      for (;;) {
+        quad_poll<M2>(a_seq, a_xoth + par, a_pub, a_b1n, a_cd, f, oth, cp, b1n, cdn);
+        if (((f >= n) & (cp >= want_ctl)) || --budget <= 0) break;
+      }
+      if (l == 1) {
+        b1_next = b1n;
+        cd = cdn;
+      }
+      // activation of k-step s = 4m + r: from the wave that owns tile m
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) act[m * 4 + r] = ((m / M2) == W) ? own[m % M2][r] : oth[m % M2][r];
+    }
+#pragma unroll
+    for (int s = (W == 0) ? KS2 : 0; s < KSH; s++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(AL[s], act[s], o, 0, 0, 0);
+    s3 = fmaf(o[0] + BL[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
+    s4 = fmaf(o[1] + BL[1], a.dt, s4);
+    s5 = fmaf(o[2] + BL[2], a.dt, s5);
+    s6 = fmaf(o[3] + BL[3], a.dt, s6);
+  }
+}
+
+template <int H, int NHID, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
+{
+  static_assert((H / 16) % 2 == 0 && NHID >= 2, "needs two M tiles and a hidden layer to split");
+  constexpr int NSW = NHID - 1;
+  __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;  // wave-uniform
-  const int j = lane & 15, g = lane >> 4;
+  const int j = lane & 15;
   const int k = blockIdx.x * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
-  const int phases = (T + kPhaseSteps - 1) / kPhaseSteps;
-  // Barrier schedule (every wave executes exactly phases + 1 barriers):
-  //   noise:    produce eps(p) ; barrier #(p+1)            ... then one trailing barrier
-  //   dynamics: barrier #1 ; [eps(p) -> rec(p)] ; barrier #(p+2)
-  //   cost:     barrier #1 ; barrier #(p+2) ; consume rec(p)
+  // sequence words start at 0, the constant rows of the layer-0 operand at 0; the only barrier
+  if (role == 0) { sh.xseq[0][lane] = 0; sh.xseq[1][lane] = 0; sh.cost_done[lane] = 0; sh.ctl_pub[lane] = 0; }
+  if (role == 3)
+    for (int q = 0; q < kRing; q++) sh.ctl_b1[q][lane] = 0.0f;
+  __syncthreads();
 
-  if (role == 2) {
-    // -------------------------------- noise wave --------------------------------
-    const bool active = a.inline_noise && lane < kRolloutsPerWave;
+  if (role == 3) {
+    // -------------------------------- control wave --------------------------------
+    const bool inl = a.inline_noise != 0;
+    const bool active = lane < kRolloutsPerWave;
     Mrg gsta{0, 0, 0, 0, 0, 0};
-    if (active) {
+    if (active && inl) {
       gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
       gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
     }
-    for (int p = 0; p < phases; p++) {
-      const int nq = min(kPhaseSteps, T - p * kPhaseSteps);
-      if (active)
-        for (int q = 0; q < nq; q++) eps_ring[p & 1][q][lane] = noise_pair(gsta);
-      __syncthreads();
-    }
-    if (active) {
-      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
-      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
-    }
-    __syncthreads();
-  } else if (role == 0) {
-    // ------------------------------ dynamics wave ------------------------------
-    float A[N::nA], Bi[N::nBias];
-    load_weights<H, NHID>(a.wpack, lane, A, Bi);
-    float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
     float2 *const noise = reinterpret_cast<float2 *>(a.noise);
     const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
     const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
     const bool pure_noise_k = (k >= a.k99);  // :141
-    const bool inl = a.inline_noise != 0;
-    float2 eps = *(inl ? Useq : &noise[(size_t)k]);
-    float2 Unext = Useq[0];
-    __syncthreads();  // barrier #1: eps(0) is in the ring
-    float2 el_next = eps_ring[0][0][j];  // ring value of the step about to run (read one step ahead)
-    for (int p = 0; p < phases; p++) {
-      const int t0 = p * kPhaseSteps, nq = min(kPhaseSteps, T - t0);
-      for (int q = 0; q < nq; q++) {
-        const int t = t0 + q;
-        const float2 eg = eps;  // explicit-noise path: requested one step ahead from the buffer
-        const float2 el = el_next;
-        const float2 Ut = Unext;
-        const int tn = min(t + 1, T - 1);
-        // always one load (so the compiler can count outstanding loads and never drains the queue): the
-        // buffer with explicit noise, a cache-resident dummy (no HBM read of eps) with in-kernel noise
-        eps = *(inl ? Useq : &noise[(size_t)tn * K + k]);
-        Unext = Useq[tn];
-        if (q + 1 < nq) el_next = eps_ring[p & 1][q + 1][j];
-        const float2 e = inl ? el : eg;
-        // control perturbation, mppi_controller.cu:136-153
-        const bool nf = noise_free_k | (t < a.opt_delay);
-        const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
-        const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
-        float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
-        float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
-        noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
-        // pin the two prefetches above: issued here, first used at the top of the NEXT step, so
-        // their latency never sits on the recurrence (the scheduler otherwise sinks them)
-        __builtin_amdgcn_sched_barrier(0);
-        u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
-        u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
-        // record for the cost wave: state BEFORE this step's update, clamped u, du
-        float2 rec;
-        rec.x = (g == 0) ? s3 : (g == 1) ? s5 : (g == 2) ? u0 : du0;
-        rec.y = (g == 0) ? s4 : (g == 1) ? s6 : (g == 2) ? u1 : du1;
-        *reinterpret_cast<float2 *>(&ring[p & 1][q][j][2 * g]) = rec;
-        float d[4];
-        nn_forward_mfma<H, NHID>(A, Bi, g, s3, s4, s5, s6, u0, u1, d);
-        s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
-        s4 = fmaf(d[1], a.dt, s4);
-        s5 = fmaf(d[2], a.dt, s5);
-        s6 = fmaf(d[3], a.dt, s6);
+    const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]), a_seq1 = lds_addr(&sh.xseq[1][0]);
+    const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+    const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
+    int budget = kSpinBudget;
+    int seen_x = 0, seen_c = 0;  // swaps published by both dynamics waves / steps consumed by the cost wave
+    for (int t0 = 0; t0 < T; t0 += kCtlChunk) {
+      // the chunk's nominal controls and (explicit noise) eps are requested together
+      float2 Uq[kCtlChunk], eq[kCtlChunk];
+#pragma unroll
+      for (int q = 0; q < kCtlChunk; q++) {
+        const int tq = min(t0 + q, T - 1);
+        Uq[q] = Useq[tq];
+        eq[q] = (active && !inl) ? noise[(size_t)tq * K + k] : make_float2(0.0f, 0.0f);
       }
-      __syncthreads();  // barrier #(p+2): rec(p) is complete, eps(p+1) is in the ring
-      el_next = eps_ring[(p + 1) & 1][0][j];
-    }
-  } else {
-    // -------------------------------- cost wave --------------------------------
-    float x = a.state[0], y = a.state[1], yaw = a.state[2];
-    int crash = 0;
-    float J = 0.0f;
-    double rt_next = a.inv_t[0];
-    __syncthreads();  // barrier #1
-    for (int p = 0; p < phases; p++) {
-      __syncthreads();  // barrier #(p+2): rec(p) is complete
-      const int t0 = p * kPhaseSteps, nq = min(kPhaseSteps, T - t0);
-      for (int q = 0; q < nq; q++) {
+#pragma unroll
+      for (int q = 0; q < kCtlChunk; q++) {
         const int t = t0 + q;
-        const double rt = rt_next;
-        rt_next = a.inv_t[min(t + 1, T - 1)];
-        const float4 r0 = *reinterpret_cast<const float4 *>(&ring[p & 1][q][j][0]);  // s3 s4 s5 s6
-        const float4 r1 = *reinterpret_cast<const float4 *>(&ring[p & 1][q][j][4]);  // u0 u1 du0 du1
-        // getCrash of the previous step's update (costs.cu:301-305): r0.x is s3 after update t-1
-        crash |= (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));
+        if (t < T) {
+          // slot t % kRing held step t - kRing: the dynamics waves read it during step t - kRing - 1
+          // (done once both published the first swap of step t - kRing), the cost wave in step t - kRing
+          const int need_x = (t >= kRing) ? (t - kRing) * NSW + 1 : 0;
+          const int need_c = t - kRing + 1;
+          while ((seen_x < need_x || seen_c < need_c) && --budget > 0) {
+            seen_x = min(lds_peek(a_seq0), lds_peek(a_seq1));
+            seen_c = lds_peek(a_cd);
+            if (seen_x < need_x || seen_c < need_c) __builtin_amdgcn_s_sleep(2);
+          }
+          if (active) {
+            const float2 e = inl ? noise_pair(gsta) : eq[q];
+            // control perturbation, mppi_controller.cu:136-153
+            const bool nf = noise_free_k | (t < a.opt_delay);
+            const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+            const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+            float u0 = nf ? Uq[q].x : (pure_noise_k ? n0 : Uq[q].x + n0);
+            float u1 = nf ? Uq[q].y : (pure_noise_k ? n1 : Uq[q].y + n1);
+            noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+            u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+            u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+            const int slot = t & (kRing - 1);
+            sh.ctl_b1[slot][lane] = u0;
+            sh.ctl_b1[slot][kRolloutsPerWave + lane] = u1;
+            *reinterpret_cast<float4 *>(&sh.ctl_rec[slot][lane][0]) = make_float4(u0, u1, du0, du1);
+          }
+          lds_publish(a_mypub, t + 1);
+        }
+      }
+    }
+    if (active && inl) {
+      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
+      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+    }
+  } else if (role == 2) {
+    // -------------------------------- cost wave --------------------------------
+    // Software-pipelined by one step: the costmap texels of step t are requested in iteration t and
+    // consumed in iteration t+1, so their latency never stalls the consumption of the rings.
+    const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]);
+    const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int crash = 0, budget = kSpinBudget, seen = 0;
+    float J = 0.0f;
+    float tf_p = 0.0f, tb_p = 0.0f;
+    CostTerms ct_p{0.0f, 0.0f, 0.0f};
+    int rc_p = 0;
+    double rt_p = 0.0;
+    for (int t = 0; t <= T; t++) {
+      float tf = 0.0f, tb = 0.0f;
+      CostTerms ct{0.0f, 0.0f, 0.0f};
+      int rc = 0;
+      double rt = 0.0;
+      if (t < T) {
+        rt = a.inv_t[t];
+        // rec(t) is written before wave 0 publishes the first swap of step t; ctl(t) was published
+        // before the dynamics waves could start step t
+        const int need = t * NSW + 1;
+        while (seen < need && --budget > 0) {
+          seen = lds_peek(a_seq0);
+          if (seen < need) __builtin_amdgcn_s_sleep(1);
+        }
+        const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kRing - 1)][j][0]);      // s3 s4 s5 s6
+        const float4 r1 = *reinterpret_cast<const float4 *>(&sh.ctl_rec[t & (kRing - 1)][j][0]);  // u0 u1 du0 du1
+        lds_publish(a_mydone, t + 1);  // executes after the two reads (the LDS runs a wave's instructions in order)
+        rc = (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
         float spsi, cpsi;
         sincos_fast(yaw, spsi, cpsi);
         const float st[3] = {x, y, yaw};
-        float tf, tb;
         track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
-        CostTerms ct;
         cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
         // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
         const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
@@ -369,244 +602,25 @@ __global__ __launch_bounds__(192) void rollout_split_kernel(const RolloutArgs a)
         x = fmaf(sd0, a.dt, x);
         y = fmaf(sd1, a.dt, y);
         yaw = fmaf(sd2, a.dt, yaw);
-        // running mean over t = 1..T-1 (Q5); the t = 0 evaluation is discarded
-        int crash_new = crash;
-        const float c = cost_terms_b(a.cost, ct, tf, tb, crash_new);
-        const float Jn = running_mean(J, c, t, rt);
-        J = (t > 0) ? Jn : J;
-        crash = (t > 0) ? crash_new : crash;
       }
-    }
-    a.costs[k] = J + 0.0f;  // + terminalCost (= 0); the 4 lanes of a rollout write the same value
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// rollout_quad_kernel: FOUR wavefronts per 16 rollouts -- the network itself is split over two
-// SIMDs.  Used while 4*K/16 <= number of SIMDs (K <= 4096 on MI355X), where every wave owns a SIMD.
-//
-// Why: the f32 MFMA occupies the f32 vector datapath (DESIGN.md 4.1), so one wave cannot go below
-// (MFMA cycles + VALU cycles) per step.  Halving the recurrence needs a second datapath:
-//   wave 0 / wave 1 "dynamics": each owns half of the 16-row M tiles of every hidden layer (half of
-//          the MFMAs and half of the tanh of layers 0..NHID-1).  Before each following layer the
-//          two waves swap their activations through LDS -- lane l of one wave needs exactly
-//          registers r of lane l of the other (same rollout j, same k-slot g), so the swap is one
-//          16-byte store + one 16-byte load per lane -- and one workgroup barrier.  The output
-//          layer (a single M tile, a serial chain) is computed by both, so both hold the new state.
-//          Every dot product keeps its k-ascending order: bit-identical results.
-//   wave 2 "cost", wave 3 "noise": as in rollout_split_kernel, but in lock step with the NHID
-//          barriers per step; their work is cut at the barriers so that neither delays one.
-// ---------------------------------------------------------------------------------------------
-template <int H, int NHID, bool AFFINE, bool CTRL>
-__global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
-{
-  using N = MfmaNet<H, NHID>;
-  constexpr int MT = N::MT, M2 = MT / 2, KSH = N::KSH, NX = M2 * 4;
-  static_assert(MT % 2 == 0 && NHID >= 2, "needs two M tiles and two exchanges per step");
-  __shared__ __attribute__((aligned(16))) float xb[NHID][2][64][NX];
-  __shared__ __attribute__((aligned(16))) float rec[2][kRolloutsPerWave][8];
-  __shared__ __attribute__((aligned(16))) float2 eps_ring[3][kRolloutsPerWave];
-  const int lane = threadIdx.x & 63;
-  const int role = threadIdx.x >> 6;  // wave-uniform
-  const int j = lane & 15, g = lane >> 4;
-  const int k = blockIdx.x * kRolloutsPerWave + j;
-  const int K = a.K, T = a.T;
-  const bool inl = a.inline_noise != 0;
-  // Every wave executes exactly 1 + NHID*T barriers: the prologue barrier, then barriers
-  // B_0(t) .. B_{NHID-1}(t) of step t (one per activation swap).
-
-  if (role == 3) {
-    // -------------------------------- noise wave --------------------------------
-    // eps(t+2) is drawn during step t (generator steps after B_0, Box-Muller after B_1) into a
-    // three-slot ring; the dynamics waves read eps(t+1) after B_0(t).
-    const bool active = inl && lane < kRolloutsPerWave;
-    Mrg gsta{0, 0, 0, 0, 0, 0};
-    if (active) {
-      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
-      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
-      eps_ring[0][lane] = noise_pair(gsta);
-      if (T > 1) eps_ring[1][lane] = noise_pair(gsta);
-    }
-    __syncthreads();  // prologue
-    for (int t = 0; t < T; t++) {
-      const bool draw = active && (t + 2 < T);
-      __syncthreads();  // B_0(t)
-      float u1 = 0.0f, u2 = 0.0f;
-      if (draw) {
-        u1 = (float)mrg_next_z(gsta) * 0x1p-32f;
-        u2 = (float)mrg_next_z(gsta) * 0x1p-32f;
-      }
-      __syncthreads();  // B_1(t)
-      if (draw) {
-        const float r = sqrtf(-2.0f * spec_logf(u1));
-        float sn, cs;
-        spec_sincos2pi(u2, sn, cs);
-        eps_ring[(t + 2) % 3][lane] = make_float2(r * sn, r * cs);
-      }
-#pragma unroll
-      for (int e = 2; e < NHID; e++) __syncthreads();
-    }
-    if (active) {
-      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
-      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
-    }
-  } else if (role == 2) {
-    // -------------------------------- cost wave --------------------------------
-    float x = a.state[0], y = a.state[1], yaw = a.state[2];
-    int crash = 0;
-    float J = 0.0f;
-    double rt_next = a.inv_t[0];
-    __syncthreads();  // prologue
-    for (int t = 0; t < T; t++) {
-      const double rt = rt_next;
-      rt_next = a.inv_t[min(t + 1, T - 1)];
-      __syncthreads();  // B_0(t): rec(t) is in LDS
-      const float4 r0 = *reinterpret_cast<const float4 *>(&rec[t & 1][j][0]);  // s3 s4 s5 s6
-      const float4 r1 = *reinterpret_cast<const float4 *>(&rec[t & 1][j][4]);  // u0 u1 du0 du1
-      crash |= (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
-      float spsi, cpsi;
-      sincos_fast(yaw, spsi, cpsi);
-      const float st[3] = {x, y, yaw};
-      float tf, tb;
-      track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
-      const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
-      const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
-      const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
-      x = fmaf(sd0, a.dt, x);
-      y = fmaf(sd1, a.dt, y);
-      yaw = fmaf(sd2, a.dt, yaw);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // B_1(t)
-      CostTerms ct;
-      cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
-      int crash_new = crash;
-      const float c = cost_terms_b(a.cost, ct, tf, tb, crash_new);
-      const float Jn = running_mean(J, c, t, rt);
-      J = (t > 0) ? Jn : J;
-      crash = (t > 0) ? crash_new : crash;
-#pragma unroll
-      for (int e = 2; e < NHID; e++) __syncthreads();
+      if (t > 0) {  // finish step t-1: running mean over 1..T-1 (Q5); the t = 0 evaluation is discarded
+        const int tp = t - 1;
+        crash |= rc_p;
+        int crash_new = crash;
+        const float c = cost_terms_b(a.cost, ct_p, tf_p, tb_p, crash_new);
+        const float Jn = running_mean(J, c, tp, rt_p);
+        J = (tp > 0) ? Jn : J;
+        crash = (tp > 0) ? crash_new : crash;
+      }
+      tf_p = tf; tb_p = tb; ct_p = ct; rc_p = rc; rt_p = rt;
     }
+    if (budget <= 0) J = __builtin_nanf("");  // a hand-over never arrived: poison, do not hang
     a.costs[k] = J + 0.0f;
+  } else if (role == 0) {
+    quad_dynamics<H, NHID, 0>(a, sh);
   } else {
-    // --------------------------- dynamics waves (w = 0, 1) ---------------------------
-    const int w = role;
-    float A0[M2 * 2], AH[(NHID - 1) * M2 * KSH], AL[KSH], Bh[NHID * NX], BL[4];
-#pragma unroll
-    for (int i = 0; i < M2; i++) {
-      const int m = w * M2 + i;
-#pragma unroll
-      for (int s = 0; s < 2; s++) A0[i * 2 + s] = a.wpack[(m * 2 + s) * 64 + lane];
-#pragma unroll
-      for (int l = 1; l < NHID; l++)
-#pragma unroll
-        for (int s = 0; s < KSH; s++)
-          AH[((l - 1) * M2 + i) * KSH + s] = a.wpack[(N::nA0 + (l - 1) * N::nAH + m * KSH + s) * 64 + lane];
-#pragma unroll
-      for (int l = 0; l < NHID; l++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          Bh[l * NX + i * 4 + r] = a.wpack[(N::nA + l * MT * 4 + m * 4 + r) * 64 + lane] * kTanhScale;
-    }
-#pragma unroll
-    for (int s = 0; s < KSH; s++) AL[s] = a.wpack[(N::nA0 + (NHID - 1) * N::nAH + s) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < 4; r++) BL[r] = a.wpack[(N::nA + NHID * MT * 4 + r) * 64 + lane];
-
-    float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
-    float2 *const noise = reinterpret_cast<float2 *>(a.noise);
-    const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
-    const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
-    const bool pure_noise_k = (k >= a.k99);  // :141
-    float2 eps = *(inl ? Useq : &noise[(size_t)k]);
-    float2 Unext = Useq[0];
-    __syncthreads();  // prologue: eps(0), eps(1) are in the ring
-    float2 el_next = eps_ring[0][j];
-    for (int t = 0; t < T; t++) {
-      const float2 eg = eps;
-      const float2 el = el_next;
-      const float2 Ut = Unext;
-      const int tn = min(t + 1, T - 1);
-      eps = *(inl ? Useq : &noise[(size_t)tn * K + k]);  // always one load; dummy with in-kernel noise
-      Unext = Useq[tn];
-      const float2 e = inl ? el : eg;
-      // control perturbation, mppi_controller.cu:136-153 (computed by both dynamics waves)
-      const bool nf = noise_free_k | (t < a.opt_delay);
-      const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
-      const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
-      float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
-      float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
-      if (w == 0) noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above (first used next step)
-      u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
-      u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
-      if (w == 0) {  // record for the cost wave: state BEFORE this step's update, clamped u, du
-        float2 rc;
-        rc.x = (g == 0) ? s3 : (g == 1) ? s5 : (g == 2) ? u0 : du0;
-        rc.y = (g == 0) ? s4 : (g == 1) ? s6 : (g == 2) ? u1 : du1;
-        *reinterpret_cast<float2 *>(&rec[t & 1][j][2 * g]) = rc;
-      }
-      // layer 0, own M tiles
-      const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
-      const float b1 = (g == 0) ? u0 : (g == 1) ? u1 : 0.0f;
-      f32x4 acc[M2];
-#pragma unroll
-      for (int i = 0; i < M2; i++) {
-        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        z = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[i * 2 + 0], b0, z, 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[i * 2 + 1], b1, z, 0, 0, 0);
-      }
-      float d[4];
-#pragma unroll
-      for (int e2 = 0; e2 < NHID; e2++) {
-        // own half of the activations of hidden layer e2, swapped with the partner wave
-        float own[NX], oth[NX];
-#pragma unroll
-        for (int i = 0; i < M2; i++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) own[i * 4 + r] = tanh_bias(acc[i][r], Bh[e2 * NX + i * 4 + r]);
-#pragma unroll
-        for (int q = 0; q < NX / 4; q++)
-          *reinterpret_cast<float4 *>(&xb[e2][w][lane][4 * q]) =
-              make_float4(own[4 * q], own[4 * q + 1], own[4 * q + 2], own[4 * q + 3]);
-        __syncthreads();  // B_e2(t)
-#pragma unroll
-        for (int q = 0; q < NX / 4; q++) {
-          const float4 v = *reinterpret_cast<const float4 *>(&xb[e2][1 - w][lane][4 * q]);
-          oth[4 * q] = v.x; oth[4 * q + 1] = v.y; oth[4 * q + 2] = v.z; oth[4 * q + 3] = v.w;
-        }
-        if (e2 == 0) el_next = eps_ring[(t + 1) % 3][j];  // written during step t-1, visible after B_0(t)
-        // activation of k-step s = 4m + r: from the wave that owns tile m
-        float act[MT * 4];
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const bool mine = (m / M2) == 0;  // tile owned by wave 0
-            const int li = (m % M2) * 4 + r;
-            act[m * 4 + r] = (w == 0) ? (mine ? own[li] : oth[li]) : (mine ? oth[li] : own[li]);
-          }
-        if (e2 < NHID - 1) {
-#pragma unroll
-          for (int i = 0; i < M2; i++) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int s = 0; s < KSH; s++)
-#pragma unroll
-            for (int i = 0; i < M2; i++)
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AH[(e2 * M2 + i) * KSH + s], act[s], acc[i], 0, 0, 0);
-        } else {
-          f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int s = 0; s < KSH; s++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(AL[s], act[s], o, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; r++) d[r] = o[r] + BL[r];
-        }
-      }
-      s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
-      s4 = fmaf(d[1], a.dt, s4);
-      s5 = fmaf(d[2], a.dt, s5);
-      s6 = fmaf(d[3], a.dt, s6);
-    }
+    quad_dynamics<H, NHID, 1>(a, sh);
   }
 }
 
@@ -646,20 +660,12 @@ template <int H, int NHID>
 static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipStream_t stream)
 {
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
-  if (block_threads == 512) {  // quad form: two dynamics waves + cost wave + noise wave per 16 rollouts
+  if (block_threads == 512) {  // quad form: two dynamics waves + cost wave + control wave per 16 rollouts
     const dim3 grid(a.K / kRolloutsPerWave), block(256);
     if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
     else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
     else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
-    return hipGetLastError();
-  }
-  if (block_threads == 128) {  // split form: one dynamics wave + one cost wave per 16 rollouts
-    const dim3 grid(a.K / kRolloutsPerWave), block(192);
-    if (affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
-    else if (affine && ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
-    else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_split_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rollout_split_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
   const int waves = a.K / kRolloutsPerWave;

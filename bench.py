@@ -27,7 +27,7 @@ import numpy as np
 
 # Algorithmic HBM bytes per state update.  SURVEY 8(d) counts 32 B for the
 # whole solve with a stand-alone generator (noise write 8 + rollout read 8 + write-back 8 +
-# reduction read 8).  The split and quad rollout kernels draw eps in-kernel, so their share is the 8-B
+# reduction read 8).  The quad rollout kernel draws eps in-kernel, so its share is the 8-B
 # write-back only (whole solve 16 B); the single-wave / VALU forms read eps from HBM (16 B).
 ROLLOUT_BYTES_INLINE_NOISE = 8
 ROLLOUT_BYTES_BUFFERED_NOISE = 16
@@ -247,7 +247,7 @@ def main():
             fl = flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            bpu = ROLLOUT_BYTES_INLINE_NOISE if ("split" in variant or "quad" in variant) else ROLLOUT_BYTES_BUFFERED_NOISE
+            bpu = ROLLOUT_BYTES_INLINE_NOISE if ("quad" in variant) else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

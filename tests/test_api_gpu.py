@@ -161,12 +161,12 @@ def test_update_model_and_costmap_and_limits(golden_dir):
 
 @pytest.mark.parametrize("K,T", [(64, 2), (64, 11), (128, 10), (192, 29), (64, 203)])
 def test_edge_sizes(K, T):
-    """Smallest K, T = 2, T around the 10-step phase of the LDS rings, T > 2 phases."""
+    """Smallest K, T = 2, T around the control wave's 4-step chunks and the 16-step LDS rings."""
     cfg = S.make_config(K, T, track="ring")
     eps = noise_for(cfg)
     U0 = warm_U(cfg)
     ref = O.Oracle(cfg).compute_control(cfg["start_state"], U0, np.zeros(4, np.float32), eps)
-    for variant in ("split", "fused", "valu"):
+    for variant in ("quad", "fused", "valu"):
         sol = capi.Solver(cfg)
         sol.set_rollout_variant(variant)
         sol.set_control_seq(U0)
@@ -176,7 +176,7 @@ def test_edge_sizes(K, T):
         np.testing.assert_array_equal(sol.get_applied_controls().view(np.uint32), ref["V"][-1].view(np.uint32))
         assert float(np.percentile(rel_err(got["costs"], ref["costs"]), 95)) < 1e-5, variant
         assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4, variant
-        # generator mode on the same handle (in-kernel noise for split, stand-alone kernel otherwise)
+        # generator mode on the same handle (in-kernel noise for quad, stand-alone kernel otherwise)
         sol.seed(1234, 0)
         sol.set_control_seq(U0)
         sol.compute_control(cfg["start_state"])
@@ -198,7 +198,7 @@ def test_baseline_config4_full_size_properties():
     eps = rng.standard_normal((1, K, T, 2)).astype(np.float32)
     ref_costs, _, _ = O.Oracle(small, nthreads=8).rollouts(cfg["start_state"], U0, eps[0, :64])
     outs = {}
-    for variant in ("auto", "split"):
+    for variant in ("auto", "quad"):
         sol = capi.Solver(cfg)
         sol.set_rollout_variant(variant)
         sol.set_control_seq(U0)
@@ -207,9 +207,9 @@ def test_baseline_config4_full_size_properties():
         outs[variant] = dict(sol.get_results(), V=sol.get_applied_controls(), name=sol.rollout_variant())
         sol.close()
     a = outs["auto"]
-    assert "fused" in a["name"] and "split" in outs["split"]["name"]  # auto picks the single-wave form here
-    np.testing.assert_array_equal(a["costs"].view(np.uint32), outs["split"]["costs"].view(np.uint32))
-    np.testing.assert_array_equal(a["U"].view(np.uint32), outs["split"]["U"].view(np.uint32))
+    assert "fused" in a["name"] and "quad" in outs["quad"]["name"]  # auto picks the single-wave form here
+    np.testing.assert_array_equal(a["costs"].view(np.uint32), outs["quad"]["costs"].view(np.uint32))
+    np.testing.assert_array_equal(a["U"].view(np.uint32), outs["quad"]["U"].view(np.uint32))
     assert float(np.percentile(rel_err(a["costs"][:64], ref_costs), 90)) < 1e-5
     w = a["w"]
     assert w.max() == 1.0 and np.all(w >= 0) and np.all(np.isfinite(a["U"]))

@@ -154,20 +154,24 @@ def test_mfma_and_valu_variants_agree_bitwise():
         np.testing.assert_array_equal(a["U"].view(np.uint32), o["U"].view(np.uint32))
 
 
-@pytest.mark.parametrize("K,T,track,layers", [(512, 43, "oval", None), (256, 30, "ring", [6, 64, 64, 4])])
-def test_split_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
-    """The two-wave (dynamics + cost) form does the same arithmetic in the same order as the
-    single-wave form; T is not a multiple of the LDS ring's phase length on purpose."""
-    cfg = S.make_config(K, T, layers=layers, track=track)
+@pytest.mark.parametrize("K,T,track,layers", [(512, 43, "oval", None), (256, 30, "ring", [6, 64, 64, 4]),
+                                              (192, 37, "oval", [6, 32, 32, 32, 32, 4])])
+def test_quad_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
+    """The four-wave form (network split over two wavefronts, cost wave, control wave) does the same
+    arithmetic in the same order as the single-wave form; T is not a multiple of the control wave's
+    chunk nor of the LDS rings' depth on purpose.  Explicit noise here; generator mode below."""
+    kw = {}
+    if layers:
+        l, th = P.synthetic_model(layers, seed=4)
+        kw = dict(layers=l, theta=th)
+    cfg = S.make_config(K, T, track=track, **kw)
     U0 = warm_U(cfg)
     _, a = _solve_both(cfg, U0=U0, variant="fused")
-    _, b = _solve_both(cfg, U0=U0, variant="split")
     _, c = _solve_both(cfg, U0=U0, variant="quad")
-    assert "fused" in a["variant"] and "split" in b["variant"] and "quad" in c["variant"]
-    for o in (b, c):
-        np.testing.assert_array_equal(a["costs"].view(np.uint32), o["costs"].view(np.uint32))
-        np.testing.assert_array_equal(a["V"].view(np.uint32), o["V"].view(np.uint32))
-        np.testing.assert_array_equal(a["U"].view(np.uint32), o["U"].view(np.uint32))
+    assert "fused" in a["variant"] and "quad" in c["variant"]
+    np.testing.assert_array_equal(a["costs"].view(np.uint32), c["costs"].view(np.uint32))
+    np.testing.assert_array_equal(a["V"].view(np.uint32), c["V"].view(np.uint32))
+    np.testing.assert_array_equal(a["U"].view(np.uint32), c["U"].view(np.uint32))
 
 
 def test_cold_start_zero_controls():
