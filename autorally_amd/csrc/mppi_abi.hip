@@ -79,7 +79,8 @@ struct mppi_handle {
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
   unsigned seq = 0;             // sequence number of the last enqueued solve (published in h_res[3])
-  unsigned *d_counter = nullptr;
+  unsigned *d_counter = nullptr;  // [1 + T] arrival counters of the tail kernel
+  float *d_part = nullptr;        // [T][K/64][2] chain results of the tail kernel when K > 4096
   float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
 
   std::vector<float> U, hist, theta, map_rgba;
@@ -466,7 +467,7 @@ int enqueue_solve(mppi_handle *h, const float *state)
     const int sstride = h->cfg.optimization_stride;
     const bool want_slid = last && sstride >= 1 && sstride < T;
     HIPCHK(h, launch_solve_tail(h->d_costs, noise, h->d_in, h->d_in + 2 * T, h->d_w, h->d_scal, h->d_res_map,
-                                h->d_counter, K, T, h->cfg.gamma, last ? 1 : 0, h->seq,
+                                h->d_counter, h->d_part, K, T, h->cfg.gamma, last ? 1 : 0, h->seq,
                                 want_slid ? h->d_in_buf[1 - h->in_cur] : nullptr, sstride,
                                 h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
     if (last) h->slid_valid = want_slid;
@@ -482,7 +483,7 @@ void free_all(mppi_handle *h)
 {
   if (!h) return;
   float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
-                 h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map};
+                 h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map, h->d_part};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
@@ -586,7 +587,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   h->hist.assign(4, 0.0f);  // control_hist_, :347
   // noise chunking: enough (k, chunk) threads to cover the chip
   {
-    int chunks = std::max(1, (1 << 16) / h->K);
+    int chunks = std::max(1, (1 << 18) / h->K);
     chunks = std::min(chunks, 64);
     h->noise_L = std::max(1, (h->T + chunks - 1) / chunks);
     h->noise_C = (h->T + h->noise_L - 1) / h->noise_L;
@@ -609,8 +610,9 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_res, sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_scal, sizeof(float) * 4));
   CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)h->n_slots));
-  CR(hipMalloc(&h->d_counter, sizeof(unsigned)));
-  CR(hipMemset(h->d_counter, 0, sizeof(unsigned)));
+  CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
+  CR(hipMemset(h->d_counter, 0, sizeof(unsigned) * (1 + (size_t)h->T)));
+  if (h->K > 4096) CR(hipMalloc(&h->d_part, sizeof(float) * (size_t)h->T * (h->K / 64) * 2));
   CR(hipMalloc(&h->d_stage, sizeof(float) * KT2));
   CR(hipMalloc(&h->d_costs, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_w, sizeof(float) * h->K));

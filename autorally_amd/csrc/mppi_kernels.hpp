@@ -31,7 +31,7 @@ hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const fl
 
 // solve_kernels.hip
 hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
-                             float *scal, float *res, unsigned *counter, int K, int T, float gamma,
+                             float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,
                              int last_iter, unsigned seq, float *slid, int slide_stride, float init0,
                              float init1, hipStream_t stream);
 hipError_t launch_slide(float *in, int T, int stride, float init0, float init1, hipStream_t stream);

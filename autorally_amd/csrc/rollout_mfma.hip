@@ -86,7 +86,12 @@ __device__ __forceinline__ void nn_hidden(const float (&A)[MfmaNet<H, NHID>::nA]
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_bias(acc[m][r], Bi[boff + m * 4 + r]);
+      for (int r = 0; r < 4; r += 2) {
+        const f32x2 v = tanh_bias2(f32x2{acc[m][r], acc[m][r + 1]},
+                                   f32x2{Bi[boff + m * 4 + r], Bi[boff + m * 4 + r + 1]});
+        act[m * 4 + r] = v.x;
+        act[m * 4 + r + 1] = v.y;
+      }
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -111,7 +116,12 @@ __device__ __forceinline__ void nn_last(const float (&A)[MfmaNet<H, NHID>::nA],
 #pragma unroll
   for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) act[m * 4 + r] = tanh_bias(acc[m][r], Bi[boff + m * 4 + r]);
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2 v = tanh_bias2(f32x2{acc[m][r], acc[m][r + 1]},
+                                 f32x2{Bi[boff + m * 4 + r], Bi[boff + m * 4 + r + 1]});
+      act[m * 4 + r] = v.x;
+      act[m * 4 + r + 1] = v.y;
+    }
   f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < KSH; s++)

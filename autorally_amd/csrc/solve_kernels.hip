@@ -18,10 +18,14 @@ namespace mppi {
 //       here, so U is bit-identical to the reference order given the same weights.
 //   U = SavitzkyGolay([hist | Unew | pad])   (last iteration only), mppi_controller.cu:468-499
 //
-// Grid = T workgroups (one per timestep) + one that publishes the weights and scalars.  Every workgroup recomputes beta and eta from the K
+// Grid = T*C workgroups (one per timestep and chunk of kRedChunk rollouts; C = 1 up to K = 4096) +
+// one that publishes the weights and scalars.  Every workgroup recomputes beta and eta from the K
 // costs (16 KB at K=4096, L2 resident; same code in every workgroup => the same bits), stages its
-// row V[t][*][*] (K*8 contiguous bytes of the time-major buffer) through LDS with 16-B loads and runs
-// the (m, j) chains.  The workgroup that finishes last (agent-scope release / acquire around an
+// piece of row V[t][*][*] (contiguous bytes of the time-major buffer) through LDS with 16-B loads and
+// runs the (m, j) chains.  With C > 1 the chain results go to a global scratch and the workgroup that
+// arrives last at the row's counter adds them in order; beta, eta and the weights then come from
+// weights_kernel (one launch more, but no K exps per workgroup -- the single-launch form is the
+// latency path of K <= 4096).  The workgroup that finishes last (agent-scope release / acquire around an
 // arrival counter, MI355X guide G16) smooths the sequence and writes the single result block --
 // (beta, eta, trajectory cost, sequence number) + U -- straight into host-mapped memory, so the
 // host needs no D2H copy and no stream synchronise: it polls the sequence number.
@@ -75,6 +79,80 @@ __device__ __forceinline__ float block_sum(float v, float *red, float *bc)
   return r;
 }
 
+// weights_kernel (K > kRedChunk only): beta, w_k = expf(-gamma (J_k - beta)), eta, trajectory cost --
+// once, in one workgroup, instead of once per workgroup of the tail kernel.
+constexpr int kWeightThreads = 1024;
+constexpr int kWeightCache = 16;  // float4 per thread held in registers: 65536 costs
+__global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__restrict__ costs,
+                                                                 float *__restrict__ w, float *__restrict__ scal,
+                                                                 int K, float gamma)
+{
+  __shared__ float red[kWeightThreads / 64];
+  __shared__ float bc;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto bcast = [&](float v, bool is_min) {
+    v = is_min ? wave_min(v) : wave_sum(v);
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    if (tid == 0) {
+      float r = red[0];
+      for (int i = 1; i < kWeightThreads / 64; i++) r = is_min ? fminf(r, red[i]) : r + red[i];
+      bc = r;
+    }
+    __syncthreads();
+    const float r = bc;
+    __syncthreads();
+    return r;
+  };
+  // The first kWeightCache*4096 costs stay in registers (one 16-B load per thread and slot, all in
+  // flight together); anything beyond is re-read from memory.
+  const float4 *c4 = reinterpret_cast<const float4 *>(costs);
+  float4 *w4 = reinterpret_cast<float4 *>(w);
+  const int K4 = K / 4;
+  float4 c[kWeightCache];
+#pragma unroll
+  for (int i = 0; i < kWeightCache; i++) {
+    const int q = i * kWeightThreads + tid;
+    c[i] = (q < K4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+  }
+  float m = INFINITY;
+#pragma unroll
+  for (int i = 0; i < kWeightCache; i++) m = fminf(fminf(m, fminf(c[i].x, c[i].y)), fminf(c[i].z, c[i].w));
+  for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) m = fminf(m, costs[k]);
+  const float beta = bcast(m, true);
+  float part = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kWeightCache; i++) {
+    const int q = i * kWeightThreads + tid;
+    if (q < K4) {
+      c[i].x = expf(-gamma * (c[i].x - beta));  // normExpKernel :201
+      c[i].y = expf(-gamma * (c[i].y - beta));
+      c[i].z = expf(-gamma * (c[i].z - beta));
+      c[i].w = expf(-gamma * (c[i].w - beta));
+      w4[q] = c[i];
+      part += (c[i].x + c[i].y) + (c[i].z + c[i].w);
+    }
+  }
+  for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) {
+    const float e = expf(-gamma * (costs[k] - beta));
+    w[k] = e;
+    part += e;
+  }
+  const float eta = bcast(part, false);
+  float tc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kWeightCache; i++) {
+    const int q = i * kWeightThreads + tid;
+    if (q < K4) tc += (c[i].x * c[i].x / eta + c[i].y * c[i].y / eta) + (c[i].z * c[i].z / eta + c[i].w * c[i].w / eta);  // :651 (Q8)
+  }
+  for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) {
+    const float e = w[k];  // own store
+    tc += e * e / eta;
+  }
+  const float traj = bcast(tc, false);
+  if (tid == 0) { scal[0] = beta; scal[1] = eta; scal[2] = traj; }
+}
+
 struct TailArgs {
   const float *costs;   // [K]
   const float *V;       // [T][K][2] applied controls of this iteration
@@ -83,7 +161,9 @@ struct TailArgs {
   float *w;             // [K] exp weights (for mppi_get_results)
   float *scal;          // [3] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup)
   float *res;           // host-mapped result block: [beta, eta, traj, seq-bits | U(2T)]
-  unsigned *counter;    // arrival counter, zero on entry, reset by the last workgroup
+  unsigned *counter;    // [1 + T] arrival counters (all rows, then per row), zero on entry, reset by the last arriver
+  float *part;          // [T][K/64][2] chain results when a row is spread over several workgroups (K > kRedChunk)
+  int pre;              // K > kRedChunk: beta, eta, trajectory cost and w[] were computed by weights_kernel
   int K, T;
   float gamma;
   float *slid;          // optional [2T + 4]: receives [U | hist] slid by slide_stride (or nullptr)
@@ -104,81 +184,73 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   __shared__ int is_last;
   extern __shared__ float dyn[];  // partial[K/64][2], then X[(T+4)*2] for the smoothing
   float *partial = dyn;
-  const int t = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int K = a.K, T = a.T;
+  const int C = (K + kRedChunk - 1) / kRedChunk;  // workgroups per row
+  const bool extra = ((int)blockIdx.x == T * C);  // (single-launch form) publishes w[], beta, eta, trajectory cost
+  const int t = extra ? 0 : (int)blockIdx.x / C;
+  const int base = extra ? 0 : ((int)blockIdx.x % C) * kRedChunk;
+  const int n = min(kRedChunk, K - base);  // rollouts of this workgroup's chunk (multiple of 64)
 
-  // ---- weights: beta, eta (every workgroup), w[] and the trajectory cost (workgroup 0) ----
-  // When all K weights fit the LDS tile (K <= kRedChunk) each exp is evaluated once per workgroup
-  // and kept there; otherwise it is re-evaluated per chunk (same bits either way).
-  const bool cached = (K <= kRedChunk);
-  // The first chunk of row t is requested NOW, before anything else, so that its HBM latency
-  // overlaps the latency of the cost vector and the weight arithmetic below (the row was written by
-  // the rollout kernel on other XCDs: it comes from HBM / Infinity Cache, not from this L2).
-  const bool extra = (t == T);  // the (T+1)-th workgroup: publishes w[], beta, eta, trajectory cost
-  const float *row = a.V + (size_t)(extra ? 0 : t) * K * 2;
+  // The chunk of row t is requested NOW, before anything else, so that its HBM latency overlaps the
+  // latency of the cost vector and the weight arithmetic below (the row was written by the rollout
+  // kernel on other XCDs: it comes from HBM / Infinity Cache, not from this L2).
+  const float *row = a.V + ((size_t)t * K + base) * 2;
   constexpr int kPre = kRedChunk / 2 / kTailThreads;  // float4 per thread in a full chunk
   float4 pre[kPre];
   {
-    const int n0 = min(kRedChunk, K);
     const float4 *src0 = reinterpret_cast<const float4 *>(row);
 #pragma unroll
     for (int i = 0; i < kPre; i++) {
       const int q = tid + i * kTailThreads;
-      pre[i] = (q < n0 / 2) ? src0[q] : make_float4(0, 0, 0, 0);
+      pre[i] = (q < n / 2) ? src0[q] : make_float4(0, 0, 0, 0);
     }
   }
-  float m = INFINITY;
-  for (int k = tid; k < K; k += kTailThreads) m = fminf(m, a.costs[k]);
-  const float beta = block_min(m, red, &bc);
-  float part = 0.0f;
-  for (int k = tid; k < K; k += kTailThreads) {
-    const float e = expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
-    if (cached) wtile[k + (k >> 6)] = e;
-    part += e;
-  }
-  const float eta = block_sum(part, red, &bc);
-  float traj = 0.0f;
-  if (extra) {
-    float tc = 0.0f;
+  // ---- weights: beta, eta (every workgroup), w[] and the trajectory cost (the extra workgroup) ----
+  // Each exp of the workgroup's own chunk is evaluated once and kept in LDS.
+  float eta;
+  if (a.pre) {
+    eta = a.scal[1];
+    for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = a.w[base + q];
+  } else {
+    float m = INFINITY;
+    for (int k = tid; k < K; k += kTailThreads) m = fminf(m, a.costs[k]);
+    const float beta = block_min(m, red, &bc);
+    float part = 0.0f;
     for (int k = tid; k < K; k += kTailThreads) {
-      const float e = cached ? wtile[k + (k >> 6)] : expf(-a.gamma * (a.costs[k] - beta));
-      a.w[k] = e;
-      tc += e * e / eta;  // :651 (Q8)
+      const float e = expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
+      wtile[k + (k >> 6)] = e;
+      part += e;
     }
-    traj = block_sum(tc, red, &bc);
-    if (tid == 0) {
-      __hip_atomic_store(&a.scal[0], beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&a.scal[1], eta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&a.scal[2], traj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    eta = block_sum(part, red, &bc);
+    if (extra) {
+      float tc = 0.0f;
+      for (int k = tid; k < K; k += kTailThreads) {
+        const float e = wtile[k + (k >> 6)];
+        a.w[k] = e;
+        tc += e * e / eta;  // :651 (Q8)
+      }
+      const float traj = block_sum(tc, red, &bc);
+      if (tid == 0) {
+        __hip_atomic_store(&a.scal[0], beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.scal[1], eta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.scal[2], traj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 
-  // ---- weighted reduction of row t ----
-  for (int base = 0; base < (extra ? 0 : K); base += kRedChunk) {
-    const int n = min(kRedChunk, K - base);  // multiple of 64
-    const float4 *src = reinterpret_cast<const float4 *>(row + (size_t)base * 2);
-    if (base == 0) {
+  // ---- weighted reduction of the chunk ----
+  if (!extra) {
 #pragma unroll
-      for (int i = 0; i < kPre; i++) {
-        const int q = tid + i * kTailThreads;
-        if (q < n / 2) {
-          const int kk = 2 * q;
-          const int o = kk * 2 + (kk >> 6) * 2;
-          tile[o + 0] = pre[i].x; tile[o + 1] = pre[i].y; tile[o + 2] = pre[i].z; tile[o + 3] = pre[i].w;
-        }
-      }
-    } else {
-      for (int q = tid; q < n / 2; q += kTailThreads) {
-        const float4 v = src[q];  // rollouts base+2q, base+2q+1
-        const int kk = 2 * q;
+    for (int i = 0; i < kPre; i++) {
+      const int q = tid + i * kTailThreads;
+      if (q < n / 2) {
+        const int kk = 2 * q;  // rollouts base+2q, base+2q+1
         const int o = kk * 2 + (kk >> 6) * 2;
-        tile[o + 0] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+        tile[o + 0] = pre[i].x; tile[o + 1] = pre[i].y; tile[o + 2] = pre[i].z; tile[o + 3] = pre[i].w;
       }
     }
-    for (int q = tid; q < n; q += kTailThreads) {  // weight = w/normalizer, :244
-      const float e = cached ? wtile[q + (q >> 6)] : expf(-a.gamma * (a.costs[base + q] - beta));
-      wtile[q + (q >> 6)] = e / eta;
-    }
+    for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = wtile[q + (q >> 6)] / eta;  // weight = w/normalizer, :244
     __syncthreads();
     for (int c = tid; c < (n / 64) * 2; c += kTailThreads) {
       const int ml = c >> 1, j = c & 1;
@@ -187,7 +259,24 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
       float acc = 0.0f;
 #pragma unroll
       for (int i = 0; i < 64; i++) acc = fmaf(wp[i], p[2 * i], acc);  // u_system += weight*u :246
-      partial[(base / 64 + ml) * 2 + j] = acc;
+      if (C == 1) partial[ml * 2 + j] = acc;
+      else __hip_atomic_store(&a.part[((size_t)t * (K / 64) + base / 64 + ml) * 2 + j], acc, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (C > 1) {
+      // the row is spread over C workgroups: the last to arrive at the row's counter collects all
+      // chain results (same hand-off form as below: write-through stores, drained, then the counter)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(a.counter + 1 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (ticket == (unsigned)(C - 1)) ? 1 : 0;
+        if (is_last) __hip_atomic_store(a.counter + 1 + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+      }
+      __syncthreads();
+      if (!is_last) return;
+      for (int i = tid; i < (K / 64) * 2; i += kTailThreads)
+        partial[i] = __hip_atomic_load(&a.part[(size_t)t * (K / 64) * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
@@ -210,10 +299,11 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
   // (s_waitcnt vmcnt(0)) and only then one lane bumps the agent-scope counter; the last arriver
   // reads every handed-off word with sc1 loads.  No buffer_wbl2 / buffer_inv on this path. ----
+  __syncthreads();  // is_last may still be read from the row hand-off above
   if (tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (ticket == (unsigned)T) ? 1 : 0;  // T row workgroups + the extra one
+    is_last = (ticket == (unsigned)(a.pre ? T - 1 : T)) ? 1 : 0;  // T rows (+ the extra workgroup)
   }
   __syncthreads();
   if (!is_last) return;
@@ -345,16 +435,20 @@ __global__ void tk_to_kt_kernel(const float2 *__restrict__ src, float2 *__restri
 
 // ---- launchers ----
 hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
-                             float *scal, float *res, unsigned *counter, int K, int T, float gamma,
+                             float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,
                              int last_iter, unsigned seq, float *slid, int slide_stride, float init0,
                              float init1, hipStream_t stream)
 {
   TailArgs a;
   a.slid = slid; a.slide_stride = slide_stride; a.init0 = init0; a.init1 = init1;
-  a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter;
+  a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter; a.part = part;
   a.K = K; a.T = T; a.gamma = gamma; a.last_iter = last_iter; a.seq = seq;
   const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2) * sizeof(float);
-  hipLaunchKernelGGL(solve_tail_kernel, dim3(T + 1), dim3(kTailThreads), dyn, stream, a);
+  const int C = (K + kRedChunk - 1) / kRedChunk;
+  if (C > 1 && part == nullptr) return hipErrorInvalidValue;
+  a.pre = (C > 1) ? 1 : 0;
+  if (a.pre) hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, costs, w, scal, K, gamma);
+  hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), dyn, stream, a);
   return hipGetLastError();
 }
 

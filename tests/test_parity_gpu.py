@@ -95,6 +95,7 @@ CASES = [
     (2048, 100, "ring", None),
     (4096, 100, "oval", None),
     (256, 60, "ring", [6, 64, 64, 4]),
+    (6144, 24, "oval", None),  # rows of the weighted reduction spread over two workgroups (4096 + 2048)
 ]
 
 
