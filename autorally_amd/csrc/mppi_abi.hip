@@ -406,6 +406,10 @@ int wait_pending(mppi_handle *h)
   h->eta = h->h_res[1];
   h->traj_cost = h->h_res[2];
   memcpy(h->U.data(), h->h_res + 4, sizeof(float) * 2 * (size_t)h->T);  // device U == host U again
+  // The minimum-cost rollout has weight 1 and costs are capped (never NaN), so eta >= 1 always.
+  // Anything else means a rollout wavefront gave up on a hand-over (its spin budget) and poisoned
+  // its costs: report it instead of returning a NaN control sequence.
+  if (!(h->eta >= 1.0f)) return fail(h, MPPI_ERR_HIP, "solve produced a non-finite normaliser (device hand-over failed)");
   if (h->pending_timed) {
     h->pending_timed = false;
     for (size_t it = 0; it < h->ev.size(); it++) {
