@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmppi_hip.so")
 SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_valu.hip", "solve_kernels.hip",
-           "noise_mrg32k3a.hip"]
-HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
+           "noise_mrg32k3a.hip", "ddp_feedback.cpp"]
+HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file), which removes
 # the v_accvgpr_read per accumulator register after every layer
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])

@@ -58,6 +58,7 @@ SYMBOLS = [
     "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
     "mppi_compute_control", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
     "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
+    "mppi_set_ddp_weights", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
 ]
@@ -111,6 +112,9 @@ def lib():
         L.mppi_get_applied_controls.argtypes = [hp, fp, C.c_size_t]
         L.mppi_rollout_only.argtypes = [hp, fp, fp]
         L.mppi_nominal_traj.argtypes = [hp, fp, fp, fp]
+        L.mppi_set_ddp_weights.argtypes = [hp, fp, fp, fp]
+        L.mppi_compute_feedback_gains.argtypes = [hp, fp, fp, fp]
+        L.mppi_get_feedback_gains.argtypes = [hp, fp, fp, fp, fp, fp]
         L.mppi_enable_stage_timing.argtypes = [hp, C.c_int]
         L.mppi_reset_stage_times.argtypes = [hp]
         L.mppi_get_stage_times.argtypes = [hp, C.POINTER(StageTimes)]
@@ -305,6 +309,23 @@ class Solver:
         cs = np.zeros((self.T, 2), dtype=np.float32)
         self._ck(self.L.mppi_nominal_traj(self.h, _fp(_f32(state, (7,))), _fp(ss), _fp(cs)))
         return ss, cs
+
+    def set_ddp_weights(self, Q, R, Qf):
+        self._ck(self.L.mppi_set_ddp_weights(self.h, _fp(_f32(Q, (7,))), _fp(_f32(R, (2,))), _fp(_f32(Qf, (7,)))))
+
+    def compute_feedback_gains(self, state, target_x=None, target_u=None):
+        """computeFeedbackGains + getFeedbackGains: dict(feedback[T,2,7], feedforward[T,2], x, u, total_cost).
+        Targets default to the nominal trajectory of the current control sequence from `state`."""
+        tx = _fp(_f32(target_x, (self.T, 7))) if target_x is not None else None
+        tu = _fp(_f32(target_u, (self.T, 2))) if target_u is not None else None
+        self._ck(self.L.mppi_compute_feedback_gains(self.h, _fp(_f32(state, (7,))), tx, tu))
+        fb = np.zeros((self.T, 2, 7), dtype=np.float32)
+        ff = np.zeros((self.T, 2), dtype=np.float32)
+        x = np.zeros((self.T, 7), dtype=np.float32)
+        u = np.zeros((self.T, 2), dtype=np.float32)
+        tc = np.zeros(1, dtype=np.float32)
+        self._ck(self.L.mppi_get_feedback_gains(self.h, _fp(fb), _fp(ff), _fp(x), _fp(u), _fp(tc)))
+        return dict(feedback=fb, feedforward=ff, x=x, u=u, total_cost=float(tc[0]))
 
     def debug_dynamics(self, states, controls):
         states = _f32(states).reshape(-1, 7)

@@ -1,0 +1,307 @@
+// ddp_feedback.cpp -- see ddp_feedback.hpp.  Plain fp32 host arithmetic (the reference is Eigen
+// fp32 on the host); matrix products are written as k-ascending sums, association as in the source
+// expressions of ddp.h (e.g. (B^T Vxx) Phi).
+#include "ddp_feedback.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace mppi {
+namespace {
+
+template <int R, int C>
+struct Mat {
+  float v[R][C];
+  void zero() { std::memset(v, 0, sizeof(v)); }
+};
+
+template <int R, int K, int C>
+Mat<R, C> mul(const Mat<R, K> &a, const Mat<K, C> &b)
+{
+  Mat<R, C> o;
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j < C; j++) {
+      float s = 0.0f;
+      for (int k = 0; k < K; k++) s += a.v[i][k] * b.v[k][j];
+      o.v[i][j] = s;
+    }
+  return o;
+}
+template <int R, int C>
+Mat<C, R> transpose(const Mat<R, C> &a)
+{
+  Mat<C, R> o;
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j < C; j++) o.v[j][i] = a.v[i][j];
+  return o;
+}
+
+// Host network: forward pass keeping the pre-activations (computeDynamics, neural_net_model.cu:201-230)
+struct HostNet {
+  const DdpNet &n;
+  std::vector<std::vector<float>> z;  // weighted_in_[l]
+  std::vector<size_t> woff, boff;
+  explicit HostNet(const DdpNet &net) : n(net)
+  {
+    size_t off = 0;
+    for (int l = 0; l + 1 < n.n_layers; l++) {
+      woff.push_back(off);
+      boff.push_back(off + (size_t)n.layers[l] * n.layers[l + 1]);
+      off += (size_t)n.layers[l] * n.layers[l + 1] + n.layers[l + 1];
+      z.emplace_back(n.layers[l + 1]);
+    }
+  }
+  // out[4] = network(s3..s6, u0, u1)
+  void forward(const float *x, const float *u, float *out)
+  {
+    std::vector<float> a(n.max_width), b(n.max_width);
+    for (int i = 0; i < 4; i++) a[i] = x[3 + i];
+    a[4] = u[0];
+    a[5] = u[1];
+    const int L = n.n_layers - 1;
+    for (int l = 0; l < L; l++) {
+      const int nin = n.layers[l], nout = n.layers[l + 1];
+      const float *W = n.theta + woff[l], *bias = n.theta + boff[l];
+      for (int j = 0; j < nout; j++) {
+        float s = 0.0f;
+        for (int k = 0; k < nin; k++) s += W[j * nin + k] * a[k];
+        s += bias[j];
+        z[l][j] = s;
+        b[j] = (l < L - 1) ? std::tanh(s) : s;
+      }
+      a.swap(b);
+    }
+    for (int i = 0; i < 4; i++) out[i] = a[i];
+  }
+  // f(x, u): computeKinematics + computeDynamics (ddp_model_wrapper.h:57-68)
+  void f(const DdpProblem &p, const float *x, const float *u, float *dx)
+  {
+    dx[0] = std::cos(x[2]) * x[4] - std::sin(x[2]) * x[5];
+    dx[1] = std::sin(x[2]) * x[4] + std::cos(x[2]) * x[5];
+    dx[2] = p.negate_yaw_der ? -x[6] : x[6];
+    forward(x, u, dx + 3);
+  }
+  // computeGrad (neural_net_model.cu:233-264): 7 x 9 Jacobian of f wrt [x | u]
+  void jacobian(const float *x, const float *u, Mat<kDdpS, kDdpSC> &J)
+  {
+    J.zero();
+    const float sn = std::sin(x[2]), cs = std::cos(x[2]);
+    J.v[0][2] = -sn * x[4] - cs * x[5]; J.v[0][4] = cs; J.v[0][5] = -sn;
+    J.v[1][2] = cs * x[4] - sn * x[5];  J.v[1][4] = sn; J.v[1][5] = cs;
+    J.v[2][6] = -1.0f;  // regardless of negate_yaw_der (reference quirk)
+    float out[4];
+    forward(x, u, out);
+    const int L = n.n_layers - 1;  // weight matrices
+    // delta: [width of layer l+1... ][4], starts as the 4x4 identity at the output
+    std::vector<float> d(4 * 4, 0.0f), dn;
+    for (int i = 0; i < 4; i++) d[i * 4 + i] = 1.0f;
+    int rows = 4;  // == layers[L]
+    for (int l = L - 1; l > 0; l--) {
+      // delta <- (W_l^T delta) .* tanh'(z_{l-1})
+      const int nin = n.layers[l], nout = n.layers[l + 1];
+      const float *W = n.theta + woff[l];
+      dn.assign((size_t)nin * 4, 0.0f);
+      for (int i = 0; i < nin; i++)
+        for (int c = 0; c < 4; c++) {
+          float s = 0.0f;
+          for (int k = 0; k < nout; k++) s += W[k * nin + i] * d[k * 4 + c];
+          dn[i * 4 + c] = s;
+        }
+      for (int i = 0; i < nin; i++) {
+        const float th = std::tanh(z[l - 1][i]);
+        const float zp = 1.0f - std::pow(th, 2.0f);
+        for (int c = 0; c < 4; c++) dn[i * 4 + c] = dn[i * 4 + c] * zp;
+      }
+      d.swap(dn);
+      rows = nin;
+    }
+    (void)rows;
+    {
+      const int nin = n.layers[0], nout = n.layers[1];
+      const float *W = n.theta + woff[0];
+      dn.assign((size_t)nin * 4, 0.0f);
+      for (int i = 0; i < nin; i++)
+        for (int c = 0; c < 4; c++) {
+          float s = 0.0f;
+          for (int k = 0; k < nout; k++) s += W[k * nin + i] * d[k * 4 + c];
+          dn[i * 4 + c] = s;
+        }
+    }
+    // bottom-right 4 x 6 block += delta^T: rows = outputs, columns = [s3..s6, u0, u1]
+    for (int o = 0; o < 4; o++)
+      for (int i = 0; i < 6; i++) J.v[3 + o][3 + i] += dn[i * 4 + o];
+  }
+};
+
+inline float clamp_minmax(float v, float lo, float hi)
+{  // cwiseMin(u_max).cwiseMax(u_min), ddp.h:62,131
+  v = (v < hi) ? v : hi;
+  v = (v > lo) ? v : lo;
+  return v;
+}
+
+// x = A^{-1} b for symmetric 2x2 A via a pivoted LDL^T (Eigen::LDLT semantics: largest |diagonal| first)
+struct Ldlt2 {
+  int p;        // pivot index
+  float l, d0, d1;
+  bool ok;
+  explicit Ldlt2(const Mat<2, 2> &A)
+  {
+    p = (std::fabs(A.v[1][1]) > std::fabs(A.v[0][0])) ? 1 : 0;
+    const int q = 1 - p;
+    d0 = A.v[p][p];
+    l = A.v[q][p] / d0;
+    d1 = A.v[q][q] - l * A.v[q][p];
+    ok = std::isfinite(d0) && std::isfinite(d1) && std::isfinite(l) && d0 != 0.0f;
+  }
+  void solve(const float b[2], float x[2]) const
+  {
+    const int q = 1 - p;
+    const float z0 = b[p];
+    const float z1 = b[q] - l * z0;
+    const float w0 = z0 / d0;
+    const float w1 = (d1 != 0.0f) ? z1 / d1 : 0.0f;
+    const float v1 = w1;
+    const float v0 = w0 - l * v1;
+    x[p] = v0;
+    x[q] = v1;
+  }
+};
+
+}  // namespace
+
+int ddp_feedback_gains(const DdpNet &net, const DdpProblem &p, const float *x0, const float *target_x,
+                       const float *target_u, DdpResult &out)
+{
+  const int H = p.T;
+  const float dt = p.dt;
+  HostNet nn(net);
+  std::vector<float> x((size_t)H * kDdpS), u(target_u, target_u + (size_t)H * kDdpC);
+  // initial rollout, ddp.h:55-65
+  for (int i = 0; i < kDdpS; i++) x[i] = x0[i];
+  for (int i = 1; i < H; i++) {
+    float *up = &u[(size_t)(i - 1) * kDdpC];
+    if (i < H - 1)
+      for (int j = 0; j < kDdpC; j++) up[j] = clamp_minmax(up[j], p.u_lo[j], p.u_hi[j]);
+    float dx[kDdpS];
+    nn.f(p, &x[(size_t)(i - 1) * kDdpS], up, dx);
+    for (int s = 0; s < kDdpS; s++) x[(size_t)i * kDdpS + s] = x[(size_t)(i - 1) * kDdpS + s] + dx[s] * dt;
+  }
+  // Jacobians and cost derivatives, ddp.h:71-80
+  std::vector<Mat<kDdpS, kDdpSC>> df(H);
+  std::vector<float> dL((size_t)H * kDdpSC);
+  for (int k = 0; k < H; k++) {
+    nn.jacobian(&x[(size_t)k * kDdpS], &u[(size_t)k * kDdpC], df[k]);
+    for (int i = 0; i < kDdpS; i++)
+      for (int j = 0; j < kDdpSC; j++) df[k].v[i][j] = df[k].v[i][j] * dt;
+    for (int i = 0; i < kDdpS; i++) df[k].v[i][i] += 1.0f;
+    for (int i = 0; i < kDdpS; i++) dL[(size_t)k * kDdpSC + i] = p.Q[i] * (x[(size_t)k * kDdpS + i] - target_x[(size_t)k * kDdpS + i]);
+    for (int j = 0; j < kDdpC; j++) dL[(size_t)k * kDdpSC + kDdpS + j] = p.R[j] * (u[(size_t)k * kDdpC + j] - target_u[(size_t)k * kDdpC + j]);
+  }
+  // boundary condition, ddp.h:83-87 (target of the terminal cost = target_x[H-1], mppi_controller.cu:439)
+  Mat<kDdpS, kDdpS> Vxx;
+  Vxx.zero();
+  for (int i = 0; i < kDdpS; i++) Vxx.v[i][i] = p.Qf[i];
+  float Vx[kDdpS], Vlast = 0.0f;
+  for (int i = 0; i < kDdpS; i++) {
+    const float e = x[(size_t)(H - 1) * kDdpS + i] - target_x[(size_t)(H - 1) * kDdpS + i];
+    Vx[i] = p.Qf[i] * e;
+    Vlast += e * (p.Qf[i] * e);
+  }
+  out.feedback.assign((size_t)H * kDdpC * kDdpS, 0.0f);
+  out.feedforward.assign((size_t)H * kDdpC, 0.0f);
+  // backward pass, ddp.h:90-123
+  for (int k = H - 2; k >= 0; k--) {
+    Mat<kDdpS, kDdpS> Phi;
+    Mat<kDdpS, kDdpC> B;
+    for (int i = 0; i < kDdpS; i++) {
+      for (int j = 0; j < kDdpS; j++) Phi.v[i][j] = df[k].v[i][j];
+      for (int j = 0; j < kDdpC; j++) B.v[i][j] = df[k].v[i][kDdpS + j];
+    }
+    const Mat<kDdpS, kDdpS> PhiT = transpose(Phi);
+    const Mat<kDdpC, kDdpS> BT = transpose(B);
+    float qx[kDdpS], qu[kDdpC];
+    for (int i = 0; i < kDdpS; i++) {
+      float s = 0.0f;
+      for (int m = 0; m < kDdpS; m++) s += PhiT.v[i][m] * Vx[m];
+      qx[i] = dL[(size_t)k * kDdpSC + i] * dt + s;
+    }
+    for (int j = 0; j < kDdpC; j++) {
+      float s = 0.0f;
+      for (int m = 0; m < kDdpS; m++) s += BT.v[j][m] * Vx[m];
+      qu[j] = dL[(size_t)k * kDdpSC + kDdpS + j] * dt + s;
+    }
+    const Mat<kDdpC, kDdpS> BtV = mul(BT, Vxx);
+    Mat<kDdpC, kDdpS> qux = mul(BtV, Phi);           // d2L's bottom-left block is zero
+    Mat<kDdpS, kDdpS> qxx = mul(mul(PhiT, Vxx), Phi);
+    for (int i = 0; i < kDdpS; i++) qxx.v[i][i] = p.Q[i] * dt + qxx.v[i][i];
+    Mat<kDdpC, kDdpC> quu = mul(BtV, B);
+    for (int j = 0; j < kDdpC; j++) quu.v[j][j] = p.R[j] * dt + quu.v[j][j];
+    const Ldlt2 ldlt(quu);
+    if (!ldlt.ok) return 1;
+    Mat<kDdpC, kDdpS> Lk;
+    for (int c = 0; c < kDdpS; c++) {
+      const float b[2] = {-qux.v[0][c], -qux.v[1][c]};
+      float s[2];
+      ldlt.solve(b, s);
+      Lk.v[0][c] = s[0];
+      Lk.v[1][c] = s[1];
+    }
+    float lk[2];
+    {
+      const float b[2] = {-qu[0], -qu[1]};
+      ldlt.solve(b, lk);
+    }
+    for (int j = 0; j < kDdpC; j++) {
+      for (int c = 0; c < kDdpS; c++) out.feedback[((size_t)k * kDdpC + j) * kDdpS + c] = Lk.v[j][c];
+      out.feedforward[(size_t)k * kDdpC + j] = lk[j];
+    }
+    // value function, ddp.h:117-122
+    const Mat<kDdpS, kDdpC> quxT = transpose(qux);
+    const Mat<kDdpS, kDdpS> corr = mul(quxT, Lk);
+    Mat<kDdpS, kDdpS> Vn;
+    for (int i = 0; i < kDdpS; i++)
+      for (int j = 0; j < kDdpS; j++) Vn.v[i][j] = qxx.v[i][j] + corr.v[i][j];
+    for (int i = 0; i < kDdpS; i++)
+      for (int j = 0; j < kDdpS; j++) Vxx.v[i][j] = 0.5f * (Vn.v[i][j] + Vn.v[j][i]);
+    for (int i = 0; i < kDdpS; i++) Vx[i] = qx[i] + (quxT.v[i][0] * lk[0] + quxT.v[i][1] * lk[1]);
+  }
+  // forward pass with alpha = 1; iteration 0 is always accepted (ddp.h:125-152)
+  out.x.assign((size_t)H * kDdpS, 0.0f);
+  out.u.assign((size_t)H * kDdpC, 0.0f);
+  out.cost.assign(H, 0.0f);
+  for (int i = 0; i < kDdpS; i++) out.x[i] = x[i];
+  for (int k = 0; k + 1 < H; k++) {
+    float dx[kDdpS];
+    for (int i = 0; i < kDdpS; i++) dx[i] = out.x[(size_t)k * kDdpS + i] - x[(size_t)k * kDdpS + i];
+    float un[kDdpC];
+    for (int j = 0; j < kDdpC; j++) {
+      float s = 0.0f;
+      for (int i = 0; i < kDdpS; i++) s += out.feedback[((size_t)k * kDdpC + j) * kDdpS + i] * dx[i];
+      un[j] = (u[(size_t)k * kDdpC + j] + 1.0f * out.feedforward[(size_t)k * kDdpC + j]) + s;
+      un[j] = clamp_minmax(un[j], p.u_lo[j], p.u_hi[j]);
+      out.u[(size_t)k * kDdpC + j] = un[j];
+    }
+    float fx[kDdpS];
+    nn.f(p, &out.x[(size_t)k * kDdpS], un, fx);
+    for (int i = 0; i < kDdpS; i++) out.x[(size_t)(k + 1) * kDdpS + i] = out.x[(size_t)k * kDdpS + i] + fx[i] * dt;
+    float sc = 0.0f, cc = 0.0f;
+    for (int i = 0; i < kDdpS; i++) {
+      const float e = out.x[(size_t)k * kDdpS + i] - target_x[(size_t)k * kDdpS + i];
+      sc += e * (p.Q[i] * e);
+    }
+    for (int j = 0; j < kDdpC; j++) {
+      const float e = un[j] - target_u[(size_t)k * kDdpC + j];
+      cc += e * (p.R[j] * e);
+    }
+    out.cost[k] = (sc + cc) * dt;
+  }
+  out.cost[H - 1] = Vlast;
+  float tot = 0.0f;
+  for (int k = 0; k < H; k++) tot += out.cost[k];
+  out.total_cost = tot;
+  out.iterations = 1;
+  return 0;
+}
+
+}  // namespace mppi

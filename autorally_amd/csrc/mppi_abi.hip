@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mppi_kernels.hpp"
+#include "ddp_feedback.hpp"
 
 using namespace mppi;
 
@@ -79,6 +80,12 @@ struct mppi_handle {
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
   unsigned seq = 0;             // sequence number of the last enqueued solve (published in h_res[3])
+  // DDP feedback gains (row f2): weights of initDDP (mppi_controller.cu:410-417) and the last result
+  float ddp_Q[7] = {0.5f, 0.5f, 0.25f, 0.0f, 0.05f, 0.01f, 0.01f};
+  float ddp_R[2] = {10.0f, 10.0f};
+  float ddp_Qf[7] = {0, 0, 0, 0, 0, 0, 0};
+  DdpResult ddp;
+  bool have_ddp = false;
   unsigned *d_counter = nullptr;  // [1 + T] arrival counters of the tail kernel
   float *d_part = nullptr;        // [T][K/64][2] chain results of the tail kernel when K > 4096
   float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
@@ -1056,6 +1063,69 @@ int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
     control_seq[2 * t] = u[0];
     control_seq[2 * t + 1] = u[1];
   }
+  return MPPI_OK;
+}
+
+int mppi_set_ddp_weights(mppi_handle *h, const float Q[MPPI_STATE_DIM], const float R[MPPI_CONTROL_DIM],
+                         const float Qf[MPPI_STATE_DIM])
+{
+  if (!h || !Q || !R || !Qf) return MPPI_ERR_INVALID;
+  for (int i = 0; i < kStateDim; i++) {
+    if (!(Q[i] >= 0.0f) || !(Qf[i] >= 0.0f)) return fail(h, MPPI_ERR_INVALID, "Q and Qf must be non-negative");
+  }
+  for (int j = 0; j < kControlDim; j++)
+    if (!(R[j] > 0.0f)) return fail(h, MPPI_ERR_INVALID, "R must be positive");
+  memcpy(h->ddp_Q, Q, sizeof(h->ddp_Q));
+  memcpy(h->ddp_R, R, sizeof(h->ddp_R));
+  memcpy(h->ddp_Qf, Qf, sizeof(h->ddp_Qf));
+  return MPPI_OK;
+}
+
+int mppi_compute_feedback_gains(mppi_handle *h, const float state[MPPI_STATE_DIM],
+                                const float *target_state_seq, const float *target_control_seq)
+{
+  if (!h || !state) return MPPI_ERR_INVALID;
+  if ((target_state_seq == nullptr) != (target_control_seq == nullptr))
+    return fail(h, MPPI_ERR_INVALID, "give both target sequences or neither");
+  if (!h->have_nn) return fail(h, MPPI_ERR_STATE, "mppi_set_nn_params has not been called");
+  const int T = h->T;
+  std::vector<float> xs((size_t)T * kStateDim), us((size_t)T * kControlDim);
+  if (target_state_seq) {
+    memcpy(xs.data(), target_state_seq, sizeof(float) * xs.size());
+    memcpy(us.data(), target_control_seq, sizeof(float) * us.size());
+  } else {
+    int rc = mppi_nominal_traj(h, state, xs.data(), us.data());  // state_solution_, control_solution_
+    if (rc) return rc;
+  }
+  DdpNet net;
+  net.n_layers = h->net.n_layers;
+  net.layers = h->net.layers;
+  net.theta = h->theta.data();
+  net.max_width = h->net.max_width;
+  DdpProblem p;
+  p.T = T;
+  p.dt = (float)(1.0 / h->cfg.hz);  // mppi_controller.cu:408
+  for (int j = 0; j < kControlDim; j++) { p.u_lo[j] = h->u_lo[j]; p.u_hi[j] = h->u_hi[j]; p.R[j] = h->ddp_R[j]; }
+  for (int i = 0; i < kStateDim; i++) { p.Q[i] = h->ddp_Q[i]; p.Qf[i] = h->ddp_Qf[i]; }
+  p.negate_yaw_der = h->cfg.negate_yaw_der;
+  h->have_ddp = false;
+  if (ddp_feedback_gains(net, p, state, xs.data(), us.data(), h->ddp) != 0)
+    return fail(h, MPPI_ERR_STATE, "DDP: control Hessian could not be factorised");
+  h->have_ddp = true;
+  return MPPI_OK;
+}
+
+int mppi_get_feedback_gains(mppi_handle *h, float *feedback, float *feedforward, float *state_traj,
+                            float *control_traj, float *total_cost)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  if (!h->have_ddp) return fail(h, MPPI_ERR_STATE, "mppi_compute_feedback_gains has not succeeded yet");
+  const DdpResult &r = h->ddp;
+  if (feedback) memcpy(feedback, r.feedback.data(), sizeof(float) * r.feedback.size());
+  if (feedforward) memcpy(feedforward, r.feedforward.data(), sizeof(float) * r.feedforward.size());
+  if (state_traj) memcpy(state_traj, r.x.data(), sizeof(float) * r.x.size());
+  if (control_traj) memcpy(control_traj, r.u.data(), sizeof(float) * r.u.size());
+  if (total_cost) *total_cost = r.total_cost;
   return MPPI_OK;
 }
 

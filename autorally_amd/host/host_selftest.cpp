@@ -1,6 +1,7 @@
 // host_selftest.cpp -- CPU-only checks of the host layer (no GPU, no libmppi_hip):
 //   npz reader against a numpy-written model file and a round trip of the writer,
-//   launch-XML loader against a launch file in the reference's format.
+//   launch-XML loader against a launch file in the reference's format,
+//   the headless plant's feedback law.
 // usage: host_selftest <model.npz> <launch.xml> <tmp_dir>
 #include <cmath>
 #include <cstdio>
@@ -8,6 +9,7 @@
 
 #include "npz.hpp"
 #include "param_getter.hpp"
+#include "run_control_loop.hpp"  // SimPlant only: nothing of libmppi_hip is referenced
 
 using namespace mppi_host;
 
@@ -60,6 +62,27 @@ int main(int argc, char **argv)
   bool threw = false;
   try { (void)(int)p["gamma"]; } catch (const std::exception &) { threw = true; }
   REQUIRE(threw);  // typed like XmlRpcValue
+  // --- the plant's feedback law (autorally_plant.cpp:217-250) on a 3-step solution ---
+  {
+    SimPlant plant;
+    const std::vector<float> ss = {0, 0, 0, 0, 1, 0, 0, /**/ 1, 0, 0, 0, 1, 0, 0, /**/ 2, 0, 0, 0, 1, 0, 0};
+    const std::vector<float> cs = {0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f};
+    std::vector<float> g(3 * 14, 0.0f);
+    g[0 * 14 + 1] = -2.0f;      // t=0: steering reacts to the y error
+    g[1 * 14 + 1] = -4.0f;      // t=1
+    g[1 * 14 + 7 + 4] = 0.5f;   // t=1: throttle reacts to the u_x error
+    plant.setSolution(ss, cs, g, ControllerType::ACTUAL_STATE);
+    const float x[7] = {0.5f, 0.1f, 0, 0, 0.8f, 0, 0};
+    float u[2];
+    REQUIRE(!plant.controlAt(0.0, 0.02, x, true, u) && !plant.controlAt(0.04, 0.02, x, true, u));
+    REQUIRE(plant.controlAt(0.01, 0.02, x, false, u));                 // halfway between t=0 and t=1
+    REQUIRE(std::fabs(u[0] - 0.2f) < 1e-6f && std::fabs(u[1] - 0.3f) < 1e-6f);
+    REQUIRE(plant.controlAt(0.01, 0.02, x, true, u));
+    REQUIRE(std::fabs(u[0] - (0.2f + -3.0f * 0.1f)) < 1e-6f);           // K_y = -3 at the midpoint
+    REQUIRE(std::fabs(u[1] - (0.3f + 0.25f * (0.8f - 1.0f))) < 1e-6f);  // K_ux = 0.25
+    const float far[7] = {0, 10.0f, 0, 0, 1, 0, 0};
+    REQUIRE(plant.controlAt(0.01, 0.02, far, true, u) && u[0] == -1.0f);  // saturated like pubControl
+  }
   printf("host selftest OK (%zu params)\n", p.size());
   return 0;
 }

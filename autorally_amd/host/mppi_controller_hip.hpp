@@ -8,8 +8,8 @@
 // Same method names and argument meaning.  Differences forced by the environment: Eigen is not
 // available, so states are `const float*` / std::array<float,7> instead of Eigen::Matrix<float,7,1>;
 // K, BDIM and the layer list are runtime values instead of template constants (the reference must be
-// recompiled to change them, path_integral_main.cu:65-78).  DDP feedback gains are not part of the
-// hot path: computeFeedbackGains() is a documented no-op here.
+// recompiled to change them, path_integral_main.cu:65-78).  DDP feedback gains:
+// computeFeedbackGains()/getFeedbackGains() run the library's host DDP (mppi_compute_feedback_gains).
 //
 // All compute goes through the C ABI; there is no CPU fallback.  The only host arithmetic is what the
 // reference also does on the host: computeNominalTraj / model->updateState (mppi_nominal_traj).
@@ -313,8 +313,28 @@ class MPPIController {
     model_->control_rngs_[1].y = 0.0f;
     model_->touch();
   }
-  // DDP feedback gains (mppi_controller.cu:402-445) are outside the hot path.
-  void computeFeedbackGains(const float *) {}
+  // OptimizerResult of ddp/result.h, flattened
+  struct FeedbackResult {
+    std::vector<float> feedback_gain;      // [T][2][7]
+    std::vector<float> feedforward_gain;   // [T][2]
+    std::vector<float> state_trajectory;   // [T][7]
+    std::vector<float> control_trajectory; // [T][2]
+    float total_cost = 0.0f;
+  };
+  // computeFeedbackGains(state), mppi_controller.cu:431-441: tracks state_solution_/control_solution_
+  void computeFeedbackGains(const float *state)
+  {
+    syncParams(false);  // the host copy of the network / control ranges the Jacobians are taken of
+    ck(mppi_compute_feedback_gains(h_, state, state_solution_.data(), control_solution_.data()));
+    const size_t T = (size_t)numTimesteps_;
+    result_.feedback_gain.resize(T * CONTROL_DIM * STATE_DIM);
+    result_.feedforward_gain.resize(T * CONTROL_DIM);
+    result_.state_trajectory.resize(T * STATE_DIM);
+    result_.control_trajectory.resize(T * CONTROL_DIM);
+    ck(mppi_get_feedback_gains(h_, result_.feedback_gain.data(), result_.feedforward_gain.data(),
+                               result_.state_trajectory.data(), result_.control_trajectory.data(), &result_.total_cost));
+  }
+  const FeedbackResult &getFeedbackGains() const { return result_; }  // :443-446
 
   void slideControlAndStateSeq(int stride)
   {
@@ -379,6 +399,7 @@ class MPPIController {
   mppi_handle *h_ = nullptr;
   float trajectory_cost_ = 0.0f;
   std::vector<float> state_solution_, control_solution_;
+  FeedbackResult result_;
   unsigned model_seen_ = 0, cost_seen_ = 0, map_seen_ = 0;
   bool first_model_ = true;
 };

@@ -90,11 +90,16 @@ int main(int argc, char **argv)
     const LoopStats st = runControlLoop(&predicted, &actual, &robot, &params, &is_alive, sleep_to_rate, trace);
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (trace) fclose(trace);
+    // the gains handed to the plant with the last solution: first-step row sums as a fingerprint
+    double g0 = 0.0, g1 = 0.0;
+    if (robot.last_feedback_gains.size() >= 14)
+      for (int i = 0; i < 7; i++) { g0 += robot.last_feedback_gains[i]; g1 += robot.last_feedback_gains[7 + i]; }
     printf("{\"iterations\": %d, \"rollouts\": %d, \"timesteps\": %d, \"avg_tick_ms\": %.4f, \"avg_sleep_ms\": %.4f, "
-           "\"wall_s\": %.4f, \"actual_state_used\": %d, \"final_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f]}\n",
+           "\"wall_s\": %.4f, \"actual_state_used\": %d, \"final_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f], "
+           "\"feedback_gain_row_sums_t0\": [%.6f, %.6f]}\n",
            st.iterations, actual.NUM_ROLLOUTS, T, st.avg_tick_ms, st.avg_sleep_ms, wall, robot.n_actual,
            st.final_state[0], st.final_state[1], st.final_state[2], st.final_state[3], st.final_state[4],
-           st.final_state[5], st.final_state[6]);
+           st.final_state[5], st.final_state[6], g0, g1);
   } catch (const std::exception &e) {
     fprintf(stderr, "path_integral_nn: %s\n", e.what());
     return 1;

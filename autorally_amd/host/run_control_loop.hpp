@@ -2,7 +2,8 @@
 //
 // Same structure as the reference loop: two controllers (actual-state / predicted-state), slide by
 // the stride, computeControl(state) / computeControl(), arbitration by getComputedTrajectoryCost(),
-// hand the chosen solution to the plant, debug-mode self-simulation, profiler_max_iter stop.
+// feedback gains of the chosen controller (use_feedback_gains), hand the chosen solution to the plant,
+// debug-mode self-simulation, profiler_max_iter stop.
 // The plant is a template parameter with the subset of AutorallyPlant the loop uses; SimPlant is the
 // headless stand-in (no pose source => status 1 => fixed stride, exactly the reference's debug_mode).
 #pragma once
@@ -24,21 +25,50 @@ enum class ControllerType { NONE, ACTUAL_STATE, PREDICTED_STATE };
 struct SimPlant {
   struct FullState { float x_pos = 0, y_pos = 0, yaw = 0, roll = 0, u_x = 0, u_y = 0, yaw_mder = 0; };
   FullState fs;
-  std::vector<float> last_state_seq, last_control_seq;
+  std::vector<float> last_state_seq, last_control_seq, last_feedback_gains;  // gains [T][2][7]
   ControllerType last_used = ControllerType::NONE;
   int n_solutions = 0, n_actual = 0;
   double avgLoop = 0, avgTick = 0, avgSleep = 0;
   FullState getState() const { return fs; }
   void setTimingInfo(double a, double b, double c) { avgLoop = a; avgTick = b; avgSleep = c; }
-  void setSolution(const std::vector<float> &ss, const std::vector<float> &cs, ControllerType used)
+  void setSolution(const std::vector<float> &ss, const std::vector<float> &cs, const std::vector<float> &gains,
+                   ControllerType used)
   {
     last_state_seq = ss;
     last_control_seq = cs;
+    last_feedback_gains = gains;
     last_used = used;
     n_solutions++;
     if (used == ControllerType::ACTUAL_STATE) n_actual++;
   }
   int checkStatus() const { return 1; }  // no pose estimate: autorally_plant.cpp:443-459 returns 1
+  // pubControl's feedback law (autorally_plant.cpp:217-250) at a time `since` seconds after the
+  // solution, for a measured state: u = u_ff(t) + K(t) (x - x_des(t)), all linearly interpolated.
+  // false when outside the solution's horizon (the plant then publishes nothing).
+  bool controlAt(double since, double dt, const float x[7], bool use_feedback, float u_out[2]) const
+  {
+    const int T = (int)(last_control_seq.size() / 2);
+    if (T < 2 || !(since > 0) || !(since < (T - 1) * dt)) return false;
+    const int lo = (int)(since / dt), hi = lo + 1;
+    const double a = (since - lo * dt) / dt;
+    double u[2];
+    for (int j = 0; j < 2; j++) u[j] = (1 - a) * last_control_seq[2 * lo + j] + a * last_control_seq[2 * hi + j];
+    if (use_feedback && last_feedback_gains.size() == (size_t)T * 14) {
+      float du[2] = {0.0f, 0.0f};
+      for (int j = 0; j < 2; j++)
+        for (int i = 0; i < 7; i++) {
+          const float des = (float)((1 - a) * last_state_seq[7 * lo + i] + a * last_state_seq[7 * hi + i]);
+          const float k = (float)((1 - a) * last_feedback_gains[(lo * 2 + j) * 7 + i] + a * last_feedback_gains[(hi * 2 + j) * 7 + i]);
+          du[j] += k * (x[i] - des);
+        }
+      if (!std::isnan(du[0]) && !std::isnan(du[1])) {  // :243-246
+        u[0] += du[0];
+        u[1] += du[1];
+      }
+    }
+    for (int j = 0; j < 2; j++) u_out[j] = (float)std::fmax(-1.0, std::fmin(1.0, u[j]));  // :252-253
+    return true;
+  }
 };
 
 struct LoopStats {
@@ -62,6 +92,7 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
   const bool only_actual = (bool)(*params)["use_only_actual_state_controller"];
   const bool only_predicted = (bool)(*params)["use_only_predicted_state_controller"];
   const int max_iter = params->count("profiler_max_iter") ? (int)(*params)["profiler_max_iter"] : INT_MAX;
+  const bool use_feedback_gains = params->count("use_feedback_gains") ? (bool)(*params)["use_feedback_gains"] : false;  // :100
 
   float state[7] = {x_pos, y_pos, heading, 0, 0, 0, 0};
   if (!debug_mode) {
@@ -69,7 +100,7 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     const float s[7] = {fs.x_pos, fs.y_pos, fs.yaw, fs.roll, fs.u_x, fs.u_y, fs.yaw_mder};
     for (int i = 0; i < 7; i++) state[i] = s[i];
   }
-  std::vector<float> controlSolution, stateSolution;
+  std::vector<float> controlSolution, stateSolution, feedback_gain;
   int num_iter = 0, status = 1;
   double avgTick = 0, avgSleep = 0;
   const std::chrono::duration<double, std::milli> period(optimization_stride * 1000.0 / hz);
@@ -77,7 +108,9 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
   actual_state_controller->setState(state);
   predicted_state_controller->setState(state);
   actual_state_controller->resetControls();
+  actual_state_controller->computeFeedbackGains(state);  // :151-154 (gains around the initial sequence)
   predicted_state_controller->resetControls();
+  predicted_state_controller->computeFeedbackGains(state);
 
   while (is_alive->load() && num_iter < max_iter) {
     const auto loop_start = std::chrono::steady_clock::now();
@@ -90,6 +123,11 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     }
     actual_state_controller->computeControl(state);
     predicted_state_controller->computeControl();
+    if (use_feedback_gains) {  // :220-225: both controllers, from the measured state
+      actual_state_controller->computeFeedbackGains(state);
+      predicted_state_controller->computeFeedbackGains(state);
+    }
+    feedback_gain = predicted_state_controller->getFeedbackGains().feedback_gain;  // :229
 
     ControllerType to_use = ControllerType::NONE;
     if (only_actual && !only_predicted) to_use = ControllerType::ACTUAL_STATE;
@@ -100,6 +138,7 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
          actual_state_controller->getComputedTrajectoryCost() < predicted_state_controller->getComputedTrajectoryCost())) {
       controlSolution = actual_state_controller->getControlSeq();
       stateSolution = actual_state_controller->getStateSeq();
+      feedback_gain = actual_state_controller->getFeedbackGains().feedback_gain;  // :254
       if (to_use == ControllerType::NONE) {  // :255-258
         predicted_state_controller->setStateSequence(stateSolution);
         predicted_state_controller->setControlSequence(controlSolution);
@@ -108,9 +147,10 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     } else {
       controlSolution = predicted_state_controller->getControlSeq();
       stateSolution = predicted_state_controller->getStateSeq();
+      feedback_gain = predicted_state_controller->getFeedbackGains().feedback_gain;  // :267
       used = ControllerType::PREDICTED_STATE;
     }
-    robot->setSolution(stateSolution, controlSolution, used);
+    robot->setSolution(stateSolution, controlSolution, feedback_gain, used);
     status = robot->checkStatus();
     if (status != 0 && debug_mode) {
       // :296-302 -- both controllers share ONE model object, so the reference advances `state`

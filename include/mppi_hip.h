@@ -161,6 +161,24 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
 int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *state_seq,
                       float *control_seq);
 
+/* computeFeedbackGains (PI/mppi_controller.cu:431-441) -> DDP::run (ddp/ddp.h:49-157), one
+ * iteration, dt = 1/hz, from `state`, tracking target_state_seq [T][7] / target_control_seq [T][2]
+ * -- the reference passes state_solution_ / control_solution_ of the last computeControl, which for
+ * the predicted-state controller were NOT computed from `state` (run_control_loop.cuh:218-225).
+ * Both NULL: the nominal trajectory of the current control sequence from `state`.
+ * Host computation like the reference (T Jacobians of the network via computeGrad,
+ * neural_net_model.cu:233-264, and T-1 sequential 7x7 Riccati steps).  Weights default to initDDP's
+ * Q = diag(.5,.5,.25,0,.05,.01,.01), R = diag(10,10), Qf = 0 (mppi_controller.cu:410-417).
+ * Returns MPPI_ERR_STATE where the reference exits (-3) on a failed LDLT. */
+int mppi_set_ddp_weights(mppi_handle *h, const float Q[MPPI_STATE_DIM], const float R[MPPI_CONTROL_DIM],
+                         const float Qf[MPPI_STATE_DIM]);
+int mppi_compute_feedback_gains(mppi_handle *h, const float state[MPPI_STATE_DIM],
+                                const float *target_state_seq, const float *target_control_seq);
+/* getFeedbackGains (:443-446), OptimizerResult (ddp/result.h): feedback [T][2][7] (the last one is
+ * zero), feedforward [T][2], state_traj [T][7], control_traj [T][2], total_cost; any may be NULL. */
+int mppi_get_feedback_gains(mppi_handle *h, float *feedback, float *feedforward, float *state_traj,
+                            float *control_traj, float *total_cost);
+
 /* Measurement hooks.  on = 1: HIP events around every stage of every solve; on = N > 1: only on
  * every Nth solve (event packets between kernels lengthen the launch gaps, so sampling keeps the
  * measured run close to the unmeasured one); on = 0: off. */

@@ -121,6 +121,16 @@ void orc_compute_control(const orc_problem *p, int num_iters, const float *state
                          float *U, const float *hist, float *eps, float *traj_cost,
                          float *costs, float *w);
 
+/* ---- feedback gains (ddp_oracle.c, parity UNPINNED -- see its header) ----
+ * computeFeedbackGains -> DDP::run, mppi_controller.cu:402-441, ddp/ddp.h:49-157.
+ * feedback [T][2][7], feedforward [T][2], xout [T][7], uout [T][2]. Returns 0, or 1 where the
+ * reference exits on a failed LDLT. */
+int orc_ddp_feedback_gains(const float *theta, const int *layers, int n_layers, int T, float dt,
+                           const float *u_lo, const float *u_hi, int negate_yaw_der, const float *Q,
+                           const float *R, const float *Qf, const float *x0, const float *target_x,
+                           const float *target_u, float *feedback, float *feedforward, float *xout,
+                           float *uout, float *total_cost);
+
 /* ---- noise generator spec (this build's own; cuRAND's XORWOW stream is not reproducible) ---- */
 typedef struct { uint32_t s1[3]; uint32_t s2[3]; } orc_mrg_state;
 void orc_mrg_seed(orc_mrg_state *st, uint64_t seed);

@@ -66,10 +66,9 @@ class MrgState(C.Structure):
 
 def build(force=False):
     """Compile oracle/libmppi_oracle.so with gcc (idempotent)."""
-    src = os.path.join(_HERE, "mppi_oracle.c")
-    hdr = os.path.join(_HERE, "mppi_oracle.h")
+    deps = [os.path.join(_HERE, f) for f in ("mppi_oracle.c", "ddp_oracle.c", "mppi_oracle.h")]
     if not force and os.path.exists(_LIB_PATH):
-        if os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        if os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "libmppi_oracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -116,6 +115,9 @@ def lib():
         L.orc_mrg_jump_matrices.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_box_muller.argtypes = [C.c_float, C.c_float, fp, fp]
         L.orc_generate_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, fp]
+        L.orc_ddp_feedback_gains.restype = C.c_int
+        L.orc_ddp_feedback_gains.argtypes = [fp, ip, C.c_int, C.c_int, C.c_float, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp,
+                                             fp, fp, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -242,6 +244,29 @@ class Oracle:
         cs = np.zeros((T, 2), dtype=np.float32)
         self.L.orc_nominal_traj(C.byref(self.p), _fp(state), _fp(U), _fp(ss), _fp(cs))
         return ss, cs
+
+    DDP_Q = (0.5, 0.5, 0.25, 0.0, 0.05, 0.01, 0.01)  # initDDP, mppi_controller.cu:410-417
+    DDP_R = (10.0, 10.0)
+    DDP_QF = (0.0,) * 7
+
+    def ddp_feedback_gains(self, state, target_x, target_u, Q=DDP_Q, R=DDP_R, Qf=DDP_QF):
+        """computeFeedbackGains (mppi_controller.cu:431-441): dict(feedback[T,2,7], feedforward[T,2], x, u, total_cost)."""
+        T = self.p.T
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        state, tx, tu = f32(state), f32(target_x).reshape(T, 7), f32(target_u).reshape(T, 2)
+        Q, R, Qf = f32(Q), f32(R), f32(Qf)
+        lo, hi = f32([self.p.u_lo[0], self.p.u_lo[1]]), f32([self.p.u_hi[0], self.p.u_hi[1]])
+        fb = np.zeros((T, 2, 7), np.float32)
+        ff = np.zeros((T, 2), np.float32)
+        x = np.zeros((T, 7), np.float32)
+        u = np.zeros((T, 2), np.float32)
+        tc = np.zeros(1, np.float32)
+        rc = self.L.orc_ddp_feedback_gains(_fp(self.theta), self.p.layers, self.p.n_layers, T, self.p.dt, _fp(lo), _fp(hi),
+                                           self.p.negate_yaw_der, _fp(Q), _fp(R), _fp(Qf), _fp(state), _fp(tx), _fp(tu),
+                                           _fp(fb), _fp(ff), _fp(x), _fp(u), _fp(tc))
+        if rc:
+            raise RuntimeError("DDP: control Hessian could not be factorised")
+        return dict(feedback=fb, feedforward=ff, x=x, u=u, total_cost=float(tc[0]))
 
     def slide_control_seq(self, U, hist, init_u, stride):
         U = np.array(U, dtype=np.float32).reshape(-1, 2).copy()

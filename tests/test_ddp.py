@@ -1,0 +1,168 @@
+"""Feedback gains around the MPPI solution: computeFeedbackGains -> DDP::run
+(mppi_controller.cu:402-441, ddp/ddp.h:49-157).
+
+The reference has no fixture for this path and cannot be built here (Eigen absent): the C
+restatement (oracle/ddp_oracle.c) is "parity unpinned".  It is checked here against an independent
+float64 LQR recursion built from finite-difference Jacobians of a numpy network, and the product
+(host code behind mppi_compute_feedback_gains) is checked against the restatement."""
+import numpy as np
+import pytest
+
+from autorally_amd import params as P
+from autorally_amd import synthetic as S
+from oracle import oracle as O
+from tests.helpers import warm_U
+
+
+def _np_f(cfg, x, u):
+    """float64 restatement of ModelWrapperDDP::f (kinematics + network) for finite differences."""
+    layers, theta = cfg["layers"], np.asarray(cfg["theta"], np.float64)
+    a = np.array([x[3], x[4], x[5], x[6], u[0], u[1]], np.float64)
+    off = 0
+    for l in range(len(layers) - 1):
+        nin, nout = layers[l], layers[l + 1]
+        W = theta[off:off + nin * nout].reshape(nout, nin)
+        b = theta[off + nin * nout:off + nin * nout + nout]
+        off += nin * nout + nout
+        a = W @ a + b
+        if l < len(layers) - 2:
+            a = np.tanh(a)
+    yaw = x[2]
+    dx = np.zeros(7)
+    dx[0] = np.cos(yaw) * x[4] - np.sin(yaw) * x[5]
+    dx[1] = np.sin(yaw) * x[4] + np.cos(yaw) * x[5]
+    dx[2] = -x[6] if cfg["negate_yaw_der"] else x[6]
+    dx[3:] = a
+    return dx
+
+
+def _fd_jac(cfg, x, u, h=1e-6):
+    z = np.concatenate([x, u]).astype(np.float64)
+    J = np.zeros((7, 9))
+    for i in range(9):
+        zp, zm = z.copy(), z.copy()
+        zp[i] += h
+        zm[i] -= h
+        J[:, i] = (_np_f(cfg, zp[:7], zp[7:]) - _np_f(cfg, zm[:7], zm[7:])) / (2 * h)
+    return J
+
+
+def _lqr64(cfg, xs, us, Q, R, Qf):
+    """Time-varying discrete LQR (the backward pass of ddp.h:90-123 in exact arithmetic, float64)."""
+    T = xs.shape[0]
+    dt = 1.0 / cfg["hz"]
+    Vxx = np.diag(np.asarray(Qf, np.float64))
+    K = np.zeros((T, 2, 7))
+    for k in range(T - 2, -1, -1):
+        J = _fd_jac(cfg, xs[k], us[k]) * dt
+        A = J[:, :7] + np.eye(7)
+        B = J[:, 7:]
+        qux = B.T @ Vxx @ A
+        qxx = np.diag(Q) * dt + A.T @ Vxx @ A
+        quu = np.diag(R) * dt + B.T @ Vxx @ B
+        K[k] = np.linalg.solve(quu, -qux)
+        V = qxx + qux.T @ K[k]
+        Vxx = 0.5 * (V + V.T)
+    return K
+
+
+def _case(T=40, layers=None, negate=True, track="oval"):
+    kw = {}
+    if layers:
+        l, th = P.synthetic_model(layers, seed=3)
+        kw = dict(layers=l, theta=th)
+    cfg = S.make_config(64, T, track=track, **kw)
+    cfg = dict(cfg, negate_yaw_der=negate)
+    return cfg
+
+
+def test_oracle_gains_match_float64_lqr():
+    cfg = _case()
+    orc = O.Oracle(cfg)
+    U = warm_U(cfg)
+    xs, us = orc.nominal_traj(cfg["start_state"], U)
+    r = orc.ddp_feedback_gains(cfg["start_state"], xs, us)
+    # tracking its own nominal trajectory: nothing to correct (the replay inside DDP::run differs from
+    # computeNominalTraj's by rounding only: no FMA contraction in the host dynamics)
+    np.testing.assert_allclose(r["x"], xs, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(r["u"][:-1], us[:-1], rtol=0, atol=1e-6)
+    assert np.all(r["u"][-1] == 0.0) and np.all(r["feedback"][-1] == 0.0)  # never written (ddp.h:127,139)
+    assert np.max(np.abs(r["feedforward"])) < 1e-5 and abs(r["total_cost"]) < 1e-9
+    K64 = _lqr64(cfg, xs.astype(np.float64), us.astype(np.float64), O.Oracle.DDP_Q, O.Oracle.DDP_R, O.Oracle.DDP_QF)
+    scale = np.abs(K64).max()
+    assert scale > 1e-3
+    assert np.max(np.abs(r["feedback"] - K64)) <= 2e-3 * scale
+
+
+def test_oracle_feedforward_pulls_towards_the_target():
+    """Start 0.3 m beside the tracked trajectory: the forward pass with the gains ends closer to the
+    target than the open-loop replay, and its cost is what DDP::run reports."""
+    cfg = _case(T=50)
+    orc = O.Oracle(cfg)
+    U = warm_U(cfg)
+    xs, us = orc.nominal_traj(cfg["start_state"], U)
+    x0 = np.array(cfg["start_state"], np.float32)
+    x0[1] += 0.3
+    x0[4] -= 0.5
+    r = orc.ddp_feedback_gains(x0, xs, us)
+    open_loop, _ = orc.nominal_traj(x0, us)
+    Q = np.array(O.Oracle.DDP_Q)
+    err_cl = float(((r["x"] - xs) ** 2 * Q).sum())
+    err_ol = float(((open_loop - xs) ** 2 * Q).sum())
+    assert err_cl < err_ol
+    dt = 1.0 / cfg["hz"]
+    c = (((r["x"] - xs) ** 2 * Q).sum(1) + ((r["u"] - us) ** 2 * np.array(O.Oracle.DDP_R)).sum(1)) * dt
+    assert abs(float(c[:-1].sum()) - r["total_cost"]) <= 1e-4 * max(1.0, r["total_cost"])
+    lo, hi = np.array(cfg["u_lo"]), np.array(cfg["u_hi"])
+    assert np.all(r["u"][:-1] >= lo - 1e-7) and np.all(r["u"][:-1] <= hi + 1e-7)
+
+
+def test_oracle_jacobian_quirk_and_fd():
+    """computeGrad hard-codes d(yaw rate)/d(s6) = -1 (neural_net_model.cu:241): with negate_yaw_der
+    false the gains differ from the float64 LQR of the true dynamics, with it true they agree."""
+    cfg = _case(T=12, negate=False)
+    orc = O.Oracle(cfg)
+    xs, us = orc.nominal_traj(cfg["start_state"], warm_U(cfg))
+    r = orc.ddp_feedback_gains(cfg["start_state"], xs, us)
+    K64 = _lqr64(cfg, xs.astype(np.float64), us.astype(np.float64), O.Oracle.DDP_Q, O.Oracle.DDP_R, O.Oracle.DDP_QF)
+    assert np.max(np.abs(r["feedback"] - K64)) > 1e-2 * np.abs(K64).max()
+
+
+# ------------------------------------------------------------------ product (needs a device handle)
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,layers,negate", [(100, None, True), (30, [6, 64, 64, 4], True), (25, [6, 16, 8, 4], False)])
+def test_product_matches_oracle(T, layers, negate):
+    from autorally_amd import capi
+    cfg = _case(T=T, layers=layers, negate=negate)
+    orc = O.Oracle(cfg)
+    sol = capi.Solver(cfg)
+    U = warm_U(cfg)
+    sol.set_control_seq(U)
+    x0 = np.array(cfg["start_state"], np.float32)
+    got = sol.compute_feedback_gains(x0)
+    xs, us = orc.nominal_traj(x0, U)
+    ref = orc.ddp_feedback_gains(x0, xs, us)
+    scale = np.abs(ref["feedback"]).max()
+    assert np.max(np.abs(got["feedback"] - ref["feedback"])) <= 1e-4 * scale
+    np.testing.assert_allclose(got["x"], ref["x"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got["u"], ref["u"], rtol=0, atol=1e-6)
+    assert abs(got["total_cost"] - ref["total_cost"]) <= 1e-6
+    # after a solve, from a state off the nominal start
+    sol.compute_control(x0)
+    x1 = x0.copy()
+    x1[0] += 0.2
+    x1[5] += 0.1
+    got = sol.compute_feedback_gains(x1)
+    xs, us = orc.nominal_traj(x1, sol.get_control_seq())
+    ref = orc.ddp_feedback_gains(x1, xs, us)
+    assert np.max(np.abs(got["feedback"] - ref["feedback"])) <= 1e-4 * np.abs(ref["feedback"]).max()
+    # custom weights
+    Q, R, Qf = np.full(7, 0.2, np.float32), np.array([3.0, 4.0], np.float32), np.full(7, 1.5, np.float32)
+    sol.set_ddp_weights(Q, R, Qf)
+    got = sol.compute_feedback_gains(x1)
+    ref = orc.ddp_feedback_gains(x1, xs, us, Q, R, Qf)
+    assert np.max(np.abs(got["feedback"] - ref["feedback"])) <= 1e-4 * np.abs(ref["feedback"]).max()
+    assert np.max(np.abs(got["feedforward"] - ref["feedforward"])) <= 1e-4 * max(1e-3, np.abs(ref["feedforward"]).max())
+    with pytest.raises(capi.MppiError):
+        sol.set_ddp_weights(Q, np.array([0.0, 1.0], np.float32), Qf)
+    sol.close()

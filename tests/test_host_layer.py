@@ -87,14 +87,20 @@ def test_path_integral_nn_binary_matches_python_loop(bins, golden_dir, tmp_path)
         predicted.compute_control(ps)
         p_ss, p_cs = predicted.nominal_traj(ps)
         ca, cp = actual.get_results(False)["traj_cost"], predicted.get_results(False)["traj_cost"]
+        # use_feedback_gains (launch default): both controllers, from the measured state, each tracking
+        # its own solution (run_control_loop.cuh:220-225)
+        ga = actual.compute_feedback_gains(state, a_ss, a_cs)["feedback"]
+        gp = predicted.compute_feedback_gains(state, p_ss, p_cs)["feedback"]
         if ca < cp:
-            cs, pred_state_seq = a_cs, a_ss.copy()
+            cs, pred_state_seq, gains = a_cs, a_ss.copy(), ga
             n_actual += 1
         else:
-            cs, pred_state_seq = p_cs, p_ss.copy()
+            cs, pred_state_seq, gains = p_cs, p_ss.copy(), gp
         u = cs[0].copy()
         state, _ = orc.update_state(state, u)   # the reference advances the state twice per tick
         state, _ = orc.update_state(state, u)   # (shared model object, run_control_loop.cuh:299-300)
     np.testing.assert_allclose(out["final_state"], state, atol=2e-4, rtol=1e-4)
     assert out["actual_state_used"] == n_actual
+    np.testing.assert_allclose(out["feedback_gain_row_sums_t0"], gains[0].sum(axis=1), rtol=2e-3, atol=2e-4)
+    assert np.abs(gains[0]).max() > 1e-3
     assert abs(state[4]) > 0.5  # the car actually drove
