@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmppi_hip.so")
 SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_valu.hip", "solve_kernels.hip",
-           "noise_mrg32k3a.hip", "ddp_feedback.cpp"]
-HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
+           "noise_mrg32k3a.hip", "rollout_bf.hip", "ddp_feedback.cpp"]
+HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", "basis_funcs.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file), which removes
 # the v_accvgpr_read per accumulator register after every layer
@@ -76,9 +76,10 @@ def build_host(force=False):
     os.makedirs(BIN, exist_ok=True)
     cxx = shutil.which("g++") or "g++"
     hdrs = [os.path.join(HOST, h) for h in ("npz.hpp", "param_getter.hpp", "mppi_controller_hip.hpp",
-                                            "run_control_loop.hpp")] + [os.path.join(HERE, "..", "include", "mppi_hip.h")]
+                                            "run_control_loop.hpp", "path_integral_main.hpp")] + [os.path.join(CSRC, "basis_funcs.hpp")] + [os.path.join(HERE, "..", "include", "mppi_hip.h")]
     outs = []
-    for name, libs in (("host_selftest", []), ("path_integral_nn", ["-L" + HERE, "-lmppi_hip", "-Wl,-rpath,$ORIGIN/.."])):
+    link = ["-L" + HERE, "-lmppi_hip", "-Wl,-rpath,$ORIGIN/.."]
+    for name, libs in (("host_selftest", []), ("path_integral_nn", link), ("path_integral_bf", link)):
         src = os.path.join(HOST, name + ".cpp")
         out = os.path.join(BIN, name)
         outs.append(out)

@@ -58,7 +58,7 @@ SYMBOLS = [
     "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
     "mppi_compute_control", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
     "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
-    "mppi_set_ddp_weights", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
+    "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
 ]
@@ -112,6 +112,7 @@ def lib():
         L.mppi_get_applied_controls.argtypes = [hp, fp, C.c_size_t]
         L.mppi_rollout_only.argtypes = [hp, fp, fp]
         L.mppi_nominal_traj.argtypes = [hp, fp, fp, fp]
+        L.mppi_set_bf_params.argtypes = [hp, fp, C.c_size_t]
         L.mppi_set_ddp_weights.argtypes = [hp, fp, fp, fp]
         L.mppi_compute_feedback_gains.argtypes = [hp, fp, fp, fp]
         L.mppi_get_feedback_gains.argtypes = [hp, fp, fp, fp, fp, fp]
@@ -150,7 +151,8 @@ def make_config_struct(cfg, device=0):
     c.optimization_stride = int(cfg["opt_stride"])
     c.gamma = float(cfg["gamma"])
     c.num_iters = int(cfg.get("num_iters", 1))
-    layers = [int(x) for x in cfg["layers"]]
+    # cfg["bf_W"] selects the GeneralizedLinear basis-function dynamics (n_layers = 0)
+    layers = [] if cfg.get("bf_W") is not None else [int(x) for x in cfg["layers"]]
     c.n_layers = len(layers)
     for i, v in enumerate(layers):
         c.layers[i] = v
@@ -186,8 +188,12 @@ class Solver:
         if rc != OK:
             self.h = C.c_void_p()
             raise MppiError(rc, self.L.mppi_strerror(rc).decode())
-        theta = _f32(cfg["theta"])
-        self._ck(self.L.mppi_set_nn_params(self.h, _fp(theta), theta.size))
+        if cfg.get("bf_W") is not None:
+            W = _f32(cfg["bf_W"], (4, 25))
+            self._ck(self.L.mppi_set_bf_params(self.h, _fp(W), W.size))
+        else:
+            theta = _f32(cfg["theta"])
+            self._ck(self.L.mppi_set_nn_params(self.h, _fp(theta), theta.size))
         m = _f32(cfg["map_rgba"])
         H, W = m.shape[0], m.shape[1]
         self._ck(self.L.mppi_set_costmap(self.h, W, H, _fp(m), _fp(_f32(cfg["r_c1"])),

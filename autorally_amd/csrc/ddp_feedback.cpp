@@ -2,9 +2,13 @@
 // fp32 on the host); matrix products are written as k-ascending sums, association as in the source
 // expressions of ddp.h (e.g. (B^T Vxx) Phi).
 #include "ddp_feedback.hpp"
+#include "basis_funcs.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
+#include <memory>
 
 namespace mppi {
 namespace {
@@ -36,12 +40,22 @@ Mat<C, R> transpose(const Mat<R, C> &a)
   return o;
 }
 
+// ModelWrapperDDP (ddp/ddp_model_wrapper.h:37-80): f and its Jacobian wrt [x | u]
+struct HostModel {
+  virtual ~HostModel() {}
+  virtual void f(const DdpProblem &p, const float *x, const float *u, float *dx) = 0;
+  virtual void jacobian(const DdpProblem &p, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J) = 0;
+};
+
 // Host network: forward pass keeping the pre-activations (computeDynamics, neural_net_model.cu:201-230)
-struct HostNet {
+struct HostNet : HostModel {
   const DdpNet &n;
   std::vector<std::vector<float>> z;  // weighted_in_[l]
+  std::vector<std::vector<float>> th;  // tanh(weighted_in_[l]) of the hidden layers, kept for computeGrad
   std::vector<size_t> woff, boff;
-  explicit HostNet(const DdpNet &net) : n(net)
+  std::vector<float> a_, b_, d_, dn_;  // scratch (no allocation per call: this runs T times per solve)
+  explicit HostNet(const DdpNet &net)
+      : n(net), a_(net.max_width), b_(net.max_width), d_((size_t)net.max_width * 4), dn_((size_t)net.max_width * 4)
   {
     size_t off = 0;
     for (int l = 0; l + 1 < n.n_layers; l++) {
@@ -49,12 +63,13 @@ struct HostNet {
       boff.push_back(off + (size_t)n.layers[l] * n.layers[l + 1]);
       off += (size_t)n.layers[l] * n.layers[l + 1] + n.layers[l + 1];
       z.emplace_back(n.layers[l + 1]);
+      th.emplace_back(n.layers[l + 1]);
     }
   }
   // out[4] = network(s3..s6, u0, u1)
   void forward(const float *x, const float *u, float *out)
   {
-    std::vector<float> a(n.max_width), b(n.max_width);
+    std::vector<float> &a = a_, &b = b_;
     for (int i = 0; i < 4; i++) a[i] = x[3 + i];
     a[4] = u[0];
     a[5] = u[1];
@@ -67,14 +82,14 @@ struct HostNet {
         for (int k = 0; k < nin; k++) s += W[j * nin + k] * a[k];
         s += bias[j];
         z[l][j] = s;
-        b[j] = (l < L - 1) ? std::tanh(s) : s;
+        b[j] = (l < L - 1) ? (th[l][j] = std::tanh(s)) : s;
       }
       a.swap(b);
     }
     for (int i = 0; i < 4; i++) out[i] = a[i];
   }
   // f(x, u): computeKinematics + computeDynamics (ddp_model_wrapper.h:57-68)
-  void f(const DdpProblem &p, const float *x, const float *u, float *dx)
+  void f(const DdpProblem &p, const float *x, const float *u, float *dx) override
   {
     dx[0] = std::cos(x[2]) * x[4] - std::sin(x[2]) * x[5];
     dx[1] = std::sin(x[2]) * x[4] + std::cos(x[2]) * x[5];
@@ -82,7 +97,7 @@ struct HostNet {
     forward(x, u, dx + 3);
   }
   // computeGrad (neural_net_model.cu:233-264): 7 x 9 Jacobian of f wrt [x | u]
-  void jacobian(const float *x, const float *u, Mat<kDdpS, kDdpSC> &J)
+  void jacobian(const DdpProblem &, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J) override
   {
     J.zero();
     const float sn = std::sin(x[2]), cs = std::cos(x[2]);
@@ -93,14 +108,14 @@ struct HostNet {
     forward(x, u, out);
     const int L = n.n_layers - 1;  // weight matrices
     // delta: [width of layer l+1... ][4], starts as the 4x4 identity at the output
-    std::vector<float> d(4 * 4, 0.0f), dn;
+    std::vector<float> &d = d_, &dn = dn_;
+    std::fill(d.begin(), d.begin() + 16, 0.0f);
     for (int i = 0; i < 4; i++) d[i * 4 + i] = 1.0f;
     int rows = 4;  // == layers[L]
     for (int l = L - 1; l > 0; l--) {
       // delta <- (W_l^T delta) .* tanh'(z_{l-1})
       const int nin = n.layers[l], nout = n.layers[l + 1];
       const float *W = n.theta + woff[l];
-      dn.assign((size_t)nin * 4, 0.0f);
       for (int i = 0; i < nin; i++)
         for (int c = 0; c < 4; c++) {
           float s = 0.0f;
@@ -108,8 +123,10 @@ struct HostNet {
           dn[i * 4 + c] = s;
         }
       for (int i = 0; i < nin; i++) {
-        const float th = std::tanh(z[l - 1][i]);
-        const float zp = 1.0f - std::pow(th, 2.0f);
+        // MPPI_NNET_NONLINEARITY_DERIV: 1 - powf(tanh(z), 2); tanh(z) is the value the forward pass above
+        // just computed from the same z, and powf(x, 2) is the correctly rounded x*x
+        const float tz = th[l - 1][i];
+        const float zp = 1.0f - tz * tz;
         for (int c = 0; c < 4; c++) dn[i * 4 + c] = dn[i * 4 + c] * zp;
       }
       d.swap(dn);
@@ -119,7 +136,6 @@ struct HostNet {
     {
       const int nin = n.layers[0], nout = n.layers[1];
       const float *W = n.theta + woff[0];
-      dn.assign((size_t)nin * 4, 0.0f);
       for (int i = 0; i < nin; i++)
         for (int c = 0; c < 4; c++) {
           float s = 0.0f;
@@ -130,6 +146,42 @@ struct HostNet {
     // bottom-right 4 x 6 block += delta^T: rows = outputs, columns = [s3..s6, u0, u1]
     for (int o = 0; o < 4; o++)
       for (int i = 0; i < 6; i++) J.v[3 + o][3 + i] += dn[i * 4 + o];
+  }
+};
+
+// GeneralizedLinear on the host (generalized_linear.cu:140-175).  It has no computeGrad, so
+// ModelWrapperDDP::df falls back to Dynamics::df = Eigen::NumericalDiff<..., Central>
+// (ddp/ddp_dynamics.h:71-84): step h_j = sqrt(eps_fp32) |z_j| (sqrt(eps) when z_j == 0) in fp32.
+struct HostBasis : HostModel {
+  const float *W;
+  explicit HostBasis(const float *w) : W(w) {}
+  void f(const DdpProblem &, const float *x, const float *u, float *dx) override
+  {
+    dx[0] = std::cos(x[2]) * x[4] - std::sin(x[2]) * x[5];
+    dx[1] = std::sin(x[2]) * x[4] + std::cos(x[2]) * x[5];
+    dx[2] = -x[6];
+    float phi[kNumBfs];
+    basis_funcs(x, u[0], u[1], phi);
+    basis_dynamics(W, phi, dx + 3);
+  }
+  void jacobian(const DdpProblem &p, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J) override
+  {
+    const float eps = std::sqrt(std::numeric_limits<float>::epsilon());
+    float z[kDdpSC];
+    for (int i = 0; i < kDdpS; i++) z[i] = x[i];
+    for (int j = 0; j < kDdpC; j++) z[kDdpS + j] = u[j];
+    for (int j = 0; j < kDdpSC; j++) {
+      const float zj = z[j];
+      float h = eps * std::fabs(zj);
+      if (h == 0.0f) h = eps;
+      float v1[kDdpS], v2[kDdpS];
+      z[j] += h;
+      f(p, z, z + kDdpS, v2);
+      z[j] -= 2 * h;
+      f(p, z, z + kDdpS, v1);
+      z[j] = zj;
+      for (int i = 0; i < kDdpS; i++) J.v[i][j] = (v2[i] - v1[i]) / (2 * h);
+    }
   }
 };
 
@@ -175,7 +227,10 @@ int ddp_feedback_gains(const DdpNet &net, const DdpProblem &p, const float *x0, 
 {
   const int H = p.T;
   const float dt = p.dt;
-  HostNet nn(net);
+  std::unique_ptr<HostModel> model;
+  if (net.n_layers == 0) model.reset(new HostBasis(net.theta));
+  else model.reset(new HostNet(net));
+  HostModel &nn = *model;
   std::vector<float> x((size_t)H * kDdpS), u(target_u, target_u + (size_t)H * kDdpC);
   // initial rollout, ddp.h:55-65
   for (int i = 0; i < kDdpS; i++) x[i] = x0[i];
@@ -191,7 +246,7 @@ int ddp_feedback_gains(const DdpNet &net, const DdpProblem &p, const float *x0, 
   std::vector<Mat<kDdpS, kDdpSC>> df(H);
   std::vector<float> dL((size_t)H * kDdpSC);
   for (int k = 0; k < H; k++) {
-    nn.jacobian(&x[(size_t)k * kDdpS], &u[(size_t)k * kDdpC], df[k]);
+    nn.jacobian(p, &x[(size_t)k * kDdpS], &u[(size_t)k * kDdpC], df[k]);
     for (int i = 0; i < kDdpS; i++)
       for (int j = 0; j < kDdpSC; j++) df[k].v[i][j] = df[k].v[i][j] * dt;
     for (int i = 0; i < kDdpS; i++) df[k].v[i][i] += 1.0f;

@@ -14,7 +14,7 @@ namespace mppi {
 constexpr int kDdpS = 7, kDdpC = 2, kDdpSC = kDdpS + kDdpC;
 
 struct DdpNet {
-  int n_layers;         // layer sizes incl. input and output
+  int n_layers;         // layer sizes incl. input and output; 0: basis-function model, theta = W[4][25]
   const int *layers;
   const float *theta;   // packed [W1|b1|W2|b2|...], W row-major [out][in] (neural_net_model.cu:120-141)
   int max_width;

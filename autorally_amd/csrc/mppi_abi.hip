@@ -21,6 +21,7 @@
 
 #include "mppi_kernels.hpp"
 #include "ddp_feedback.hpp"
+#include "basis_funcs.hpp"
 
 using namespace mppi;
 
@@ -80,6 +81,7 @@ struct mppi_handle {
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
   unsigned seq = 0;             // sequence number of the last enqueued solve (published in h_res[3])
+  bool basis = false;  // GeneralizedLinear basis-function dynamics (cfg.n_layers == 0); theta holds W[4][25]
   // DDP feedback gains (row f2): weights of initDDP (mppi_controller.cu:410-417) and the last result
   float ddp_Q[7] = {0.5f, 0.5f, 0.25f, 0.0f, 0.05f, 0.01f, 0.01f};
   float ddp_R[2] = {10.0f, 10.0f};
@@ -211,12 +213,12 @@ std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int
 
 bool use_mfma(const mppi_handle *h)
 {
-  if (h->variant_pref == 2 || h->variant_pref == 3) return false;
+  if (h->basis || h->variant_pref == 2 || h->variant_pref == 3) return false;
   return h->mfma_ok;
 }
 
 // "valu" on a standard shape runs the register/scalar-operand kernel; "valu_lds" forces the generic one
-bool use_valu_reg(const mppi_handle *h) { return !use_mfma(h) && h->valu_reg_ok && h->variant_pref != 3; }
+bool use_valu_reg(const mppi_handle *h) { return !h->basis && !use_mfma(h) && h->valu_reg_ok && h->variant_pref != 3; }
 
 // Kernel form for the MFMA path.  The quad form spends four wavefronts per 16 rollouts (the network
 // itself on two SIMDs, a cost wave, a control/noise wave); it wins while the recurrence is latency
@@ -294,7 +296,8 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
 
 int launch_rollout(mppi_handle *h, const RolloutArgs &a)
 {
-  hipError_t e = use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
+  hipError_t e = h->basis ? launch_rollout_bf(a, h->stream)
+                 : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
                                    : launch_rollout_valu(h->net, a, h->stream);
   if (e != hipSuccess) return fail(h, MPPI_ERR_HIP, "rollout launch", e);
@@ -551,10 +554,13 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   if (cfg->num_rollouts <= 0 || cfg->num_rollouts % 64 != 0) return MPPI_ERR_INVALID;
   if (cfg->num_timesteps < 2 || cfg->hz <= 0 || cfg->num_iters < 1) return MPPI_ERR_INVALID;
   if (cfg->optimization_stride < 0) return MPPI_ERR_INVALID;
-  if (cfg->n_layers < 2 || cfg->n_layers > MPPI_MAX_LAYERS) return MPPI_ERR_INVALID;
-  if (cfg->layers[0] != kNetIn || cfg->layers[cfg->n_layers - 1] != kNetOut) return MPPI_ERR_INVALID;
-  for (int i = 0; i < cfg->n_layers; i++)
-    if (cfg->layers[i] <= 0 || cfg->layers[i] > 256) return MPPI_ERR_INVALID;
+  const bool basis = (cfg->n_layers == 0);  // GeneralizedLinear basis-function dynamics
+  if (!basis) {
+    if (cfg->n_layers < 2 || cfg->n_layers > MPPI_MAX_LAYERS) return MPPI_ERR_INVALID;
+    if (cfg->layers[0] != kNetIn || cfg->layers[cfg->n_layers - 1] != kNetOut) return MPPI_ERR_INVALID;
+    for (int i = 0; i < cfg->n_layers; i++)
+      if (cfg->layers[i] <= 0 || cfg->layers[i] > 256) return MPPI_ERR_INVALID;
+  }
   if ((size_t)cfg->num_rollouts * (size_t)cfg->num_timesteps > (size_t)1 << 28) return MPPI_ERR_INVALID;
 
   int ndev = 0;
@@ -579,8 +585,10 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   for (int i = 0; i < 8; i++) h->net.layers[i] = (i < cfg->n_layers) ? cfg->layers[i] : 0;
   for (int i = 0; i < cfg->n_layers; i++) h->net.max_width = std::max(h->net.max_width, cfg->layers[i]);
   for (int i = 0; i + 1 < cfg->n_layers; i++) h->net.num_params += (cfg->layers[i] + 1) * cfg->layers[i + 1];
+  h->basis = basis;
+  if (basis) h->net.num_params = 4 * kNumBfs;  // W[4][25], generalized_linear.cu:80
   // MFMA variant: 6 -> H x NHID -> 4
-  h->n_hidden = cfg->n_layers - 2;
+  h->n_hidden = basis ? 0 : cfg->n_layers - 2;
   h->hidden = (h->n_hidden > 0) ? cfg->layers[1] : 0;
   bool uniform = h->n_hidden > 0;
   for (int i = 1; i <= h->n_hidden; i++) uniform = uniform && (cfg->layers[i] == h->hidden);
@@ -678,9 +686,23 @@ int mppi_destroy(mppi_handle *h)
   return MPPI_OK;
 }
 
+int mppi_set_bf_params(mppi_handle *h, const float *W, size_t n)
+{
+  if (!h || !W) return MPPI_ERR_INVALID;
+  if (!h->basis) return fail(h, MPPI_ERR_STATE, "handle was created with a network (n_layers != 0)");
+  if (n != (size_t)(4 * kNumBfs)) return fail(h, MPPI_ERR_INVALID, "W size != 4 * 25");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->theta.assign(W, W + n);
+  HIPCHK(h, hipMemcpy(h->d_theta, W, n * sizeof(float), hipMemcpyHostToDevice));
+  h->have_nn = true;
+  return MPPI_OK;
+}
+
 int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
 {
   if (!h || !theta) return MPPI_ERR_INVALID;
+  if (h->basis) return fail(h, MPPI_ERR_STATE, "handle was created for basis-function dynamics: use mppi_set_bf_params");
   if (n != (size_t)h->net.num_params) return fail(h, MPPI_ERR_INVALID, "theta size != NUM_PARAMS");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -708,6 +730,7 @@ int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
 int mppi_update_model(mppi_handle *h, const int *description, int n_desc, const float *data, size_t n)
 {
   if (!h || !description || !data) return MPPI_ERR_INVALID;
+  if (h->basis) return fail(h, MPPI_ERR_STATE, "updateModel exists for the network model only");
   // neural_net_model.cu:155-161: a mismatching description leaves the model untouched
   for (int i = 0; i < n_desc; i++)
     if (i >= h->net.n_layers || description[i] != h->net.layers[i])
@@ -1030,7 +1053,7 @@ int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   // like the reference this replay runs on the host (T sequential 1.4k-MAC steps).
   float s[kStateDim];
   for (int i = 0; i < kStateDim; i++) s[i] = state[i];
-  std::vector<float> a(h->net.max_width), b(h->net.max_width);
+  std::vector<float> a(std::max(h->net.max_width, 8)), b(std::max(h->net.max_width, 8));
   for (int t = 0; t < h->T; t++) {
     for (int i = 0; i < kStateDim; i++) state_seq[t * kStateDim + i] = s[i];
     float u[2] = {h->U[2 * t], h->U[2 * t + 1]};
@@ -1043,6 +1066,16 @@ int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
     sd[0] = fmaf(c, s[4], -(sn * s[5]));
     sd[1] = fmaf(sn, s[4], c * s[5]);
     sd[2] = h->cfg.negate_yaw_der ? -s[6] : s[6];
+    if (h->basis) {  // GeneralizedLinear::updateState (generalized_linear.cu:140-167), yaw rate always negated
+      float phi[kNumBfs];
+      sd[2] = -s[6];
+      basis_funcs(s, u[0], u[1], phi);
+      basis_dynamics(h->theta.data(), phi, sd + 3);
+      for (int i = 0; i < kStateDim; i++) s[i] = fmaf(sd[i], h->dt, s[i]);
+      control_seq[2 * t] = u[0];
+      control_seq[2 * t + 1] = u[1];
+      continue;
+    }
     a[0] = s[3]; a[1] = s[4]; a[2] = s[5]; a[3] = s[6]; a[4] = u[0]; a[5] = u[1];
     size_t off = 0;
     for (int l = 0; l + 1 < h->net.n_layers; l++) {
@@ -1098,7 +1131,7 @@ int mppi_compute_feedback_gains(mppi_handle *h, const float state[MPPI_STATE_DIM
     if (rc) return rc;
   }
   DdpNet net;
-  net.n_layers = h->net.n_layers;
+  net.n_layers = h->basis ? 0 : h->net.n_layers;  // 0: basis-function model, theta = W[4][25]
   net.layers = h->net.layers;
   net.theta = h->theta.data();
   net.max_width = h->net.max_width;
@@ -1159,6 +1192,7 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out)
 const char *mppi_rollout_variant(const mppi_handle *h)
 {
   if (!h) return "";
+  if (h->basis) return "basis_funcs25_valu";
   if (!use_mfma(h)) return use_valu_reg(h) ? "valu_reg_lds" : "valu_lds";
   static thread_local char buf[64];
   const int b = effective_block(h);
@@ -1200,7 +1234,8 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
   hipError_t e = hipMemcpy(d_s, states, sizeof(float) * 7 * n, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_u, controls, sizeof(float) * 2 * n, hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = use_mfma(h) ? launch_dynamics_mfma(h->hidden, h->n_hidden, h->d_wpack, d_s, d_u, d_o, n,
+    e = h->basis ? launch_dynamics_bf(h->d_theta, d_s, d_u, d_o, n, h->stream)
+        : use_mfma(h) ? launch_dynamics_mfma(h->hidden, h->n_hidden, h->d_wpack, d_s, d_u, d_o, n,
                                            h->cfg.negate_yaw_der ? 1 : 0, h->stream)
                     : launch_dynamics_valu(h->net, h->d_theta, d_s, d_u, d_o, n,
                                            h->cfg.negate_yaw_der ? 1 : 0, h->stream);

@@ -29,6 +29,11 @@ hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const fl
                                 const float *controls, float *ders, int n, int negate_yaw_der,
                                 hipStream_t stream);
 
+// rollout_bf.hip (GeneralizedLinear basis-function dynamics, W[4][25] in a.wpack)
+hipError_t launch_rollout_bf(const RolloutArgs &a, hipStream_t stream);
+hipError_t launch_dynamics_bf(const float *W, const float *states, const float *controls, float *ders, int n,
+                              hipStream_t stream);
+
 // solve_kernels.hip
 hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
                              float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,

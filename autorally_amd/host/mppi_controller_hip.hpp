@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/mppi_hip.h"
+#include "../csrc/basis_funcs.hpp"  // CarBasisFuncs arithmetic (header-only, shared with the device kernel)
 #include "npz.hpp"
 #include "param_getter.hpp"
 
@@ -154,6 +155,76 @@ class NeuralNetModel {
 };
 
 // ------------------------------------------------------------------------------------------
+// GeneralizedLinear<CarBasisFuncs, 7, 2, 25, CarKinematics, 3> (PI/generalized_linear.cuh:52-117):
+// the reference's second DYNAMICS_T (path_integral_bf, path_integral_main.cu:70-74).
+class GeneralizedLinear {
+ public:
+  static const int STATE_DIM = 7, CONTROL_DIM = 2, DYNAMICS_DIM = 4, NUM_BFS = 25;
+  std::vector<int> net_structure_;          // empty: selects the basis-function kernel (mppi_config.n_layers = 0)
+  std::vector<float2_> control_rngs_;       // generalized_linear.cuh:62
+  bool negate_yaw_der = true;               // fixed: computeKinematics always negates (generalized_linear.cu:216)
+
+  // GeneralizedLinear(float delta_t, float2* control_rngs = NULL), generalized_linear.cu:63-84
+  explicit GeneralizedLinear(float delta_t, const float2_ *control_rngs = nullptr) : dt_(delta_t)
+  {
+    control_rngs_.resize(CONTROL_DIM);
+    for (int i = 0; i < CONTROL_DIM; i++)
+      control_rngs_[i] = control_rngs ? control_rngs[i] : float2_{-FLT_MAX, FLT_MAX};
+    theta_.assign((size_t)DYNAMICS_DIM * NUM_BFS, 0.0f);
+  }
+  float dt() const { return dt_; }
+  const std::vector<float> &theta() const { return theta_; }
+
+  // setParams(theta), :86-91; row-major [DYNAMICS_DIM][NUM_BFS]
+  void setParams(const std::vector<float> &theta)
+  {
+    if (theta.size() != theta_.size()) throw std::runtime_error("GeneralizedLinear::setParams: need 4 x 25 values");
+    theta_ = theta;
+    version_++;
+  }
+  // loadParams(model_path), :93-110: key "W", (4, 25) float64, cast to float
+  void loadParams(const std::string &model_path)
+  {
+    if (!file_exists(model_path)) throw std::runtime_error("Could not load generalized linear model at path: " + model_path);
+    npz_t d = npz_load(model_path);
+    if (!d.count("W")) throw std::runtime_error("model file lacks W");
+    const NpyArray &W = d["W"];
+    if (W.num_vals() != theta_.size()) throw std::runtime_error("W must be (4, 25)");
+    for (size_t i = 0; i < theta_.size(); i++) theta_[i] = (float)W.at(i);
+    version_++;
+  }
+  // host updateState (:140-167): clamp, kinematics, basis functions, W phi, Euler step
+  void updateState(float *state, float *control) const
+  {
+    for (int i = 0; i < CONTROL_DIM; i++) {
+      if (control[i] < control_rngs_[i].x) control[i] = control_rngs_[i].x;
+      else if (control[i] > control_rngs_[i].y) control[i] = control_rngs_[i].y;
+    }
+    float sd[STATE_DIM], phi[NUM_BFS];
+    const float c = cosf(state[2]), s = sinf(state[2]);
+    sd[0] = fmaf(c, state[4], -(s * state[5]));
+    sd[1] = fmaf(s, state[4], c * state[5]);
+    sd[2] = -state[6];
+    mppi::basis_funcs(state, control[0], control[1], phi);
+    mppi::basis_dynamics(theta_.data(), phi, sd + 3);
+    for (int i = 0; i < STATE_DIM; i++) state[i] = fmaf(sd[i], dt_, state[i]);
+  }
+  // paramsToDevice(), :112-118
+  void paramsToDevice(mppi_handle *h)
+  {
+    NeuralNetModel::check(mppi_set_bf_params(h, theta_.data(), theta_.size()), h);
+    float lo[2] = {control_rngs_[0].x, control_rngs_[1].x}, hi[2] = {control_rngs_[0].y, control_rngs_[1].y};
+    NeuralNetModel::check(mppi_set_control_limits(h, lo, hi), h);
+  }
+  unsigned version_ = 0;
+  void touch() { version_++; }
+
+ private:
+  float dt_;
+  std::vector<float> theta_;
+};
+
+// ------------------------------------------------------------------------------------------
 class MPPICosts {
  public:
   // CostParams, costs.cuh:67-85
@@ -250,13 +321,14 @@ class MPPICosts {
 };
 
 // ------------------------------------------------------------------------------------------
-class MPPIController {
+template <class DYNAMICS_T>
+class MPPIControllerT {
  public:
   static const int BLOCKSIZE_WRX = 64;
   static const int STATE_DIM = 7, CONTROL_DIM = 2;
   int NUM_ROLLOUTS;
   int numTimesteps_, hz_, optimizationStride_;
-  NeuralNetModel *model_;
+  DYNAMICS_T *model_;
   MPPICosts *costs_;
 
   // MPPIController(model, costs, exploration_var, init_control, hz, num_timesteps,
@@ -264,7 +336,7 @@ class MPPIController {
   // `rollouts` replaces the ROLLOUTS template argument; rounded down to a multiple of 64 like
   // NUM_ROLLOUTS (mppi_controller.cuh:58-60).  `device` replaces the cudaStream_t argument: each
   // controller owns its own stream on that device.
-  MPPIController(NeuralNetModel *model, MPPICosts *costs, const float *exploration_var, const float *init_control,
+  MPPIControllerT(DYNAMICS_T *model, MPPICosts *costs, const float *exploration_var, const float *init_control,
                  int hz, int num_timesteps, int optimization_stride, float gamma, int num_iters, int rollouts,
                  int device = 0, unsigned long long seed = 1234ULL)
       : NUM_ROLLOUTS((rollouts / BLOCKSIZE_WRX) * BLOCKSIZE_WRX), numTimesteps_(num_timesteps), hz_(hz),
@@ -294,9 +366,9 @@ class MPPIController {
     control_solution_.assign((size_t)numTimesteps_ * CONTROL_DIM, 0.0f);
     syncParams(true);
   }
-  ~MPPIController() { deallocateCudaMem(); }
-  MPPIController(const MPPIController &) = delete;
-  MPPIController &operator=(const MPPIController &) = delete;
+  ~MPPIControllerT() { deallocateCudaMem(); }
+  MPPIControllerT(const MPPIControllerT &) = delete;
+  MPPIControllerT &operator=(const MPPIControllerT &) = delete;
 
   void deallocateCudaMem()
   {
@@ -403,5 +475,9 @@ class MPPIController {
   unsigned model_seen_ = 0, cost_seen_ = 0, map_seen_ = 0;
   bool first_model_ = true;
 };
+
+// MPPIController<DynamicsModel, MPPICosts, ...> of the two reference builds (path_integral_main.cu:65-78)
+using MPPIController = MPPIControllerT<NeuralNetModel>;
+using MPPIControllerBF = MPPIControllerT<GeneralizedLinear>;
 
 }  // namespace mppi_host

@@ -1,108 +1,21 @@
 // path_integral_nn.cpp -- ROS-free equivalent of the reference binary `path_integral_nn`
-// (src/path_integral/path_integral_main.cu:80-153): reads the SAME launch XML (same keys, same
-// $(env AR_MPPI_PARAMS_PATH) expansion) and the same cnpy-format .npz model / costmap files, builds
-// costs + model + two controllers and runs the control loop in the reference's debug_mode
-// (self-simulation, PI/run_control_loop.cuh:296-302).  ROS does not exist in this image, so there is
-// no plant I/O; `profiler_max_iter` (or --max-iter) ends the run like the reference's profiler mode.
+// (src/path_integral/path_integral_main.cu with USE_NEURAL_NETWORK_MODEL__, :65-69): see
+// path_integral_main.hpp.
 //
 // usage: path_integral_nn <launch.xml> [--rollouts K] [--layers 6-32-32-4] [--max-iter N]
 //                         [--no-sleep] [--device D] [--trace file] [--set key=value ...]
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-
-#include "run_control_loop.hpp"
+#include "path_integral_main.hpp"
 
 using namespace mppi_host;
 
-static std::vector<int> parse_layers(const std::string &s)
-{
-  std::vector<int> v;
-  size_t i = 0;
-  while (i < s.size()) {
-    size_t j = s.find('-', i);
-    if (j == std::string::npos) j = s.size();
-    v.push_back(std::atoi(s.substr(i, j - i).c_str()));
-    i = j + 1;
-  }
-  return v;
-}
-
 int main(int argc, char **argv)
 {
-  if (argc < 2) {
-    fprintf(stderr, "usage: %s <launch.xml> [--rollouts K] [--layers 6-32-32-4] [--max-iter N] [--no-sleep] "
-                    "[--device D] [--trace file] [--set key=value]\n", argv[0]);
-    return 2;
-  }
-  int rollouts = 1920;  // MPPI_NUM_ROLLOUTS__, path_integral_main.cu:66
-  std::vector<int> layers = {6, 32, 32, 4};  // NeuralNetModel<7,2,3,6,32,32,4>, :69
-  int max_iter = -1, device = 0;
-  bool sleep_to_rate = true;
-  const char *trace_path = nullptr;
-  std::vector<std::string> overrides;
-  for (int i = 2; i < argc; i++) {
-    if (!strcmp(argv[i], "--rollouts") && i + 1 < argc) rollouts = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--layers") && i + 1 < argc) layers = parse_layers(argv[++i]);
-    else if (!strcmp(argv[i], "--max-iter") && i + 1 < argc) max_iter = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--trace") && i + 1 < argc) trace_path = argv[++i];
-    else if (!strcmp(argv[i], "--set") && i + 1 < argc) overrides.push_back(argv[++i]);
-    else if (!strcmp(argv[i], "--no-sleep")) sleep_to_rate = false;
-    else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
-  }
-  try {
-    ParamMap params;
-    loadParams(&params, argv[1]);
-    for (const std::string &kv : overrides) {  // e.g. --set x_pos=0.0 (double), typed like the existing key
-      const size_t eq = kv.find('=');
-      if (eq == std::string::npos) throw std::runtime_error("--set needs key=value");
-      const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
-      const ParamValue::Type t = params.count(k) ? params[k].getType() : ParamValue::TypeString;
-      if (t == ParamValue::TypeInt) params[k] = ParamValue(std::stoi(v));
-      else if (t == ParamValue::TypeDouble) params[k] = ParamValue(std::stod(v));
-      else if (t == ParamValue::TypeBoolean) params[k] = ParamValue(v == "true");
-      else params[k] = ParamValue(v);
-    }
-    if (max_iter >= 0) params["profiler_max_iter"] = ParamValue(max_iter);
-    params["debug_mode"] = ParamValue(true);  // headless: always the self-simulating mode
-
-    MPPICosts costs(&params);
-    const float2_ control_constraints[2] = {{-.99f, .99f}, {-.99f, (float)(double)params["max_throttle"]}};
-    NeuralNetModel model(layers, (float)(1.0 / (int)params["hz"]), control_constraints);
-    model.loadParams((std::string)params["model_path"]);
-    if (params.count("negate_yaw_der")) model.negate_yaw_der = (bool)params["negate_yaw_der"];
-
-    float exploration_std[2] = {(float)(double)params["steering_std"], (float)(double)params["throttle_std"]};
-    float init_u[2] = {(float)(double)params["init_steering"], (float)(double)params["init_throttle"]};
-    const int hz = (int)params["hz"], T = (int)params["num_timesteps"], stride = (int)params["optimization_stride"];
-    const float gamma = (float)(double)params["gamma"];
-    const int num_iters = (int)params["num_iters"];
-
-    // both controllers seed their generator with 1234 (mppi_controller.cu:331): identical streams
-    MPPIController actual(&model, &costs, exploration_std, init_u, hz, T, stride, gamma, num_iters, rollouts, device);
-    MPPIController predicted(&model, &costs, exploration_std, init_u, hz, T, stride, gamma, num_iters, rollouts, device);
-    SimPlant robot;
-    std::atomic<bool> is_alive(true);
-    FILE *trace = trace_path ? fopen(trace_path, "w") : nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    const LoopStats st = runControlLoop(&predicted, &actual, &robot, &params, &is_alive, sleep_to_rate, trace);
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (trace) fclose(trace);
-    // the gains handed to the plant with the last solution: first-step row sums as a fingerprint
-    double g0 = 0.0, g1 = 0.0;
-    if (robot.last_feedback_gains.size() >= 14)
-      for (int i = 0; i < 7; i++) { g0 += robot.last_feedback_gains[i]; g1 += robot.last_feedback_gains[7 + i]; }
-    printf("{\"iterations\": %d, \"rollouts\": %d, \"timesteps\": %d, \"avg_tick_ms\": %.4f, \"avg_sleep_ms\": %.4f, "
-           "\"wall_s\": %.4f, \"actual_state_used\": %d, \"final_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f], "
-           "\"feedback_gain_row_sums_t0\": [%.6f, %.6f]}\n",
-           st.iterations, actual.NUM_ROLLOUTS, T, st.avg_tick_ms, st.avg_sleep_ms, wall, robot.n_actual,
-           st.final_state[0], st.final_state[1], st.final_state[2], st.final_state[3], st.final_state[4],
-           st.final_state[5], st.final_state[6], g0, g1);
-  } catch (const std::exception &e) {
-    fprintf(stderr, "path_integral_nn: %s\n", e.what());
-    return 1;
-  }
-  return 0;
+  // MPPI_NUM_ROLLOUTS__ = 1920, NeuralNetModel<7,2,3,6,32,32,4> (path_integral_main.cu:66-69)
+  return path_integral_main<NeuralNetModel>(
+      argc, argv, 1920, [](ParamMap &params, const std::vector<int> &layers, const float2_ *control_constraints) {
+        std::unique_ptr<NeuralNetModel> m(new NeuralNetModel(layers, (float)(1.0 / (int)params["hz"]), control_constraints));
+        m->loadParams((std::string)params["model_path"]);
+        if (params.count("negate_yaw_der")) m->negate_yaw_der = (bool)params["negate_yaw_der"];
+        return m;
+      });
 }

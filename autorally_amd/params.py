@@ -88,3 +88,12 @@ def save_costmap_npz(path, channel0, x_bounds, y_bounds, ppm):
              yBounds=np.array(y_bounds, dtype=np.float32),
              pixelsPerMeter=np.array([ppm], dtype=np.float32),
              channel0=ch0.reshape(-1), channel1=z, channel2=z, channel3=z)
+
+
+def load_bf_npz(path):
+    """GeneralizedLinear::loadParams (generalized_linear.cu:95-110): key "W", (4, 25) <f8 -> float32."""
+    z = np.load(path)
+    W = np.asarray(z["W"], dtype=np.float64)
+    if W.shape != (4, 25):
+        raise ValueError("W must be (4, 25), got %r" % (W.shape,))
+    return W.astype(np.float32)

@@ -51,6 +51,9 @@ def measured_traffic(cfg, variant):
     return None
 
 
+BASIS_FLOPS_PER_UPDATE = 270  # 100 MACs of W phi + ~70 multiply/divide/add of the 25 basis functions, no transcendentals
+
+
 def flops_per_update(layers):
     """MAC = 2, bias add = 1, no transcendentals: 2756 for 6-32-32-4, 9604 for 6-64-64-4."""
     return sum(2 * a * b + b for a, b in zip(layers[:-1], layers[1:]))
@@ -80,7 +83,11 @@ def rank_workload(args, rank):
     and RNG seed.  Rank 0 alone is configs[2]."""
     from autorally_amd import synthetic as S
     layers = [int(x) for x in args.layers.split("-")] if args.layers else None
-    return S.make_config(args.K, args.T, layers=layers, track="oval", instance=rank, seed=1234 + rank)
+    over = {}
+    if args.dynamics == "basis":
+        from autorally_amd import params as P
+        over["bf_W"] = P.load_bf_npz(os.path.join(ROOT, "tests", "golden", "models", "basis_function_09_12_2018.npz"))
+    return S.make_config(args.K, args.T, layers=layers, track="oval", instance=rank, seed=1234 + rank, **over)
 
 
 def max_over_ranks(dist, value, cuda):
@@ -153,6 +160,9 @@ def main():
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--layers", type=str, default="")
+    ap.add_argument("--dynamics", choices=("nn", "basis"), default="nn",
+                    help="basis: the reference's second model family (GeneralizedLinear, 25 basis functions; "
+                         "its build uses K=2560), with the shipped basis_function_09_12_2018.npz")
     ap.add_argument("--variant", type=str, default="auto")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,9 +242,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if cuda else "selftest-cpu (oracle stand-in, NOT a benchmark)",
-            "config": {"workload": "K=%d T=%d %s NN dynamics, CCRF-like oval costmap via .npz, "
-                                   "one independent MPPI instance per GPU" % (K, T, "-".join(map(str, cfg["layers"]))),
-                       "K": K, "T": T, "layers": cfg["layers"], "num_iters": iters,
+            "config": {"workload": "K=%d T=%d %s dynamics, CCRF-like oval costmap via .npz, "
+                                   "one independent MPPI instance per GPU"
+                                   % (K, T, "25 basis functions (GeneralizedLinear)" if cfg.get("bf_W") is not None
+                                      else "-".join(map(str, cfg["layers"])) + " NN"),
+                       "K": K, "T": T, "layers": [] if cfg.get("bf_W") is not None else cfg["layers"], "num_iters": iters,
                        "rollout_variant": sol.rollout_variant() if cuda else "none",
                        "parallelism": "replicas x%d (no collective)" % world},
             "state_updates_per_s": value * T,
@@ -244,7 +256,7 @@ def main():
             st = sol.get_stage_times()
             n = max(1, st["n_solves"])
             rollout_s = st["rollout_ms"] * 1e-3 / n / iters
-            fl = flops_per_update(cfg["layers"])
+            fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
             bpu = ROLLOUT_BYTES_INLINE_NOISE if ("quad" in variant) else ROLLOUT_BYTES_BUFFERED_NOISE

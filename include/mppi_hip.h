@@ -56,7 +56,9 @@ typedef struct {
   int optimization_stride;    /* opt_delay of rolloutKernel */
   float gamma;
   int num_iters;
-  int n_layers;               /* entries of layers[], input and output included */
+  int n_layers;               /* entries of layers[], input and output included; 0 selects the reference's
+                               * other dynamics family, GeneralizedLinear<CarBasisFuncs,7,2,25,CarKinematics,3>
+                               * (path_integral_main.cu:70-74): parameters by mppi_set_bf_params */
   int layers[MPPI_MAX_LAYERS];/* e.g. {6,32,32,4}; layers[0]==6, layers[n-1]==4 */
   float exploration_std[2];   /* nu */
   float init_control[2];      /* init_u */
@@ -105,6 +107,11 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out);
 /* deallocateCudaMem (mppi_controller.cu:389-400), without the double free of Q14. */
 int mppi_destroy(mppi_handle *h);
 
+/* GeneralizedLinear::setParams / loadParams / paramsToDevice (PI/generalized_linear.cu:86-118):
+ * W row-major [4][25] (the .npz key "W"), n == 100.  Only for handles created with n_layers == 0.
+ * The basis functions are CarBasisFuncs (PI/car_bfs.cuh:44-120); the yaw rate is always negated
+ * (generalized_linear.cu:216), negate_yaw_der is ignored. */
+int mppi_set_bf_params(mppi_handle *h, const float *W, size_t n);
 /* NeuralNetModel::paramsToDevice (neural_net_model.cu:120-150): theta is the packed
  * [W1|b1|W2|b2|...] blob, n == NUM_PARAMS. The .npz is read by the C++ host layer. */
 int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n);

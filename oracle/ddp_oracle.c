@@ -10,6 +10,7 @@
  *   ModelWrapperDDP::f / df                           ddp/ddp_model_wrapper.h:57-79
  *   TrackingCostDDP / TrackingTerminalCost            ddp/ddp_tracking_costs.h:35-52, 98-111
  *   NeuralNetModel::computeKinematics/Dynamics/Grad   PI/neural_net_model.cu:191-264
+ *   GeneralizedLinear (host) + numerical Jacobian     PI/generalized_linear.cu:140-175, ddp/ddp_dynamics.h:71-84
  * (paths relative to /root/reference/autorally_control/include/autorally_control/, PI = path_integral).
  * Eigen's internal summation order of the small products is not specified by the source; sums here
  * run in index order.  tests/test_ddp.py additionally checks the gains against a float64 Riccati
@@ -26,6 +27,7 @@
 #define NZ (NS + NC)
 
 typedef struct {
+  const float *bf_W; /* != NULL: GeneralizedLinear basis-function model (W[4][25]); the network fields are unused */
   const float *theta;
   const int *layers;
   int n_layers;
@@ -34,9 +36,14 @@ typedef struct {
   int width;
 } ddp_net;
 
-static void net_init(ddp_net *n, const float *theta, const int *layers, int n_layers)
+static void net_init(ddp_net *n, const float *theta, const int *layers, int n_layers, const float *bf_W)
 {
   int off = 0, w = 0;
+  n->bf_W = bf_W;
+  if (bf_W) {
+    n->n_layers = 0;
+    return;
+  }
   n->theta = theta;
   n->layers = layers;
   n->n_layers = n_layers;
@@ -83,8 +90,45 @@ static void model_f(ddp_net *n, int negate_yaw_der, const float *x, const float 
 {
   dx[0] = cosf(x[2]) * x[4] - sinf(x[2]) * x[5];
   dx[1] = sinf(x[2]) * x[4] + cosf(x[2]) * x[5];
+  if (n->bf_W) {
+    /* GeneralizedLinear host computeKinematics / computeDynamics, generalized_linear.cu:151-167 */
+    float phi[ORC_NUM_BFS];
+    dx[2] = -x[6];
+    for (int i = 0; i < ORC_NUM_BFS; i++) phi[i] = orc_basis_func(i, x, u);
+    for (int j = 0; j < 4; j++) {
+      float acc = 0.0f;
+      for (int y = 0; y < 4; y++) { /* same summation as the rollout restatement (mppi_oracle.c bf_state_deriv) */
+        float part = 0.0f;
+        for (int i = y; i < ORC_NUM_BFS; i += 4) part = fmaf(n->bf_W[j * ORC_NUM_BFS + i], phi[i], part);
+        acc += part;
+      }
+      dx[3 + j] = acc;
+    }
+    return;
+  }
   dx[2] = negate_yaw_der ? -x[6] : x[6];
   net_forward(n, x, u, dx + 3);
+}
+
+/* Dynamics::df -> Eigen::NumericalDiff<..., Central> (ddp/ddp_dynamics.h:71-84) for a model without
+ * computeGrad: h_j = sqrt(FLT_EPSILON) |z_j| (sqrt(FLT_EPSILON) if that is 0), central difference, fp32 */
+static void model_jac_numeric(ddp_net *n, int negate_yaw_der, const float *x, const float *u, float *J)
+{
+  const float eps = sqrtf(1.1920928955078125e-07f);
+  float z[NZ], v1[NS], v2[NS];
+  memcpy(z, x, sizeof(float) * NS);
+  memcpy(z + NS, u, sizeof(float) * NC);
+  for (int j = 0; j < NZ; j++) {
+    const float zj = z[j];
+    float h = eps * fabsf(zj);
+    if (h == 0.0f) h = eps;
+    z[j] += h;
+    model_f(n, negate_yaw_der, z, z + NS, v2);
+    z[j] -= 2 * h;
+    model_f(n, negate_yaw_der, z, z + NS, v1);
+    z[j] = zj;
+    for (int i = 0; i < NS; i++) J[i * NZ + j] = (v2[i] - v1[i]) / (2 * h);
+  }
 }
 
 /* computeGrad, neural_net_model.cu:233-264: J is [NS][NZ] row-major */
@@ -163,12 +207,12 @@ int orc_ddp_feedback_gains(const float *theta, const int *layers, int n_layers, 
                            const float *u_lo, const float *u_hi, int negate_yaw_der, const float *Q,
                            const float *R, const float *Qf, const float *x0, const float *target_x,
                            const float *target_u, float *feedback, float *feedforward, float *xout,
-                           float *uout, float *total_cost)
+                           float *uout, float *total_cost, const float *bf_W)
 {
   const int H = T;
   int rc = 0;
   ddp_net n;
-  net_init(&n, theta, layers, n_layers);
+  net_init(&n, theta, layers, n_layers, bf_W);
   float *x = (float *)calloc((size_t)H * NS, sizeof(float));
   float *u = (float *)malloc(sizeof(float) * (size_t)H * NC);
   float *df = (float *)malloc(sizeof(float) * (size_t)H * NS * NZ);
@@ -189,7 +233,8 @@ int orc_ddp_feedback_gains(const float *theta, const int *layers, int n_layers, 
   /* ddp.h:71-80 */
   for (int k = 0; k < H; k++) {
     float *J = df + (size_t)k * NS * NZ;
-    model_jac(&n, x + k * NS, u + k * NC, J);
+    if (bf_W) model_jac_numeric(&n, negate_yaw_der, x + k * NS, u + k * NC, J);
+    else model_jac(&n, x + k * NS, u + k * NC, J);
     for (int i = 0; i < NS * NZ; i++) J[i] = J[i] * dt;
     for (int i = 0; i < NS; i++) J[i * NZ + i] += 1.0f;
     for (int i = 0; i < NS; i++) dL[k * NZ + i] = Q[i] * (x[k * NS + i] - target_x[k * NS + i]);

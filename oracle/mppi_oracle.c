@@ -77,8 +77,85 @@ void orc_nn_forward(const float *theta, const int *layers, int n_layers, const f
 }
 
 /* computeKinematics (:346-355) + computeDynamics (:357-410) */
+/* CarBasisFuncs::basisFuncX, car_bfs.cuh:44-120.  Literals like 10.0 / .45 are double in the
+ * source, so those sub-expressions are evaluated in double and rounded on assignment to the float
+ * phi, exactly as a C compiler does; 1960000 / 2744000000 are integer literals (float division). */
+float orc_basis_func(int idx, const float *s, const float *u)
+{
+  float phi = 0;
+  switch (idx) {
+    case 0: phi = u[1]; break;
+    case 1: phi = s[4] / 10.0; break;
+    case 2: phi = (s[4] > .1) ? sinf(u[0]) * tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]) / 1200.0
+                              : sinf(u[0]) * tanf(-u[0]) / 1200.0; break;
+    case 3: phi = (s[4] > .1) ? sinf(u[0]) * tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]) *
+                                    fabsf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0])) / 1440000.0
+                              : sinf(u[0]) * tanf(-u[0]) * fabsf(tanf(-u[0])) / 1440000.0; break;
+    case 4: phi = (s[4] > .1) ? sinf(u[0]) * powf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]), 3) / 1728000000.0
+                              : sinf(u[0]) * powf(tanf(-u[0]), 3) / 1728000000.0; break;
+    case 5: phi = s[6] * s[5] / 25.0; break;
+    case 6: phi = s[6] / 10.0; break;
+    case 7: phi = s[5] / 10.0; break;
+    case 8: phi = sinf(u[0]); break;
+    case 9: phi = (s[4] > .1) ? s[5] / s[4] / 40.0 : 0; break;
+    case 10: phi = (s[4] > .1) ? tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]) / 1400.0
+                               : tanf(-u[0]) / 1400.0; break;
+    case 11: phi = (s[4] > .1) ? tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]) *
+                                     fabsf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0])) / 1960000
+                               : tanf(-u[0]) * fabsf(tanf(-u[0])) / 1960000; break;
+    case 12: phi = (s[4] > .1) ? powf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]), 3) / 2744000000
+                               : powf(tanf(-u[0]), 3) / 2744000000; break;
+    case 13: phi = (s[4] > .1) ? (s[5] / s[4] - .35 * s[6] / s[4]) / 40.0 : 0; break;
+    case 14: phi = (s[4] > .1) ? (s[5] / s[4] - .35 * s[6] / s[4]) * fabs(s[5] / s[4] - .35 * s[6] / s[4]) / 1600.0 : 0; break;
+    case 15: phi = (s[4] > .1) ? powf(s[5] / s[4] - .35 * s[6] / s[4], 3) / 64000.0 : 0; break;
+    case 16: phi = s[6] * s[4] / 50.0; break;
+    case 17: phi = s[3]; break;
+    case 18: phi = s[3] * s[6]; break;
+    case 19: phi = s[3] * s[4] / 3.0; break;
+    case 20: phi = s[3] * s[4] * s[6] / 5.0; break;
+    case 21: phi = powf(s[4], 2) / 100.0; break;
+    case 22: phi = powf(s[4], 3) / 1000.0; break;
+    case 23: phi = powf(u[1], 2); break;
+    case 24: phi = powf(u[1], 3); break;
+  }
+  return phi;
+}
+
+/* GeneralizedLinear device computeStateDeriv (generalized_linear.cu:196-245): kinematics with the
+ * yaw rate always negated (:216), then s_der[3+j] = sum_i W[j][i] phi_i.  The reference adds the
+ * partial sums of its BLOCKSIZE_Y = 4 (path_integral_main.cu:73) y-threads with atomicAdd, i.e. in
+ * no fixed order; this restatement takes the execution in which they land in thread order:
+ * p_y = sum over i = y, y+4, ... (FMA-contracted like nvcc's `+=`), s_der = ((0+p_0)+p_1)+p_2)+p_3. */
+static void bf_state_deriv(const orc_problem *p, const float *s, const float *u, float *sd)
+{
+  const float c = cosf(s[2]), sn = sinf(s[2]);
+  if (p->fma_mode) {
+    sd[0] = fmaf(c, s[4], -(sn * s[5]));
+    sd[1] = fmaf(sn, s[4], c * s[5]);
+  } else {
+    sd[0] = c * s[4] - sn * s[5];
+    sd[1] = sn * s[4] + c * s[5];
+  }
+  sd[2] = -s[6];
+  float phi[ORC_NUM_BFS];
+  for (int i = 0; i < ORC_NUM_BFS; i++) phi[i] = orc_basis_func(i, s, u);
+  for (int j = 0; j < 4; j++) {
+    float acc = 0.0f;
+    for (int y = 0; y < 4; y++) {
+      float part = 0.0f;
+      for (int i = y; i < ORC_NUM_BFS; i += 4) part = mac(p->bf_W[j * ORC_NUM_BFS + i], phi[i], part, p->fma_mode);
+      acc += part;
+    }
+    sd[3 + j] = acc;
+  }
+}
+
 void orc_state_deriv(const orc_problem *p, const float *s, const float *u, float *sd)
 {
+  if (p->bf_W) {
+    bf_state_deriv(p, s, u, sd);
+    return;
+  }
   const float c = cosf(s[2]), sn = sinf(s[2]);
   if (p->fma_mode) {
     sd[0] = fmaf(c, s[4], -(sn * s[5]));

@@ -69,7 +69,15 @@ typedef struct {
   const float *map_rgba; /* float4[H][W], x fastest, costs.cu:206-216 */
   int fma_mode;       /* 1: nvcc-style FMA contraction (nominal), 0: none */
   int nthreads;       /* OpenMP threads for the k loop; <=1 = serial */
+  /* Second dynamics family: GeneralizedLinear<CarBasisFuncs,7,2,25,CarKinematics,3>,
+   * PI/generalized_linear.cu:169-245 + PI/car_bfs.cuh:44-120.  bf_W != NULL selects it (theta/layers
+   * are then unused): row-major [4][25], the .npz key "W" (generalized_linear.cu:99-106). */
+  const float *bf_W;
 } orc_problem;
+
+#define ORC_NUM_BFS 25
+/* CarBasisFuncs::basisFuncX, car_bfs.cuh:44-120 (source types kept: double where the literal is) */
+float orc_basis_func(int idx, const float *s, const float *u);
 
 /* OpenMP team size used by loops that have no orc_problem (weighted reduction). */
 void orc_set_num_threads(int n);
@@ -129,7 +137,7 @@ int orc_ddp_feedback_gains(const float *theta, const int *layers, int n_layers, 
                            const float *u_lo, const float *u_hi, int negate_yaw_der, const float *Q,
                            const float *R, const float *Qf, const float *x0, const float *target_x,
                            const float *target_u, float *feedback, float *feedforward, float *xout,
-                           float *uout, float *total_cost);
+                           float *uout, float *total_cost, const float *bf_W /* NULL: network model */);
 
 /* ---- noise generator spec (this build's own; cuRAND's XORWOW stream is not reproducible) ---- */
 typedef struct { uint32_t s1[3]; uint32_t s2[3]; } orc_mrg_state;

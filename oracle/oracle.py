@@ -57,6 +57,7 @@ class Problem(C.Structure):
         ("map_rgba", C.POINTER(C.c_float)),
         ("fma_mode", C.c_int),
         ("nthreads", C.c_int),
+        ("bf_W", C.POINTER(C.c_float)),
     ]
 
 
@@ -115,9 +116,11 @@ def lib():
         L.orc_mrg_jump_matrices.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_box_muller.argtypes = [C.c_float, C.c_float, fp, fp]
         L.orc_generate_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, fp]
+        L.orc_basis_func.restype = C.c_float
+        L.orc_basis_func.argtypes = [C.c_int, fp, fp]
         L.orc_ddp_feedback_gains.restype = C.c_int
         L.orc_ddp_feedback_gains.argtypes = [fp, ip, C.c_int, C.c_int, C.c_float, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp,
-                                             fp, fp, fp, fp, fp]
+                                             fp, fp, fp, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -169,6 +172,11 @@ class Oracle:
         p.map_rgba = _fp(self.map)
         p.fma_mode = int(fma_mode)
         p.nthreads = int(nthreads)
+        # second dynamics family (GeneralizedLinear, generalized_linear.cu): cfg["bf_W"] = W[4][25]
+        self.bf_W = None
+        if cfg.get("bf_W") is not None:
+            self.bf_W = np.ascontiguousarray(cfg["bf_W"], dtype=np.float32).reshape(4, 25)
+            p.bf_W = _fp(self.bf_W)
         self.L.orc_set_num_threads(int(nthreads))
         self.p = p
 
@@ -263,7 +271,8 @@ class Oracle:
         tc = np.zeros(1, np.float32)
         rc = self.L.orc_ddp_feedback_gains(_fp(self.theta), self.p.layers, self.p.n_layers, T, self.p.dt, _fp(lo), _fp(hi),
                                            self.p.negate_yaw_der, _fp(Q), _fp(R), _fp(Qf), _fp(state), _fp(tx), _fp(tu),
-                                           _fp(fb), _fp(ff), _fp(x), _fp(u), _fp(tc))
+                                           _fp(fb), _fp(ff), _fp(x), _fp(u), _fp(tc),
+                                           _fp(self.bf_W) if self.bf_W is not None else None)
         if rc:
             raise RuntimeError("DDP: control Hessian could not be factorised")
         return dict(feedback=fb, feedforward=ff, x=x, u=u, total_cost=float(tc[0]))
