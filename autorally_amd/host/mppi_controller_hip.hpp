@@ -425,19 +425,36 @@ class MPPIControllerT {
   // computeControl(state), mppi_controller.cu:600-675
   void computeControl(const float *state)
   {
-    syncParams(false);  // costs_->paramsToDevice(); model_->paramsToDevice();  (:605-606), only when changed
-    ck(mppi_compute_control(h_, state));
-    float tc = 0.0f;
-    ck(mppi_get_results(h_, nullptr, &tc, nullptr, nullptr));
-    trajectory_cost_ = tc;
-    computeNominalTraj(state);
+    startControl(state);
+    finishControl();
   }
   // computeControl(), :588-598: start from the predicted state (first entry of the state sequence)
   void computeControl()
   {
+    startControl();
+    finishControl();
+  }
+  // The two halves of computeControl, so that a caller with several controllers (runControlLoop has two
+  // that are independent until the arbitration, run_control_loop.cuh:218-270) can put all solves on the
+  // GPU before waiting for the first: each controller owns its stream, the kernels overlap.
+  void startControl(const float *state)
+  {
+    syncParams(false);  // costs_->paramsToDevice(); model_->paramsToDevice();  (:605-606), only when changed
+    for (int i = 0; i < STATE_DIM; i++) solve_state_[i] = state[i];
+    ck(mppi_compute_control_async(h_, solve_state_));
+  }
+  void startControl()
+  {
     float s[STATE_DIM];
     for (int i = 0; i < STATE_DIM; i++) s[i] = state_solution_[i];
-    computeControl(s);
+    startControl(s);
+  }
+  void finishControl()
+  {
+    float tc = 0.0f;
+    ck(mppi_get_results(h_, nullptr, &tc, nullptr, nullptr));  // waits for the solve
+    trajectory_cost_ = tc;
+    computeNominalTraj(solve_state_);
   }
   void computeNominalTraj(const float *state)  // :501-519
   {
@@ -470,6 +487,7 @@ class MPPIControllerT {
   }
   mppi_handle *h_ = nullptr;
   float trajectory_cost_ = 0.0f;
+  float solve_state_[STATE_DIM] = {0, 0, 0, 0, 0, 0, 0};
   std::vector<float> state_solution_, control_solution_;
   FeedbackResult result_;
   unsigned model_seen_ = 0, cost_seen_ = 0, map_seen_ = 0;

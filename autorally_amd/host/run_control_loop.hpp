@@ -121,8 +121,12 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
       actual_state_controller->slideControlAndStateSeq(stride);
       predicted_state_controller->slideControlAndStateSeq(stride);
     }
-    actual_state_controller->computeControl(state);
-    predicted_state_controller->computeControl();
+    // computeControl(state) / computeControl() (:218-219); the two solves are independent, so both are
+    // put on the GPU (one stream per controller) before either is waited for
+    actual_state_controller->startControl(state);
+    predicted_state_controller->startControl();
+    actual_state_controller->finishControl();
+    predicted_state_controller->finishControl();
     if (use_feedback_gains) {  // :220-225: both controllers, from the measured state
       actual_state_controller->computeFeedbackGains(state);
       predicted_state_controller->computeFeedbackGains(state);
