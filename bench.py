@@ -210,7 +210,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if cuda:
-        sol.enable_stage_timing(8)  # HIP events on every 8th solve of the timed region
+        sol.enable_stage_timing(16)  # HIP events on every 16th solve of the timed region
         sol.reset_stage_times()
     if dist is not None:
         dist.barrier()

@@ -302,3 +302,27 @@ def test_async_and_stage_timing():
     st = sol.get_stage_times()
     assert st["n_solves"] == 3 and st["rollout_ms"] > 0 and st["total_ms"] >= st["rollout_ms"]
     sol.close()
+
+
+@pytest.mark.parametrize("K,T,layers", [(4096, 100, None), (64, 37, None), (512, 50, [6, 32, 32, 32, 32, 4])])
+def test_quad_kernel_loops_are_reproducible(K, T, layers):
+    """The four-wave kernel hands data between wavefronts through LDS sequence words: a lost or early
+    hand-over would show up as a control sequence that differs run against run (or from the
+    single-wave form on the same stream of draws), or as a poisoned (NaN) solve."""
+    cfg = S.make_config(K, T, layers=layers, track="oval")
+    sols = [capi.Solver(dict(cfg, seed=7)) for _ in range(3)]
+    sols[0].set_rollout_variant("quad")
+    sols[1].set_rollout_variant("quad")
+    sols[2].set_rollout_variant("fused")
+    x = cfg["start_state"]
+    for it in range(300):
+        us = []
+        for s in sols[:2] if it >= 40 else sols:
+            s.compute_control(x)
+            us.append(s.get_control_seq())
+            s.slide_control_seq(1)
+        assert np.all(np.isfinite(us[0]))
+        for u in us[1:]:
+            np.testing.assert_array_equal(us[0].view(np.uint32), u.view(np.uint32))
+    for s in sols:
+        s.close()
