@@ -80,7 +80,8 @@ struct mppi_handle {
   hipStream_t stream = nullptr;
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
-  unsigned seq = 0;             // sequence number of the last enqueued solve (published in h_res[3])
+  unsigned seq = 0;             // sequence number of the last enqueued solve (last word of every h_res entry)
+  std::vector<float> sg_buf;    // scratch of the host-side Savitzky-Golay pass
   bool basis = false;  // GeneralizedLinear basis-function dynamics (cfg.n_layers == 0); theta holds W[4][25]
   // DDP feedback gains (row f2): weights of initDDP (mppi_controller.cu:410-417) and the last result
   float ddp_Q[7] = {0.5f, 0.5f, 0.25f, 0.0f, 0.05f, 0.01f, 0.01f};
@@ -399,23 +400,57 @@ int upload_controls_if_dirty(mppi_handle *h)
 int wait_pending(mppi_handle *h)
 {
   if (!h->pending) return MPPI_OK;
-  volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(h->h_res) + 3;
+  // The tail kernel writes T+1 entries of 16 B into host-mapped memory -- row t: [u0, u1, 0, seq], then
+  // [beta, eta, trajectory cost, seq] -- each as one store whose last word is this solve's sequence
+  // number.  The solve is complete for the host once every entry carries it.
+  const volatile unsigned *words = reinterpret_cast<const volatile unsigned *>(h->h_res);
+  const int n_entries = h->T + 1;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long spins = 0;
-  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != h->seq) {
+  int next = 0;  // entries [0, next) have been seen with the sequence number
+  for (;;) {
+    while (next < n_entries && __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) == h->seq) next++;
+    if (next == n_entries) break;
     __builtin_ia32_pause();
     if ((++spins & 0xFFFFF) == 0) {
-      if (hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != h->seq)
+      if (hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq)
         return fail(h, MPPI_ERR_HIP, "solve finished without publishing its result block");
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         return fail(h, MPPI_ERR_HIP, "timed out waiting for the solve");
     }
   }
   h->pending = false;
-  h->baseline = h->h_res[0];
-  h->eta = h->h_res[1];
-  h->traj_cost = h->h_res[2];
-  memcpy(h->U.data(), h->h_res + 4, sizeof(float) * 2 * (size_t)h->T);  // device U == host U again
+  h->baseline = h->h_res[4 * h->T + 0];
+  h->eta = h->h_res[4 * h->T + 1];
+  h->traj_cost = h->h_res[4 * h->T + 2];
+  {
+    // savitskyGolay (mppi_controller.cu:468-499) on the host, the same operations in the same order as
+    // the tail kernel applies to the device copy (this file is compiled with -ffp-contract=off):
+    // X = [hist0, hist1, U_0 .. U_{T-1}, U_{T-1}, U_{T-1}], U_i = sum_m f_m X_{i+m}
+    const int T = h->T;
+    std::vector<float> &X = h->sg_buf;
+    X.resize((size_t)(T + 4) * 2);
+    for (int j = 0; j < 4; j++) X[j] = h->hist[j];
+    for (int t = 0; t < T; t++) {
+      X[(t + 2) * 2 + 0] = h->h_res[4 * t + 0];
+      X[(t + 2) * 2 + 1] = h->h_res[4 * t + 1];
+    }
+    for (int r = T + 2; r < T + 4; r++)
+      for (int j = 0; j < 2; j++) X[r * 2 + j] = X[(T + 1) * 2 + j];
+    const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
+    for (int i = 0; i < 2 * T; i++) {
+      float acc = f0 * X[i];
+      float p = f1 * X[i + 2];
+      acc = acc + p;
+      p = f2 * X[i + 4];
+      acc = acc + p;
+      p = f1 * X[i + 6];
+      acc = acc + p;
+      p = f0 * X[i + 8];
+      acc = acc + p;
+      h->U[i] = acc;  // device U == host U again
+    }
+  }
   // The minimum-cost rollout has weight 1 and costs are capped (never NaN), so eta >= 1 always.
   // Anything else means a rollout wavefront gave up on a hand-over (its spin budget) and poisoned
   // its costs: report it instead of returning a NaN control sequence.
@@ -646,8 +681,8 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_sub, sizeof(uint32_t) * 18 * 32));
   CR(hipMalloc(&h->d_one, sizeof(uint32_t) * 18 * 64));
   CR(hipHostMalloc(&h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
-  CR(hipHostMalloc(&h->h_res, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocMapped));
-  memset(h->h_res, 0, sizeof(float) * (2 * (size_t)h->T + 4));
+  CR(hipHostMalloc(&h->h_res, sizeof(float) * 4 * ((size_t)h->T + 1), hipHostMallocMapped));
+  memset(h->h_res, 0, sizeof(float) * 4 * ((size_t)h->T + 1));
   {
     void *dp = nullptr;
     CR(hipHostGetDevicePointer(&dp, h->h_res, 0));

@@ -25,10 +25,13 @@ namespace mppi {
 // runs the (m, j) chains.  With C > 1 the chain results go to a global scratch and the workgroup that
 // arrives last at the row's counter adds them in order; beta, eta and the weights then come from
 // weights_kernel (one launch more, but no K exps per workgroup -- the single-launch form is the
-// latency path of K <= 4096).  The workgroup that finishes last (agent-scope release / acquire around an
-// arrival counter, MI355X guide G16) smooths the sequence and writes the single result block --
-// (beta, eta, trajectory cost, sequence number) + U -- straight into host-mapped memory, so the
-// host needs no D2H copy and no stream synchronise: it polls the sequence number.
+// latency path of K <= 4096).  On the last iteration every row workgroup writes its raw weighted mean
+// straight into host-mapped memory (one 16-B entry carrying the solve's sequence number; the extra
+// workgroup / weights_kernel does the same for beta, eta and the trajectory cost): the host needs no D2H
+// copy and no stream synchronise, it polls the T+1 entries and applies the 5-tap smoothing itself.
+// The workgroup that finishes last (agent-scope arrival counter, MI355X guide G16) smooths the DEVICE
+// copy of the sequence -- the one the next solve perturbs; same operations as the host, bit-identical --
+// and leaves its stride-slid copy for slideControlSeq; none of that is on the host's critical path.
 // Sums over k are pairwise (LDS tree) instead of the host's sequential loop: same value to ~1e-7.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTailThreads = 256;
@@ -79,13 +82,25 @@ __device__ __forceinline__ float block_sum(float v, float *red, float *bc)
   return r;
 }
 
+// One result entry (16 B) straight into host-mapped memory: uncached system-scope store, the sequence
+// number in the last word, so that a reader that sees the new sequence number sees the three values
+// (one PCIe write; if it were split, the halves stay in order).
+__device__ __forceinline__ void publish_entry(float *res, int entry, float v0, float v1, float v2, unsigned seq)
+{
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 v = {v0, v1, v2, __uint_as_float(seq)};
+  float *p = res + 4 * (size_t)entry;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // weights_kernel (K > kRedChunk only): beta, w_k = expf(-gamma (J_k - beta)), eta, trajectory cost --
 // once, in one workgroup, instead of once per workgroup of the tail kernel.
 constexpr int kWeightThreads = 1024;
 constexpr int kWeightCache = 16;  // float4 per thread held in registers: 65536 costs
 __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__restrict__ costs,
                                                                  float *__restrict__ w, float *__restrict__ scal,
-                                                                 int K, float gamma)
+                                                                 int K, float gamma, float *res, int res_entry,
+                                                                 unsigned seq)
 {
   __shared__ float red[kWeightThreads / 64];
   __shared__ float bc;
@@ -150,7 +165,10 @@ __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__
     tc += e * e / eta;
   }
   const float traj = bcast(tc, false);
-  if (tid == 0) { scal[0] = beta; scal[1] = eta; scal[2] = traj; }
+  if (tid == 0) {
+    scal[0] = beta; scal[1] = eta; scal[2] = traj;
+    if (res) publish_entry(res, res_entry, beta, eta, traj, seq);  // last iteration: the host's copy
+  }
 }
 
 struct TailArgs {
@@ -160,7 +178,7 @@ struct TailArgs {
   const float *hist;    // [4]
   float *w;             // [K] exp weights (for mppi_get_results)
   float *scal;          // [3] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup)
-  float *res;           // host-mapped result block: [beta, eta, traj, seq-bits | U(2T)]
+  float *res;           // host-mapped result block, T+1 entries of 16 B: rows [u0, u1, 0, seq], then [beta, eta, traj, seq]
   unsigned *counter;    // [1 + T] arrival counters (all rows, then per row), zero on entry, reset by the last arriver
   float *part;          // [T][K/64][2] chain results when a row is spread over several workgroups (K > kRedChunk)
   int pre;              // K > kRedChunk: beta, eta, trajectory cost and w[] were computed by weights_kernel
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
         __hip_atomic_store(&a.scal[0], beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.scal[1], eta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.scal[2], traj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.last_iter) publish_entry(a.res, T, beta, eta, traj, a.seq);
       }
     }
   }
@@ -280,8 +299,8 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     }
     __syncthreads();
   }
+  float u = 0.0f;
   if (tid < 2 && !extra) {
-    float u = 0.0f;
     const int groups = K / 64;
     int mm = 0;
     for (; mm + 16 <= groups; mm += 16) {  // partials fetched 16 at a time, added in order (:256-260)
@@ -294,6 +313,13 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     for (; mm < groups; mm++) u += partial[mm * 2 + tid];
     // write-through (sc1) store: the hand-off to the last workgroup below needs no L2 write-back
     __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 64) {
+    // The host gets row t NOW (last iteration): it smooths the sequence itself (5 taps per value) as
+    // soon as all T rows and the scalars carry this solve's sequence number, so nothing below -- the
+    // arrival counter, the device-side smoothing for the next solve -- is on its critical path.
+    const float u1 = __shfl(u, 1);  // all lanes of wave 0 active
+    if (tid == 0 && !extra && a.last_iter) publish_entry(a.res, t, u, u1, 0.0f, a.seq);
   }
   // ---- arrival: the last workgroup smooths and publishes.  Hand-off form R1 of the MI355X guide
   // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
@@ -318,11 +344,6 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     else v = __hip_atomic_load(&a.U[2 * (T - 1) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     X[i] = v;
   }
-  // result block in host-mapped memory: relaxed system-scope stores (uncached, straight to PCIe)
-  if (tid < 3) {
-    const float v = __hip_atomic_load(&a.scal[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&a.res[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
   __syncthreads();
   {
     const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
@@ -336,18 +357,13 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
       acc = acc + p;
       p = f0 * X[i + 8];
       acc = acc + p;
-      a.U[i] = acc;
-      __hip_atomic_store(&a.res[4 + i], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      a.U[i] = acc;  // the device copy the next solve perturbs (the host computes the same values itself)
     }
   }
-  // every wave drains its result stores (vmcnt(0) precedes the barrier); posted PCIe writes keep
-  // their order, so the sequence number written afterwards is seen last by the polling host
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned *>(a.res) + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
-  // Off the host's critical path (the result is already published): leave a copy of [U | hist]
+  // Leave a copy of [U | hist]
   // slid by the controller's optimization stride (slideControlSeq, mppi_controller.cu:527-554) in
   // the other buffer, so that the control loop's slide -> solve costs no kernel and no upload.
   if (a.slid != nullptr) {
@@ -447,7 +463,9 @@ hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const
   const int C = (K + kRedChunk - 1) / kRedChunk;
   if (C > 1 && part == nullptr) return hipErrorInvalidValue;
   a.pre = (C > 1) ? 1 : 0;
-  if (a.pre) hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, costs, w, scal, K, gamma);
+  if (a.pre)
+    hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, costs, w, scal, K, gamma,
+                       last_iter ? res : nullptr, T, seq);
   hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), dyn, stream, a);
   return hipGetLastError();
 }
