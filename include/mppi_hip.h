@@ -192,9 +192,12 @@ int mppi_get_feedback_gains(mppi_handle *h, float *feedback, float *feedforward,
 int mppi_enable_stage_timing(mppi_handle *h, int on);
 int mppi_reset_stage_times(mppi_handle *h);
 int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
-/* Name of the rollout kernel variant selected for this net ("mfma16_h32", "valu", ...). */
+/* Name of the rollout kernel variant in use: "mfma16x16x4_h32_l2_quad4w" (four wavefronts per 16
+ * rollouts), "..._fused_b64" (one wavefront per 16 rollouts), "valu_reg_lds", "valu_lds",
+ * "basis_funcs25_valu". */
 const char *mppi_rollout_variant(const mppi_handle *h);
-/* Force a variant (A/B of SURVEY cfg 4): "auto", "mfma", "valu". */
+/* Force a variant (A/B of SURVEY cfg 4 and of the kernel forms): "auto"; "mfma" | "valu" | "valu_lds"
+ * (arithmetic unit); "quad" | "fused" | "block64" | "block256" (form of the MFMA kernel). */
 int mppi_set_rollout_variant(mppi_handle *h, const char *name);
 
 /* Test hook (not part of the drop-in surface): d/dt of n independent (state[7], control[2])
