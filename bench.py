@@ -271,6 +271,22 @@ def main():
                 "algorithmic_GBps": bpu * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
             }
+            if "quad" in variant and cfg.get("bf_W") is None:
+                # The configuration is latency bound (one 16-rollout group per CU, T sequential steps), so next
+                # to the throughput roofline: the step time of the recurrence against what its two dynamics
+                # wavefronts must at least issue (f32 MFMA = 32 cycles, tanh = 38 cycles per
+                # register with packed multiply-adds, MFMA and VALU do not overlap on a SIMD).
+                H, nh = cfg["layers"][1], len(cfg["layers"]) - 2
+                mt, ksh = H // 16, H // 4
+                mfma = 2 * mt + (nh - 1) * (mt // 2) * ksh + ksh          # layer 0 on both waves, own tiles, output layer
+                tanh = 4 * mt + (nh - 1) * 4 * (mt // 2)
+                floor = 32 * mfma + 38 * tanh
+                clk_ghz = 2.4
+                cyc = rollout_s / T * clk_ghz * 1e9
+                out["roofline"]["recurrence"] = {
+                    "cycles_per_step": cyc, "issue_floor_cycles_per_step": floor, "frac_of_floor": floor / cyc if cyc > 0 else 0.0,
+                    "mfma_per_step": mfma, "tanh_per_lane_per_step": tanh, "clock_GHz": clk_ghz,
+                    "note": "kernel time / T, launch and prologue included"}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
