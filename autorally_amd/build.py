@@ -17,8 +17,10 @@ HEADERS = ["mppi_device.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedb
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file), which removes
 # the v_accvgpr_read per accumulator register after every layer
+# host side: x86-64-v3 (AVX2 + FMA) so that fmaf() in the host replays is one instruction (same
+# assumption as oracle/Makefile; every MI355X host CPU has it)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
-         "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma"]
 
 
 def hipcc():
@@ -84,7 +86,7 @@ def build_host(force=False):
         out = os.path.join(BIN, name)
         outs.append(out)
         if force or _stale(out, [src] + hdrs + ([LIB] if libs else [])):
-            cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-DMPPI_NPZ_ZLIB", src, "-o", out] + libs + ["-lz", "-lpthread"]
+            cmd = [cxx, "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-std=c++17", "-Wall", "-DMPPI_NPZ_ZLIB", src, "-o", out] + libs + ["-lz", "-lpthread"]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("host build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
