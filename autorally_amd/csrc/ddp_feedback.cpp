@@ -45,6 +45,11 @@ struct HostModel {
   virtual ~HostModel() {}
   virtual void f(const DdpProblem &p, const float *x, const float *u, float *dx) = 0;
   virtual void jacobian(const DdpProblem &p, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J) = 0;
+  // the same, called right after f(p, x, u, .) on the same (x, u): a model may reuse that evaluation
+  virtual void jacobian_after_f(const DdpProblem &p, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J)
+  {
+    jacobian(p, x, u, J);
+  }
 };
 
 // Host network: forward pass keeping the pre-activations (computeDynamics, neural_net_model.cu:201-230)
@@ -115,15 +120,20 @@ struct HostNet : HostModel {
     forward(x, u, dx + 3);
   }
   // computeGrad (neural_net_model.cu:233-264): 7 x 9 Jacobian of f wrt [x | u]
-  void jacobian(const DdpProblem &, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J) override
+  void jacobian(const DdpProblem &p, const float *x, const float *u, Mat<kDdpS, kDdpSC> &J) override
+  {
+    float out[4];
+    forward(x, u, out);  // "First do the forward pass", neural_net_model.cu:243-244
+    jacobian_after_f(p, x, u, J);
+  }
+  // z / th hold the forward pass of this very (x, u): computeGrad's own forward pass would recompute them
+  void jacobian_after_f(const DdpProblem &, const float *x, const float *, Mat<kDdpS, kDdpSC> &J) override
   {
     J.zero();
     const float sn = std::sin(x[2]), cs = std::cos(x[2]);
     J.v[0][2] = -sn * x[4] - cs * x[5]; J.v[0][4] = cs; J.v[0][5] = -sn;
     J.v[1][2] = cs * x[4] - sn * x[5];  J.v[1][4] = sn; J.v[1][5] = cs;
     J.v[2][6] = -1.0f;  // regardless of negate_yaw_der (reference quirk)
-    float out[4];
-    forward(x, u, out);
     const int L = n.n_layers - 1;  // weight matrices
     // delta: [width of layer l+1... ][4], starts as the 4x4 identity at the output
     std::vector<float> &d = d_, &dn = dn_;
@@ -259,19 +269,21 @@ int ddp_feedback_gains(const DdpNet &net, const DdpProblem &p, const float *x0, 
   std::vector<float> x((size_t)H * kDdpS), u(target_u, target_u + (size_t)H * kDdpC);
   // initial rollout, ddp.h:55-65
   for (int i = 0; i < kDdpS; i++) x[i] = x0[i];
+  std::vector<Mat<kDdpS, kDdpSC>> df(H);
   for (int i = 1; i < H; i++) {
     float *up = &u[(size_t)(i - 1) * kDdpC];
     if (i < H - 1)
       for (int j = 0; j < kDdpC; j++) up[j] = clamp_minmax(up[j], p.u_lo[j], p.u_hi[j]);
     float dx[kDdpS];
     nn.f(p, &x[(size_t)(i - 1) * kDdpS], up, dx);
+    // the Jacobian of ddp.h:73 at the same point, while its forward pass is at hand
+    nn.jacobian_after_f(p, &x[(size_t)(i - 1) * kDdpS], up, df[i - 1]);
     for (int s = 0; s < kDdpS; s++) x[(size_t)i * kDdpS + s] = x[(size_t)(i - 1) * kDdpS + s] + dx[s] * dt;
   }
-  // Jacobians and cost derivatives, ddp.h:71-80
-  std::vector<Mat<kDdpS, kDdpSC>> df(H);
+  nn.jacobian(p, &x[(size_t)(H - 1) * kDdpS], &u[(size_t)(H - 1) * kDdpC], df[H - 1]);
+  // Jacobians (scaled, + I) and cost derivatives, ddp.h:71-80
   std::vector<float> dL((size_t)H * kDdpSC);
   for (int k = 0; k < H; k++) {
-    nn.jacobian(p, &x[(size_t)k * kDdpS], &u[(size_t)k * kDdpC], df[k]);
     for (int i = 0; i < kDdpS; i++)
       for (int j = 0; j < kDdpSC; j++) df[k].v[i][j] = df[k].v[i][j] * dt;
     for (int i = 0; i < kDdpS; i++) df[k].v[i][i] += 1.0f;
