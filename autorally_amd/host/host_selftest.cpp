@@ -2,7 +2,8 @@
 //   npz reader against a numpy-written model file and a round trip of the writer,
 //   launch-XML loader against a launch file in the reference's format,
 //   the headless plant's feedback law.
-// usage: host_selftest <model.npz> <launch.xml> <tmp_dir>
+//   loadTrackData against a costmap file written by the reference's own track_converter.py (optional).
+// usage: host_selftest <model.npz> <launch.xml> <tmp_dir> [costmap.npz]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +83,17 @@ int main(int argc, char **argv)
     REQUIRE(std::fabs(u[1] - (0.3f + 0.25f * (0.8f - 1.0f))) < 1e-6f);  // K_ux = 0.25
     const float far[7] = {0, 10.0f, 0, 0, 1, 0, 0};
     REQUIRE(plant.controlAt(0.01, 0.02, far, true, u) && u[0] == -1.0f);  // saturated like pubControl
+  }
+  // --- MPPICosts::loadTrackData (costs.cu:190-232) on a file produced by the reference's writer ---
+  if (argc > 4) {
+    MPPICosts c(1, 1);
+    c.loadTrackData(argv[4]);
+    double sum = 0.0;
+    for (size_t i = 0; i < (size_t)c.width_ * c.height_; i++) sum += c.track_costs_[4 * i];
+    printf("costmap W=%d H=%d r_c1=[%.9g %.9g %.9g] r_c2=[%.9g %.9g %.9g] trs=[%.9g %.9g %.9g] ch0[0]=%.9g ch0[last]=%.9g sum0=%.9g ch1max=%.9g\n",
+           c.width_, c.height_, c.params_.r_c1[0], c.params_.r_c1[1], c.params_.r_c1[2], c.params_.r_c2[0],
+           c.params_.r_c2[1], c.params_.r_c2[2], c.params_.trs[0], c.params_.trs[1], c.params_.trs[2],
+           c.track_costs_[0], c.track_costs_[4 * ((size_t)c.width_ * c.height_ - 1)], sum, c.track_costs_[1]);
   }
   printf("host selftest OK (%zu params)\n", p.size());
   return 0;

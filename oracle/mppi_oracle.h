@@ -12,7 +12,8 @@
  * line.  The NN dynamics step (a4+a5) IS pinned: tests/golden/nn_dynamics_golden.npz
  * holds outputs of the reference's own Python restatement
  * (scripts/ml_pipeline/utils.py) and tests/test_oracle_golden.py checks this
- * file against them.  The MRG32k3a recurrence is pinned by L'Ecuyer's published
+ * file against them.  The costmap file format (costs.cu:190-232) is pinned by a file the reference's own
+ * scripts/track_converter.py wrote (tests/golden/costmap_track_converter.npz).  The MRG32k3a recurrence is pinned by L'Ecuyer's published
  * RngStreams jump matrices (A1p76, A2p76, A1p127, A2p127).
  *
  * Paths below are relative to /root/reference/autorally_control/ :

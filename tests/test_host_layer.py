@@ -22,8 +22,9 @@ def bins():
 
 
 def test_host_selftest(bins, golden_dir, tmp_path):
+    cmap = os.path.join(golden_dir, "costmap_track_converter.npz")
     r = subprocess.run([bins["host_selftest"], os.path.join(golden_dir, "models", "autorally_nnet_09_12_2018.npz"),
-                        LAUNCH, str(tmp_path)], capture_output=True, text=True, timeout=60)
+                        LAUNCH, str(tmp_path), cmap], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     assert "host selftest OK" in r.stdout
     # the value the C++ reader printed equals numpy's view of the same file
@@ -33,6 +34,14 @@ def test_host_selftest(bins, golden_dir, tmp_path):
     m = np.load(os.path.join(str(tmp_path), "selftest_map.npz"))
     assert m["channel0"].dtype == np.float32 and m["channel0"].shape == (96,)
     assert m["xBounds"].tolist() == [-3.0, 3.0]
+    # loadTrackData on the file the reference's own track_converter.py wrote (tests/golden/gen_costmap_golden.py)
+    txt = open(os.path.join(golden_dir, "costmap_input.txt")).read().split(" ")
+    vals = np.array(txt[5:-1], dtype=np.float32)
+    line = [l for l in r.stdout.splitlines() if l.startswith("costmap ")][0]
+    assert "W=32 H=18" in line
+    assert "r_c1=[0.125 0 0]" in line and "trs=[0.375 0.444444448 1]" in line  # costs.cu:224-229
+    assert "ch0[0]=%.9g" % vals[0] in line and "ch0[last]=%.9g" % vals[-1] in line
+    assert "sum0=%.9g" % float(np.sum(vals.astype(np.float64))) in line and "ch1max=0" in line
 
 
 def _params_dir(tmp_path, golden_dir, model_file, map_file):

@@ -147,3 +147,40 @@ def test_mrg32k3a_long_run_against_bigint():
         z = (p1 - p2) % m1
         ref[i] = z if z > 0 else m1
     np.testing.assert_array_equal(zs, ref)
+
+
+def test_costmap_file_written_by_reference_track_converter(golden_dir):
+    """tests/golden/costmap_track_converter.npz was written by the reference's own
+    scripts/track_converter.py:gen_costmap (tests/golden/gen_costmap_golden.py): the loader restating
+    MPPICosts::loadTrackData (costs.cu:190-232) must read back the values of the input text, row-major
+    with x fastest, and derive the transform of :224-229."""
+    import os
+    from autorally_amd import params as P
+    txt = open(os.path.join(golden_dir, "costmap_input.txt")).read().split(" ")
+    x0, x1, y0, y1, ppm = [float(v) for v in txt[:5]]
+    vals = np.array(txt[5:-1], dtype=np.float32)
+    m, r_c1, r_c2, trs = P.load_costmap_npz(os.path.join(golden_dir, "costmap_track_converter.npz"))
+    W, H = int((x1 - x0) * ppm), int((y1 - y0) * ppm)
+    assert m.shape == (H, W, 4) and vals.size == W * H
+    np.testing.assert_array_equal(m[:, :, 0].reshape(-1), vals)
+    assert not m[:, :, 1:].any()
+    np.testing.assert_allclose(r_c1, [1.0 / (x1 - x0), 0, 0], rtol=1e-7)
+    np.testing.assert_allclose(r_c2, [0, 1.0 / (y1 - y0), 0], rtol=1e-7)
+    np.testing.assert_allclose(trs, [-x0 / (x1 - x0), -y0 / (y1 - y0), 1], rtol=1e-7)
+    # and the restated texture lookup hits the texel the text file holds at that position
+    from oracle import oracle as O
+    from autorally_amd import synthetic as S
+    cfg = S.make_config(64, 4)
+    cfg = dict(cfg, map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs)
+    orc = O.Oracle(cfg)
+    for (px, py) in [(-2.9, -1.9), (1.0, 0.25), (4.9, 2.4), (0.3, -0.6)]:
+        s = np.array([px, py, 0, 0, 0, 0, 0], np.float32)
+        # only the track term left: cost = (|front texel| + |back texel|) / 2 (costs.cu:359-393)
+        c = dict(cfg["cost"], track_coeff=1.0, speed_coeff=0.0, crash_coeff=0.0, slip_penalty=0.0,
+                 boundary_threshold=1e9, desired_speed=0.0)
+        o2 = O.Oracle(dict(cfg, cost=c))
+        # front/back points are +-0.5 m along the heading: use the mean of the two texels
+        f = vals[min(H - 1, max(0, int((py - y0) * ppm))) * W + min(W - 1, max(0, int((px + 0.5 - x0) * ppm)))]
+        b = vals[min(H - 1, max(0, int((py - y0) * ppm))) * W + min(W - 1, max(0, int((px - 0.5 - x0) * ppm)))]
+        got = o2.compute_cost(s, np.zeros(2, np.float32), np.zeros(2, np.float32))[0]
+        assert abs(got - (abs(f) + abs(b)) / 2) < 1e-6, (px, py, got, f, b)
