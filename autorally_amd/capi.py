@@ -58,7 +58,7 @@ SYMBOLS = [
     "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
     "mppi_compute_control", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
     "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
-    "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
+    "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_debug_cost_raster", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
 ]
@@ -113,6 +113,7 @@ def lib():
         L.mppi_rollout_only.argtypes = [hp, fp, fp]
         L.mppi_nominal_traj.argtypes = [hp, fp, fp, fp]
         L.mppi_set_bf_params.argtypes = [hp, fp, C.c_size_t]
+        L.mppi_debug_cost_raster.argtypes = [hp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, fp, C.c_size_t]
         L.mppi_set_ddp_weights.argtypes = [hp, fp, fp, fp]
         L.mppi_compute_feedback_gains.argtypes = [hp, fp, fp, fp]
         L.mppi_get_feedback_gains.argtypes = [hp, fp, fp, fp, fp, fp]
@@ -332,6 +333,11 @@ class Solver:
         tc = np.zeros(1, dtype=np.float32)
         self._ck(self.L.mppi_get_feedback_gains(self.h, _fp(fb), _fp(ff), _fp(x), _fp(u), _fp(tc)))
         return dict(feedback=fb, feedforward=ff, x=x, u=u, total_cost=float(tc[0]))
+
+    def debug_cost_raster(self, x, y, heading, width_m=10, height_m=10, ppm=50):
+        out = np.zeros((height_m * ppm, width_m * ppm), dtype=np.float32)
+        self._ck(self.L.mppi_debug_cost_raster(self.h, x, y, heading, width_m, height_m, ppm, _fp(out), out.size))
+        return out
 
     def debug_dynamics(self, states, controls):
         states = _f32(states).reshape(-1, 7)

@@ -1212,6 +1212,27 @@ int mppi_get_feedback_gains(mppi_handle *h, float *feedback, float *feedforward,
   return MPPI_OK;
 }
 
+int mppi_debug_cost_raster(mppi_handle *h, float x, float y, float heading, int width_m, int height_m,
+                           int ppm, float *out, size_t n)
+{
+  if (!h || !out || width_m <= 0 || height_m <= 0 || ppm <= 0) return MPPI_ERR_INVALID;
+  const size_t W = (size_t)width_m * ppm, H = (size_t)height_m * ppm;
+  if (W > 8192 || H > 8192 || n != W * H) return fail(h, MPPI_ERR_INVALID, "n != (width_m*ppm) * (height_m*ppm)");
+  if (!h->have_map) return fail(h, MPPI_ERR_STATE, "mppi_set_costmap has not been called");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  float *d = nullptr;
+  HIPCHK(h, hipMalloc(&d, n * sizeof(float)));
+  CostArgs c;
+  fill_cost_args(h, c);
+  hipError_t e = hipMemsetAsync(d, 0, n * sizeof(float), h->stream);
+  if (e == hipSuccess) e = launch_debug_cost(c, x, y, heading, width_m, height_m, ppm, d, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(h, MPPI_ERR_HIP, "mppi_debug_cost_raster", e);
+  return MPPI_OK;
+}
+
 int mppi_enable_stage_timing(mppi_handle *h, int on)
 {
   if (!h) return MPPI_ERR_INVALID;

@@ -39,6 +39,8 @@ hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const
                              float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,
                              int last_iter, unsigned seq, float *slid, int slide_stride, float init0,
                              float init1, hipStream_t stream);
+hipError_t launch_debug_cost(const CostArgs &c, float x, float y, float heading, int width_m, int height_m,
+                             int ppm, float *out, hipStream_t stream);
 hipError_t launch_slide(float *in, int T, int stride, float init0, float init1, hipStream_t stream);
 hipError_t launch_kt_to_tk(const float *src, float *dst, int K, int T, hipStream_t stream);
 hipError_t launch_tk_to_kt(const float *src, float *dst, int K, int T, hipStream_t stream);

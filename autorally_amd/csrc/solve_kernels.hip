@@ -449,6 +449,43 @@ __global__ void tk_to_kt_kernel(const float2 *__restrict__ src, float2 *__restri
   }
 }
 
+// debugCostKernel (PI/debug_kernels.cuh:39-88): raster of the costmap around (x, y) with a car marker,
+// for MPPICosts::getDebugDisplay (costs.cu:272-285; the OpenCV display itself is out of scope).
+__global__ __launch_bounds__(256) void debug_cost_kernel(CostArgs c, float x, float y, float heading, int width_m,
+                                                        int height_m, int ppm, float *__restrict__ out)
+{
+  const int x_idx = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int y_idx = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int W = width_m * ppm, H = height_m * ppm;
+  // int / (1.0*ppm), -= width_m/2.0: single double operations on values exact in fp32 == the fp32 operations
+  float x_pos = (float)x_idx / (float)ppm;
+  float y_pos = (float)y_idx / (float)ppm;
+  x_pos -= (float)width_m * 0.5f;
+  y_pos -= (float)height_m * 0.5f;
+  x_pos += x;
+  y_pos += y;
+  float cost = c.map[c.affine ? texel_index<true>(c, x_pos, y_pos) : texel_index<false>(c, x_pos, y_pos)];
+  if (x_idx < W && (H - y_idx) < H) {  // i.e. y_idx > 0, as in the reference
+    float sh, ch;
+    sincos_fast(heading, sh, ch);
+    const float dx = x_pos - x, dy = y_pos - y;
+    const float xt = fmaf(ch, dx, sh * dy);
+    const float yt = fmaf(-sh, dx, ch * dy);
+    const float dist = (float)(0.25 * (double)fabsf(xt) + (double)fabsf(yt));
+    if ((double)dist < .15 && xt > 0.0f) cost = ((double)dist < .1 && (double)xt > 0.05) ? 1.0f : 0.0f;
+    const int idx = (H - (y_idx + 1)) * W + x_idx;
+    if (idx > 0 && idx < W * H) out[idx] = cost;
+  }
+}
+
+hipError_t launch_debug_cost(const CostArgs &c, float x, float y, float heading, int width_m, int height_m,
+                             int ppm, float *out, hipStream_t stream)
+{
+  const dim3 grid((width_m * ppm - 1) / 16 + 1, (height_m * ppm - 1) / 16 + 1);
+  hipLaunchKernelGGL(debug_cost_kernel, grid, dim3(256), 0, stream, c, x, y, heading, width_m, height_m, ppm, out);
+  return hipGetLastError();
+}
+
 // ---- launchers ----
 hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
                              float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,

@@ -186,6 +186,14 @@ int mppi_compute_feedback_gains(mppi_handle *h, const float state[MPPI_STATE_DIM
 int mppi_get_feedback_gains(mppi_handle *h, float *feedback, float *feedforward, float *state_traj,
                             float *control_traj, float *total_cost);
 
+/* MPPICosts::getDebugDisplay without the OpenCV display (costs.cu:272-285 -> debugCostKernel,
+ * PI/debug_kernels.cuh:39-88): the costmap around (x, y), width_m x height_m metres at ppm pixels per
+ * metre, car marker included; out is [height_m*ppm][width_m*ppm] (n floats), index
+ * (H - (yi + 1)) * W + xi as in the reference.  The reference never writes row yi = 0 and flat index
+ * 0 (they show whatever the buffer held); here they are 0.  debugDisplayInit's default is 10, 10, 50. */
+int mppi_debug_cost_raster(mppi_handle *h, float x, float y, float heading, int width_m, int height_m,
+                           int ppm, float *out, size_t n);
+
 /* Measurement hooks.  on = 1: HIP events around every stage of every solve; on = N > 1: only on
  * every Nth solve (event packets between kernels lengthen the launch gaps, so sampling keeps the
  * measured run close to the unmeasured one); on = 0: off. */

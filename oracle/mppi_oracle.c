@@ -223,6 +223,37 @@ static inline float texel_x(const orc_problem *p, float x, float y)
   return p->map_rgba[4 * ((size_t)j * (size_t)p->map_w + (size_t)i)];
 }
 
+/* debugCostKernel + launchDebugCostKernel, PI/debug_kernels.cuh:39-88 (MPPICosts::getDebugDisplay,
+ * costs.cu:272-285): raster of the costmap around (x, y), width_m x height_m metres at ppm pixels per
+ * metre, with a car marker.  out[(H - (yi + 1)) * W + xi]; pixels the kernel never writes (row yi = 0,
+ * and flat index 0) keep the value the caller put there. */
+void orc_debug_cost_raster(const orc_problem *p, float x, float y, float heading, int width_m,
+                           int height_m, int ppm, float *out)
+{
+  const int W = width_m * ppm, H = height_m * ppm;
+  for (int y_idx = 0; y_idx < H; y_idx++)
+    for (int x_idx = 0; x_idx < W; x_idx++) {
+      float x_pos = x_idx / (1.0 * ppm);
+      float y_pos = y_idx / (1.0 * ppm);
+      x_pos -= width_m / 2.0;
+      y_pos -= height_m / 2.0;
+      x_pos += x;
+      y_pos += y;
+      float cost = texel_x(p, x_pos, y_pos);
+      if (x_idx < width_m * ppm && (height_m * ppm - y_idx) < height_m * ppm) {
+        const float x_transformed = cosf(heading) * (x_pos - x) + sinf(heading) * (y_pos - y);
+        const float y_transformed = -sinf(heading) * (x_pos - x) + cosf(heading) * (y_pos - y);
+        const float dist = 0.25 * fabsf(x_transformed) + fabsf(y_transformed);
+        if (dist < .15 && x_transformed > 0) {
+          if (dist < .1 && x_transformed > 0.05) cost = 1;
+          else cost = 0;
+        }
+        const int idx = (height_m * ppm - (y_idx + 1)) * (width_m * ppm) + x_idx;
+        if ((idx > 0) && (idx < (width_m * ppm) * (height_m * ppm))) out[idx] = cost;
+      }
+    }
+}
+
 /* costs.cu:396-409 and the helpers it calls (:307-393) */
 float orc_compute_cost(const orc_problem *p, const float *s, const float *u, const float *du,
                        int *crash)

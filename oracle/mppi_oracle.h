@@ -98,6 +98,10 @@ void orc_update_state(const orc_problem *p, float *s, float *u);
 float orc_compute_cost(const orc_problem *p, const float *s, const float *u,
                        const float *du, int *crash);
 
+/* debugCostKernel, PI/debug_kernels.cuh:39-88: out[height_m*ppm][width_m*ppm], see mppi_oracle.c */
+void orc_debug_cost_raster(const orc_problem *p, float x, float y, float heading, int width_m,
+                           int height_m, int ppm, float *out);
+
 /* rolloutKernel, mppi_controller.cu:72-184.
  * epsV: [K][T][2]; in = N(0,1) noise, out = applied (unclamped) controls (Q3).
  * costs[K]; crash_out[K] optional (final sticky crash flag). */

@@ -99,6 +99,7 @@ def lib():
         L.orc_update_state.argtypes = [pp, fp, fp]
         L.orc_compute_cost.restype = C.c_float
         L.orc_compute_cost.argtypes = [pp, fp, fp, fp, ip]
+        L.orc_debug_cost_raster.argtypes = [pp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, fp]
         L.orc_rollouts.argtypes = [pp, fp, fp, fp, fp, ip]
         L.orc_weights.argtypes = [fp, C.c_int, C.c_float, fp, fp, fp, fp]
         L.orc_weighted_reduction.argtypes = [fp, C.c_float, fp, C.c_int, C.c_int, fp, C.c_int]
@@ -208,6 +209,12 @@ class Oracle:
         cr = C.c_int(crash)
         c = self.L.orc_compute_cost(C.byref(self.p), _fp(s), _fp(u), _fp(du), C.byref(cr))
         return float(c), cr.value
+
+    def debug_cost_raster(self, x, y, heading, width_m=10, height_m=10, ppm=50):
+        """debugCostKernel (debug_kernels.cuh:39-88): [height_m*ppm, width_m*ppm] f32, unwritten pixels 0."""
+        out = np.zeros((height_m * ppm, width_m * ppm), dtype=np.float32)
+        self.L.orc_debug_cost_raster(C.byref(self.p), x, y, heading, width_m, height_m, ppm, _fp(out))
+        return out
 
     def rollouts(self, state, U, eps):
         """Returns (costs[K], V[K,T,2], crash[K]); eps is not modified."""

@@ -220,3 +220,22 @@ def test_baseline_config4_full_size_properties():
     assert np.max(np.abs(Us - a["U"])) < 5e-5
     assert abs(float((w.astype(np.float64) ** 2).sum() / eta) - a["traj_cost"]) < 1e-4 * a["traj_cost"]
     assert a["V"][..., 0].min() <= a["U"][:, 0].min() and a["U"][:, 0].max() <= a["V"][..., 0].max()
+
+
+def test_debug_cost_raster_matches_oracle():
+    """MPPICosts::getDebugDisplay's raster (debug_kernels.cuh:39-88): costmap window around the car with
+    the car marker; pixels on a texel edge or on the marker's outline may flip on a last-digit difference."""
+    cfg = S.make_config(64, 4, track="oval")
+    sol = capi.Solver(cfg)
+    orc = O.Oracle(cfg)
+    for (x, y, hd, wm, hm, ppm) in [(0.0, -10.0, 0.3, 10, 10, 50), (3.0, -9.0, 2.5, 6, 4, 20), (-30.0, 40.0, -1.0, 3, 5, 7)]:
+        got = sol.debug_cost_raster(x, y, hd, wm, hm, ppm)
+        ref = orc.debug_cost_raster(x, y, hd, wm, hm, ppm)
+        assert got.shape == (hm * ppm, wm * ppm)
+        assert int(np.sum(got != ref)) <= max(2, got.size // 500), int(np.sum(got != ref))
+        assert np.all(got[-1, :] == 0.0) and got[0, 0] == 0.0  # row yi = 0 and flat index 0 are never written
+        if (x, y) == (0.0, -10.0):
+            assert np.any(got == 1.0) and got.min() == 0.0  # the car marker is inside the window
+    with pytest.raises(capi.MppiError):
+        sol._ck(sol.L.mppi_debug_cost_raster(sol.h, 0.0, 0.0, 0.0, 10, 10, 50, capi._fp(np.zeros(4, np.float32)), 4))
+    sol.close()
