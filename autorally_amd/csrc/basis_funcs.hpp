@@ -36,6 +36,13 @@ MPPI_HD float div_const(float x, float c, float rc)
   return fmaf(r, rc, q0);
 }
 #define MPPI_DIVC(x, c) div_const((x), (c), 1.0f / (c))
+// the same in double, for the two quotients whose numerator is a genuine double (checked on 100 M operands)
+MPPI_HD double div_const_d(double x, double c, double rc)
+{
+  const double q0 = x * rc;
+  const double r = fma(-q0, c, x);
+  return fma(r, rc, q0);
+}
 
 // The sub-expressions every basis function shares.
 struct BasisShared {
@@ -86,8 +93,8 @@ MPPI_HD void basis_funcs_from(const float *s, float u1, const BasisShared &c, fl
   phi[10] = MPPI_DIVC(A, 1400.0f);
   phi[11] = MPPI_DIVC(A * fabsf(A), 1960000.0f);
   phi[12] = MPPI_DIVC(A3, 2744000000.0f);
-  phi[13] = big ? (float)(B / 40.0) : 0.0f;
-  phi[14] = big ? (float)(B * fabs(B) / 1600.0) : 0.0f;
+  phi[13] = big ? (float)div_const_d(B, 40.0, 1.0 / 40.0) : 0.0f;
+  phi[14] = big ? (float)div_const_d(B * fabs(B), 1600.0, 1.0 / 1600.0) : 0.0f;
   const float Bf = (float)B;
   phi[15] = big ? MPPI_DIVC((Bf * Bf) * Bf, 64000.0f) : 0.0f;
   phi[16] = MPPI_DIVC(s6 * s4, 50.0f);

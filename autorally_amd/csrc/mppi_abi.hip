@@ -234,6 +234,14 @@ int effective_block(const mppi_handle *h)
   return (4 * groups <= budget) ? 512 : 64;
 }
 
+// basis-function model: dynamics wave + cost wave per 64 rollouts ("fused" / "block64" force the one-wave form)
+bool bf_two_waves(const mppi_handle *h)
+{
+  if (h->block_threads == 64) return false;
+  if (h->block_threads == 512) return true;
+  return 2 * (h->K / 64) <= 2 * h->num_simds;
+}
+
 // the quad MFMA kernel carries its own control/noise wavefront
 bool has_noise_wave(const mppi_handle *h)
 {
@@ -297,7 +305,8 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
 
 int launch_rollout(mppi_handle *h, const RolloutArgs &a)
 {
-  hipError_t e = h->basis ? launch_rollout_bf(a, h->stream)
+  // basis-function model: the two-wave form while both waves of a group get a SIMD of their own
+  hipError_t e = h->basis ? launch_rollout_bf(a, bf_two_waves(h), h->stream)
                  : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
                                    : launch_rollout_valu(h->net, a, h->stream);
@@ -1263,7 +1272,7 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out)
 const char *mppi_rollout_variant(const mppi_handle *h)
 {
   if (!h) return "";
-  if (h->basis) return "basis_funcs25_valu";
+  if (h->basis) return bf_two_waves(h) ? "basis_funcs25_valu_2w" : "basis_funcs25_valu";
   if (!use_mfma(h)) return use_valu_reg(h) ? "valu_reg_lds" : "valu_lds";
   static thread_local char buf[64];
   const int b = effective_block(h);

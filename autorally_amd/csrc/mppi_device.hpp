@@ -95,6 +95,7 @@ __device__ __forceinline__ float tanh_bias(float z, float bs)
 // one issue slot for two values); exp2 and rcp stay scalar (quarter-rate unit).  Same arithmetic per
 // element as tanh_bias.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x2 tanh_bias2(f32x2 z, f32x2 bs)
 {
   const f32x2 y = __builtin_elementwise_fma(z, f32x2{kTanhScale, kTanhScale}, bs);
@@ -227,4 +228,32 @@ __device__ __forceinline__ float running_mean(float J, float c, int t, double rt
   return (float)((double)J + q);
 }
 
+// ---- hand-over between the wavefronts of a workgroup through LDS sequence words ----
+// Every spin loop draws on a per-wave budget; when it is exhausted the wave stops waiting and the costs
+// are poisoned with NaN (a loud failure instead of a hung GPU).
+constexpr int kSpinBudget = 1 << 22;
+
+// The hand-over instructions are written as ds_* assembly: they must reach the LDS in exactly this
+// order (data, then sequence word / sequence word, then data) and must not carry the waits the
+// compiler attaches to volatile accesses.  "memory" clobbers keep the ordinary LDS accesses
+// (records) on their side of a hand-over.
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ void lds_publish(uint32_t addr, int v)
+{
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_put4(uint32_t addr, f32x4 v)
+{
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// one word, wave-uniform
+__device__ __forceinline__ int lds_peek(uint32_t addr)
+{
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
 }  // namespace mppi

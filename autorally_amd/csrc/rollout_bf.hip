@@ -102,6 +102,135 @@ __global__ __launch_bounds__(kBfLanes) void rollout_bf_kernel(const RolloutArgs 
   a.costs[k] = J + 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// rollout_bf2_kernel: the same rollout with the work of 64 rollouts split over TWO wavefronts of one
+// workgroup, as in the quad form of the network kernel (rollout_mfma.hip): the T-step recurrence of a
+// rollout is latency bound (K = 2560 gives 40 wavefronts for 1024 SIMDs), so everything that does not
+// feed the next state leaves the wavefront that computes it.
+//   wave 0 "dynamics": controls + clamp + the 25 basis functions + W phi + Euler update of
+//          [roll, u_x, u_y, yaw_mder] (the basis functions do not read x, y, yaw);
+//   wave 1 "cost":     x, y, yaw kinematics, sin/cos, the costmap fetches, MPPICosts::computeCost, the
+//          running mean and the crash flags, software-pipelined by one step around the fetches, fed by
+//          a ring of per-step records (s3..s6 before the update, clamped u, du).
+// One-directional hand-over through LDS sequence words (mppi_device.hpp), kBfRing steps deep.
+// Arithmetic and its order are those of rollout_bf_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBfRing = 16;  // power of two
+
+__global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const RolloutArgs a)
+{
+  __shared__ float W_s[4 * kNumBfs];
+  __shared__ float rec[kBfRing][8][kBfLanes];  // [slot][field][lane]: s3 s4 s5 s6 u0 u1 du0 du1
+  __shared__ int pub[kBfLanes], done[kBfLanes];
+  const int lane = threadIdx.x & 63;
+  const int role = threadIdx.x >> 6;  // wave-uniform
+  for (int i = threadIdx.x; i < 4 * kNumBfs; i += 2 * kBfLanes) W_s[i] = a.wpack[i];
+  if (role == 0) { pub[lane] = 0; done[lane] = 0; }
+  __syncthreads();  // the only barrier
+  const int k = blockIdx.x * kBfLanes + lane;
+  const int K = a.K, T = a.T;
+  const uint32_t a_pub = lds_addr(&pub[0]), a_done = lds_addr(&done[0]);
+  int budget = kSpinBudget;
+
+  if (role == 0) {
+    // ------------------------------ dynamics wave ------------------------------
+    const uint32_t a_mypub = lds_addr(&pub[lane]);
+    float s[kStateDim];
+#pragma unroll
+    for (int i = 0; i < kStateDim; i++) s[i] = a.state[i];
+    float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+    const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+    const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
+    const bool pure_noise_k = (k >= a.k99);  // :141
+    float2 e_next = noise[(size_t)k];
+    float2 U_next = Useq[0];
+    int seen = 0;  // steps the cost wave has consumed
+    for (int t = 0; t < T; t++) {
+      const float2 e = e_next, Ut = U_next;
+      const int tn = min(t + 1, T - 1);
+      e_next = noise[(size_t)tn * K + k];
+      U_next = Useq[tn];
+      float du0, du1, u0, u1;
+      if (noise_free_k || t < a.opt_delay) {
+        du0 = 0.0f; du1 = 0.0f; u0 = Ut.x; u1 = Ut.y;
+      } else {
+        du0 = e.x * a.nu[0];
+        du1 = e.y * a.nu[1];
+        u0 = pure_noise_k ? du0 : Ut.x + du0;
+        u1 = pure_noise_k ? du1 : Ut.y + du1;
+      }
+      noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+      u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+      u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+      while (seen < t - kBfRing + 1 && --budget > 0) seen = lds_peek(a_done);
+      const int slot = t & (kBfRing - 1);
+      rec[slot][0][lane] = s[3]; rec[slot][1][lane] = s[4]; rec[slot][2][lane] = s[5]; rec[slot][3][lane] = s[6];
+      rec[slot][4][lane] = u0;   rec[slot][5][lane] = u1;   rec[slot][6][lane] = du0;  rec[slot][7][lane] = du1;
+      lds_publish(a_mypub, t + 1);
+      float phi[kNumBfs], d[4];
+      BasisShared c;
+      basis_shared_fast(s, u0, c);
+      basis_funcs_from(s, u1, c, phi);
+      basis_dynamics(W_s, phi, d);
+#pragma unroll
+      for (int i = 0; i < 4; i++) s[3 + i] = fmaf(d[i], a.dt, s[3 + i]);
+    }
+  } else {
+    // -------------------------------- cost wave --------------------------------
+    const uint32_t a_mydone = lds_addr(&done[lane]);
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int crash = 0, seen = 0;
+    float J = 0.0f;
+    float tf_p = 0.0f, tb_p = 0.0f;
+    CostTerms ct_p{0.0f, 0.0f, 0.0f};
+    int rc_p = 0;
+    double rt_p = 0.0;
+    for (int t = 0; t <= T; t++) {
+      float tf = 0.0f, tb = 0.0f;
+      CostTerms ct{0.0f, 0.0f, 0.0f};
+      int rc = 0;
+      double rt = 0.0;
+      if (t < T) {
+        rt = a.inv_t[t];
+        while (seen < t + 1 && --budget > 0) {
+          seen = lds_peek(a_pub);
+          if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        const int slot = t & (kBfRing - 1);
+        const float r3 = rec[slot][0][lane], r4 = rec[slot][1][lane], r5 = rec[slot][2][lane], r6 = rec[slot][3][lane];
+        const float u0 = rec[slot][4][lane], u1 = rec[slot][5][lane], du0 = rec[slot][6][lane], du1 = rec[slot][7][lane];
+        lds_publish(a_mydone, t + 1);  // executes after the reads (the LDS runs a wave's instructions in order)
+        rc = (int)((t > 0) & (fabsf(r3) >= kRollCrash));  // getCrash of update t-1
+        float spsi, cpsi;
+        sincos_fast(yaw, spsi, cpsi);
+        const float st[3] = {x, y, yaw};
+        if (t > 0) {
+          if (a.cost.affine) track_fetch<true>(a.cost, st, cpsi, spsi, tf, tb);
+          else track_fetch<false>(a.cost, st, cpsi, spsi, tf, tb);
+        }
+        if (a.cost.need_control_cost) cost_terms_a<true>(a.cost, a.nu, r4, r5, u0, u1, du0, du1, ct);
+        else cost_terms_a<false>(a.cost, a.nu, r4, r5, u0, u1, du0, du1, ct);
+        // computeKinematics (generalized_linear.cu:212-217, yaw rate always negated) + incrementState
+        const float sd0 = fmaf(cpsi, r4, -(spsi * r5));
+        const float sd1 = fmaf(spsi, r4, cpsi * r5);
+        x = fmaf(sd0, a.dt, x);
+        y = fmaf(sd1, a.dt, y);
+        yaw = fmaf(-r6, a.dt, yaw);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 1) {  // finish step t-1: running mean over 1..T-1 (Q5); step 0 is never costed
+        const int tp = t - 1;
+        crash |= rc_p;
+        const float c = cost_terms_b(a.cost, ct_p, tf_p, tb_p, crash);
+        J = running_mean(J, c, tp, rt_p);
+      }
+      tf_p = tf; tb_p = tb; ct_p = ct; rc_p = rc; rt_p = rt;
+    }
+    if (budget <= 0) J = __builtin_nanf("");  // a hand-over never arrived: poison, do not hang
+    a.costs[k] = J + 0.0f;
+  }
+}
+
 // test entry (mppi_debug_dynamics): state derivative of n independent (state, control) pairs
 __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, const float *states,
                                                                const float *controls, float *ders, int n)
@@ -123,9 +252,10 @@ __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, c
   for (int i = 0; i < kStateDim; i++) ders[idx * kStateDim + i] = sd[i];
 }
 
-hipError_t launch_rollout_bf(const RolloutArgs &a, hipStream_t stream)
+hipError_t launch_rollout_bf(const RolloutArgs &a, bool two_waves, hipStream_t stream)
 {
-  hipLaunchKernelGGL(rollout_bf_kernel, dim3(a.K / kBfLanes), dim3(kBfLanes), 0, stream, a);
+  if (two_waves) hipLaunchKernelGGL(rollout_bf2_kernel, dim3(a.K / kBfLanes), dim3(2 * kBfLanes), 0, stream, a);
+  else hipLaunchKernelGGL(rollout_bf_kernel, dim3(a.K / kBfLanes), dim3(kBfLanes), 0, stream, a);
   return hipGetLastError();
 }
 

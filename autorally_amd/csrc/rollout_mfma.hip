@@ -20,7 +20,6 @@
 
 namespace mppi {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int H, int NHID>
 struct MfmaNet {
@@ -273,31 +272,7 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 16;  // steps in flight between the waves (power of two)
 constexpr int kCtlChunk = 4;  // steps of U / explicit eps the control wave requests at once
-constexpr int kSpinBudget = 1 << 22;
 
-// The hand-over instructions are written as ds_* assembly: they must reach the LDS in exactly this
-// order (data, then sequence word / sequence word, then data) and must not carry the waits the
-// compiler attaches to volatile accesses.  "memory" clobbers keep the ordinary LDS accesses
-// (records) on their side of a hand-over.
-__device__ __forceinline__ uint32_t lds_addr(const void *p)
-{
-  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
-}
-__device__ __forceinline__ void lds_publish(uint32_t addr, int v)
-{
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_put4(uint32_t addr, f32x4 v)
-{
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-// one word, wave-uniform
-__device__ __forceinline__ int lds_peek(uint32_t addr)
-{
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-  return __builtin_amdgcn_readfirstlane(v);
-}
 // partner's sequence word, then its data; the control wave's publication count, then the lane's
 // layer-0 operand of the next step; the cost wave's consumption count
 template <int M2>

@@ -87,7 +87,6 @@ __device__ __forceinline__ float block_sum(float v, float *red, float *bc)
 // (one PCIe write; if it were split, the halves stay in order).
 __device__ __forceinline__ void publish_entry(float *res, int entry, float v0, float v1, float v2, unsigned seq)
 {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const f32x4 v = {v0, v1, v2, __uint_as_float(seq)};
   float *p = res + 4 * (size_t)entry;
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");

@@ -86,7 +86,7 @@ def test_gpu_basis_dynamics_match_oracle(golden_dir):
     cfg = _bf_cfg(golden_dir)
     orc = O.Oracle(cfg)
     sol = capi.Solver(cfg)
-    assert sol.rollout_variant() == "basis_funcs25_valu"
+    assert sol.rollout_variant() == "basis_funcs25_valu_2w"
     s, u = _samples(512, seed=3)
     got = sol.debug_dynamics(s, u)
     ref = np.stack([orc.state_deriv(s[i], u[i]) for i in range(s.shape[0])])
@@ -130,6 +130,16 @@ def test_gpu_basis_solve_matches_oracle(golden_dir, K, T, track):
     r = orc.ddp_feedback_gains(x0, rs, rc)
     scale = np.abs(r["feedback"]).max()
     assert scale > 1e-3 and np.max(np.abs(g["feedback"] - r["feedback"])) <= 2e-2 * scale
+    # the one-wave form of the kernel does the same arithmetic in the same order
+    sol.set_rollout_variant("fused")
+    assert sol.rollout_variant() == "basis_funcs25_valu"
+    sol.set_control_seq(U0)
+    sol.set_noise(eps)
+    sol.compute_control(cfg["start_state"])
+    one = sol.get_results()
+    np.testing.assert_array_equal(one["costs"].view(np.uint32), got["costs"].view(np.uint32))
+    np.testing.assert_array_equal(one["U"].view(np.uint32), got["U"].view(np.uint32))
+    sol.set_rollout_variant("auto")
     # generator mode runs too and is deterministic
     sol.seed(5, 0)
     sol.set_control_seq(U0)
