@@ -100,12 +100,12 @@ struct mppi_handle {
   float u_lo[2] = {0, 0}, u_hi[2] = {0, 0};
   bool have_nn = false, have_map = false, have_cost = false;
 
-  float *d_in = nullptr, *d_res = nullptr, *d_scal = nullptr;
+  float *d_in = nullptr, *d_scal = nullptr;
   float *d_in_buf[2] = {nullptr, nullptr};  // d_in points at one of them; the tail kernel leaves the
   int in_cur = 0;                            // stride-slid copy of [U | hist] in the other one
   bool slid_valid = false;
   float *d_noise = nullptr, *d_stage = nullptr;
-  float *d_costs = nullptr, *d_w = nullptr, *d_wn = nullptr;
+  float *d_costs = nullptr, *d_w = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
   float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
   bool valu_reg_ok = false;
@@ -540,8 +540,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
 void free_all(mppi_handle *h)
 {
   if (!h) return;
-  float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_res, h->d_scal, h->d_noise, h->d_stage, h->d_costs,
-                 h->d_w,  h->d_wn,  h->d_theta, h->d_wpack, h->d_map, h->d_part};
+  float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_scal, h->d_noise, h->d_stage, h->d_costs,
+                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
@@ -670,7 +670,6 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_in_buf[0], sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_in_buf[1], sizeof(float) * (2 * (size_t)h->T + 4)));
   h->d_in = h->d_in_buf[0];
-  CR(hipMalloc(&h->d_res, sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_scal, sizeof(float) * 4));
   CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)h->n_slots));
   CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
@@ -679,7 +678,6 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_stage, sizeof(float) * KT2));
   CR(hipMalloc(&h->d_costs, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_w, sizeof(float) * h->K));
-  CR(hipMalloc(&h->d_wn, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_theta, sizeof(float) * h->net.num_params));
   CR(hipMalloc(&h->d_theta_s, sizeof(float) * h->net.num_params));
   if (h->mfma_ok)
@@ -704,7 +702,6 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     CR(hipMemcpy(h->d_invt, invt.data(), sizeof(double) * (size_t)h->T, hipMemcpyHostToDevice));
   }
   CR(hipMemset(h->d_scal, 0, sizeof(float) * 4));
-  CR(hipMemset(h->d_res, 0, sizeof(float) * (2 * (size_t)h->T + 4)));
   h->ev.resize(cfg->num_iters);
   for (auto &s : h->ev)
     for (auto &e : s.e) CR(hipEventCreate(&e));
