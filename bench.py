@@ -122,9 +122,21 @@ def cpu_baseline(cfg, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 400:
             break
-    return {"value": K * n / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
-            "sample": "%d full solves (rollout+weights+reduction+SG on pre-generated noise) of K=%d T=%d in %.1f s"
-                      % (n, K, T, el)}
+    out = {"value": K * n / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
+           "sample": "%d full solves (rollout+weights+reduction+SG on pre-generated noise) of K=%d T=%d in %.1f s"
+                     % (n, K, T, el)}
+    # the same solve on ONE core (SURVEY 8d asks for both), a few solves only
+    orc1 = O.Oracle(cfg, fma_mode=1, nthreads=1)
+    n1, t1 = 0, time.perf_counter()
+    while True:
+        orc1.compute_control(cfg["start_state"], U, hist, eps)
+        n1 += 1
+        el1 = time.perf_counter() - t1
+        if el1 >= 4.0 or n1 >= 50:
+            break
+    out["single_thread"] = {"value": K * n1 / el1, "unit": "rollouts/s", "cores": 1,
+                            "sample": "%d full solves in %.1f s" % (n1, el1)}
+    return out
 
 
 class _OracleStandIn:
