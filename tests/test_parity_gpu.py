@@ -326,3 +326,42 @@ def test_quad_kernel_loops_are_reproducible(K, T, layers):
             np.testing.assert_array_equal(us[0].view(np.uint32), u.view(np.uint32))
     for s in sols:
         s.close()
+
+
+@pytest.mark.parametrize("variant", ["quad", "fused", "valu"])
+def test_projective_costmap_transform(variant):
+    """updateTransform (costs.cu:175-188) accepts a full homography: w = r_c1.z x + r_c2.z y + trs.z != 1
+    takes the kernels' u/w, v/w path (the shipped maps are affine and skip the two divides)."""
+    cfg = S.make_config(256, 40, track="oval")
+    r_c1 = np.array(cfg["r_c1"], np.float32)
+    r_c2 = np.array(cfg["r_c2"], np.float32)
+    trs = np.array(cfg["trs"], np.float32)
+    r_c1[2], r_c2[2], trs[2] = 0.004, -0.003, 1.1
+    cfg = dict(cfg, r_c1=r_c1, r_c2=r_c2, trs=trs)
+    ref, got = _solve_both(cfg, U0=warm_U(cfg), variant=variant)
+    plain, _ = _solve_both(dict(cfg, r_c1=S.make_config(256, 40, track="oval")["r_c1"],
+                                r_c2=S.make_config(256, 40, track="oval")["r_c2"],
+                                trs=S.make_config(256, 40, track="oval")["trs"]), U0=warm_U(cfg), variant=variant)
+    assert np.max(np.abs(ref["costs"] - plain["costs"])) > 1.0  # the homography really changes the lookups
+    np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
+    err = rel_err(got["costs"], ref["costs"])
+    assert int(np.sum(err > 1e-4)) <= 3 and float(np.percentile(err, 95)) < 1e-5
+    assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
+
+
+@pytest.mark.parametrize("name,negate", [("shallow_network_08_20_2020", False), ("wider_deeper_network_08_20_2020", False),
+                                         ("gazebo_nnet_09_12_2018", True)])
+def test_solve_with_the_other_shipped_models(golden_dir, name, negate):
+    """Whole solves with the other weight files of params/models (6-32-32-4 with negate_yaw_der = false,
+    the four-hidden-layer 6-64-64-64-64-4 net, the gazebo net): MFMA forms against the oracle and each other."""
+    layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", name + ".npz"))
+    cfg = S.make_config(256, 40, layers=layers, theta=theta, track="oval", negate_yaw_der=negate)
+    U0 = np.tile(np.array([0.0, 0.25], np.float32), (40, 1))
+    ref, q = _solve_both(cfg, U0=U0, variant="quad")
+    _, f = _solve_both(cfg, U0=U0, variant="fused")
+    assert "quad" in q["variant"] and "fused" in f["variant"]
+    np.testing.assert_array_equal(q["costs"].view(np.uint32), f["costs"].view(np.uint32))
+    np.testing.assert_array_equal(q["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
+    err = rel_err(q["costs"], ref["costs"])
+    assert int(np.sum(err > 1e-4)) <= 3 and float(np.percentile(err, 95)) < 1e-5
+    assert np.max(np.abs(q["U"] - ref["U"])) <= 1e-4
