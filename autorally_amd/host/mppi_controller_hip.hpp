@@ -216,12 +216,22 @@ class GeneralizedLinear {
     float lo[2] = {control_rngs_[0].x, control_rngs_[1].x}, hi[2] = {control_rngs_[0].y, control_rngs_[1].y};
     NeuralNetModel::check(mppi_set_control_limits(h, lo, hi), h);
   }
+  // updateModel(description, data): empty in the reference too (generalized_linear.cuh:88)
+  void updateModel(const std::vector<int> &, const std::vector<float> &) {}
   unsigned version_ = 0;
   void touch() { version_++; }
 
  private:
   float dt_;
   std::vector<float> theta_;
+};
+
+// The dynamic_reconfigure message of the reference (cfg/PathIntegralParams.cfg:12-21, its defaults):
+// what AutorallyPlant::getDynRcfgParams hands to MPPICosts::updateParams_dcfg.
+struct PathIntegralParamsConfig {
+  double max_throttle = 0.65, desired_speed = 6.0, speed_coefficient = 4.25, track_coefficient = 200.0,
+         max_slip_angle = 1.25, slip_penalty = 10.0, crash_coefficient = 10000.0, track_slop = 0.0,
+         steering_coeff = 0.0, throttle_coeff = 0.0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -296,6 +306,30 @@ class MPPICosts {
     params_.r_c1[0] = 1.f / (x_max - x_min); params_.r_c1[1] = 0; params_.r_c1[2] = 0;
     params_.r_c2[0] = 0; params_.r_c2[1] = 1.f / (y_max - y_min); params_.r_c2[2] = 0;
     params_.trs[0] = -x_min / (x_max - x_min); params_.trs[1] = -y_min / (y_max - y_min); params_.trs[2] = 1;
+    map_version_++;
+  }
+
+  // updateParams_dcfg, costs.cu:75-87: nine cost parameters (not boundary_threshold / discount / l1_cost)
+  void updateParams_dcfg(const PathIntegralParamsConfig &config)
+  {
+    params_.desired_speed = (float)config.desired_speed;
+    params_.speed_coeff = (float)config.speed_coefficient;
+    params_.track_coeff = (float)config.track_coefficient;
+    params_.max_slip_ang = (float)config.max_slip_angle;
+    params_.slip_penalty = (float)config.slip_penalty;
+    params_.crash_coeff = (float)config.crash_coefficient;
+    params_.track_slop = (float)config.track_slop;
+    params_.steering_coeff = (float)config.steering_coeff;
+    params_.throttle_coeff = (float)config.throttle_coeff;
+    version_++;
+  }
+  // updateTransform(m, trs), costs.cu:175-188: m is the 3x3 homography, row-major here; its first two
+  // columns and trs are what coorTransform uses
+  void updateTransform(const float m[9], const float trs[3])
+  {
+    params_.r_c1[0] = m[0]; params_.r_c1[1] = m[3]; params_.r_c1[2] = m[6];
+    params_.r_c2[0] = m[1]; params_.r_c2[1] = m[4]; params_.r_c2[2] = m[7];
+    for (int i = 0; i < 3; i++) params_.trs[i] = trs[i];
     map_version_++;
   }
 
@@ -459,6 +493,15 @@ class MPPIControllerT {
   void computeNominalTraj(const float *state)  // :501-519
   {
     ck(mppi_nominal_traj(h_, state, state_solution_.data(), control_solution_.data()));
+  }
+  // costs_->getDebugDisplay(x, y, heading) (costs.cu:272-285) without the cv::Mat: the raster of
+  // debugCostKernel, [height_m*ppm][width_m*ppm]; debugDisplayInit's default window is 10 m x 10 m at 50 px/m
+  std::vector<float> getDebugDisplay(float x, float y, float heading, int width_m = 10, int height_m = 10, int ppm = 50)
+  {
+    syncParams(false);
+    std::vector<float> img((size_t)width_m * ppm * height_m * ppm);
+    ck(mppi_debug_cost_raster(h_, x, y, heading, width_m, height_m, ppm, img.data(), img.size()));
+    return img;
   }
   std::vector<float> getControlSeq() { return control_solution_; }
   std::vector<float> getStateSeq() { return state_solution_; }

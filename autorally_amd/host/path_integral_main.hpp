@@ -45,6 +45,8 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
   int max_iter = -1, device = 0;
   bool sleep_to_rate = true;
   const char *trace_path = nullptr;
+  bool have_dcfg = false, debug_image = false;  // stand-ins for the plant's dynamic_reconfigure / debug window
+  double dcfg_speed = 0.0;
   std::vector<std::string> overrides;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--rollouts") && i + 1 < argc) rollouts = atoi(argv[++i]);
@@ -54,6 +56,8 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     else if (!strcmp(argv[i], "--trace") && i + 1 < argc) trace_path = argv[++i];
     else if (!strcmp(argv[i], "--set") && i + 1 < argc) overrides.push_back(argv[++i]);
     else if (!strcmp(argv[i], "--no-sleep")) sleep_to_rate = false;
+    else if (!strcmp(argv[i], "--dcfg-desired-speed") && i + 1 < argc) { dcfg_speed = atof(argv[++i]); have_dcfg = true; }
+    else if (!strcmp(argv[i], "--debug-image")) debug_image = true;
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
@@ -87,6 +91,11 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     MPPIControllerT<DYNAMICS_T> actual(&model, &costs, exploration_std, init_u, hz, T, stride, gamma, num_iters, rollouts, device);
     MPPIControllerT<DYNAMICS_T> predicted(&model, &costs, exploration_std, init_u, hz, T, stride, gamma, num_iters, rollouts, device);
     SimPlant robot;
+    if (have_dcfg) {  // one dynamic_reconfigure message waiting at the first tick (cfg defaults + the given speed)
+      robot.new_dcfg = true;
+      robot.dcfg.desired_speed = dcfg_speed;
+    }
+    robot.want_debug_image = debug_image;
     std::atomic<bool> is_alive(true);
     FILE *trace = trace_path ? fopen(trace_path, "w") : nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -97,12 +106,15 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     double g0 = 0.0, g1 = 0.0;
     if (robot.last_feedback_gains.size() >= 14)
       for (int i = 0; i < 7; i++) { g0 += robot.last_feedback_gains[i]; g1 += robot.last_feedback_gains[7 + i]; }
+    double img_sum = 0.0;
+    for (float v : robot.debug_image) img_sum += v;
     printf("{\"iterations\": %d, \"rollouts\": %d, \"timesteps\": %d, \"avg_tick_ms\": %.4f, \"avg_sleep_ms\": %.4f, "
            "\"wall_s\": %.4f, \"actual_state_used\": %d, \"final_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f], "
-           "\"feedback_gain_row_sums_t0\": [%.6f, %.6f]}\n",
+           "\"feedback_gain_row_sums_t0\": [%.6f, %.6f], \"desired_speed\": %.4f, \"debug_image_pixels\": %zu, "
+           "\"debug_image_sum\": %.4f}\n",
            st.iterations, actual.NUM_ROLLOUTS, T, st.avg_tick_ms, st.avg_sleep_ms, wall, robot.n_actual,
            st.final_state[0], st.final_state[1], st.final_state[2], st.final_state[3], st.final_state[4],
-           st.final_state[5], st.final_state[6], g0, g1);
+           st.final_state[5], st.final_state[6], g0, g1, costs.params_.desired_speed, robot.debug_image.size(), img_sum);
   } catch (const std::exception &e) {
     fprintf(stderr, "path_integral_nn: %s\n", e.what());
     return 1;

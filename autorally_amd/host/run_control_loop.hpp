@@ -42,6 +42,22 @@ struct SimPlant {
     if (used == ControllerType::ACTUAL_STATE) n_actual++;
   }
   int checkStatus() const { return 1; }  // no pose estimate: autorally_plant.cpp:443-459 returns 1
+  // Live updates the plant relays from ROS topics / dynamic_reconfigure (autorally_plant.cpp:262-310).  The
+  // headless plant has none unless a test or a caller injects them here.
+  bool new_dcfg = false, new_model = false, want_debug_image = false;
+  PathIntegralParamsConfig dcfg;
+  std::vector<int> model_description;
+  std::vector<float> model_data;  // [W1|W2|..|b1|b2|..] as AutorallyPlant::getModel delivers it
+  std::vector<float> debug_image;
+  bool hasNewDynRcfg() const { return new_dcfg; }
+  PathIntegralParamsConfig getDynRcfgParams() { new_dcfg = false; return dcfg; }
+  bool hasNewObstacles() const { return false; }
+  void getObstacles(std::vector<int> &, std::vector<float> &) {}
+  bool hasNewCostmap() const { return false; }
+  void getCostmap(std::vector<int> &, std::vector<float> &) {}
+  bool hasNewModel() const { return new_model; }
+  void getModel(std::vector<int> &description, std::vector<float> &data) { description = model_description; data = model_data; new_model = false; }
+  void setDebugImage(const std::vector<float> &img) { debug_image = img; }
   // pubControl's feedback law (autorally_plant.cpp:217-250) at a time `since` seconds after the
   // solution, for a measured state: u = u_ff(t) + K(t) (x - x_des(t)), all linearly interpolated.
   // false when outside the solution's horizon (the plant then publishes nothing).
@@ -116,6 +132,34 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     const auto loop_start = std::chrono::steady_clock::now();
     robot->setTimingInfo(0.0, avgTick, avgSleep);
     num_iter++;
+    if (debug_mode && robot->want_debug_image) {  // :162-174, the raster around the predicted state (display left to the plant)
+      const std::vector<float> seq = predicted_state_controller->getStateSeq();
+      robot->setDebugImage(predicted_state_controller->getDebugDisplay(seq[0], seq[1], seq[2]));
+    }
+    // live updates relayed by the plant, :182-204
+    if (robot->hasNewDynRcfg()) {
+      const PathIntegralParamsConfig c = robot->getDynRcfgParams();
+      actual_state_controller->costs_->updateParams_dcfg(c);
+      predicted_state_controller->costs_->updateParams_dcfg(c);
+    }
+    if (robot->hasNewObstacles()) {
+      std::vector<int> d; std::vector<float> v;
+      robot->getObstacles(d, v);
+      actual_state_controller->costs_->updateObstacles(d, v);
+      predicted_state_controller->costs_->updateObstacles(d, v);
+    }
+    if (robot->hasNewCostmap()) {
+      std::vector<int> d; std::vector<float> v;
+      robot->getCostmap(d, v);
+      actual_state_controller->costs_->updateCostmap(d, v);
+      predicted_state_controller->costs_->updateCostmap(d, v);
+    }
+    if (robot->hasNewModel()) {
+      std::vector<int> d; std::vector<float> v;
+      robot->getModel(d, v);
+      actual_state_controller->model_->updateModel(d, v);
+      predicted_state_controller->model_->updateModel(d, v);
+    }
     const int stride = optimization_stride;  // status != 0 => fixed stride (run_control_loop.cuh:208-211)
     if (stride >= 0 && stride < num_timesteps) {
       actual_state_controller->slideControlAndStateSeq(stride);

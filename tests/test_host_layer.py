@@ -128,3 +128,28 @@ def test_path_integral_binaries_match_python_loop(bins, golden_dir, tmp_path, bi
     np.testing.assert_allclose(out["feedback_gain_row_sums_t0"], gains[0].sum(axis=1), rtol=gtol, atol=2e-4)
     assert np.abs(gains[0]).max() > 1e-3
     assert abs(state[4]) > 0.5  # the car actually drove
+
+
+@pytest.mark.gpu
+def test_live_update_hooks_and_debug_raster(bins, golden_dir, tmp_path):
+    """runControlLoop's live updates (run_control_loop.cuh:162-204): a dynamic_reconfigure message waiting at
+    the first tick reaches both controllers' cost parameters (updateParams_dcfg, costs.cu:75-87), and the debug
+    raster around the predicted state is handed to the plant."""
+    from autorally_amd import capi
+    model_file, map_file = "autorally_nnet_09_12_2018.npz", "ccrf_costmap_09_29_2017.npz"
+    d = _params_dir(tmp_path, golden_dir, model_file, map_file)
+    launch_path = os.path.join(ROOT, "autorally_amd", "host", "launch", "path_integral_nn.launch")
+    env = dict(os.environ, AR_MPPI_PARAMS_PATH=d)
+    base = [bins["path_integral_nn"], launch_path, "--rollouts", "512", "--max-iter", "30", "--no-sleep",
+            "--set", "x_pos=0.0", "--set", "y_pos=-10.0", "--set", "heading=0.0", "--set", "use_feedback_gains=false"]
+    outs = {}
+    for tag, extra in (("plain", []), ("slow", ["--dcfg-desired-speed", "2.0", "--debug-image"])):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["plain"]["desired_speed"] == 8.0 and outs["plain"]["debug_image_pixels"] == 0  # launch value, no window
+    assert outs["slow"]["desired_speed"] == 2.0
+    assert outs["slow"]["final_state"][4] < outs["plain"]["final_state"][4] - 0.5  # the car really drives slower
+    # the raster handed over at the last tick: 10 m x 10 m at 50 px/m around the predicted state
+    assert outs["slow"]["debug_image_pixels"] == 500 * 500
+    assert 0.0 < outs["slow"]["debug_image_sum"] < 500 * 500 * 10.0  # the synthetic map rises above 1 off the track
