@@ -29,8 +29,40 @@ __device__ __forceinline__ void basis_shared_fast(const float *s, float u0, Basi
   c.A = c.big ? (q - t) / fmaf(q, t, 1.0f) : -t;
 }
 
+// W phi on the device: the same four i-mod-4 chains per output as basis_dynamics (basis_funcs.hpp), two
+// outputs per packed multiply-add.  Wr is W transposed, [25] columns of four outputs, held in registers
+// for the whole rollout (100 VGPRs; one wavefront per SIMD has 512), loaded once through LDS.
+struct BfWeights {
+  f32x4 col[kNumBfs];
+  __device__ __forceinline__ void load(const float *Wt_s)
+  {
+#pragma unroll
+    for (int i = 0; i < kNumBfs; i++) col[i] = *reinterpret_cast<const f32x4 *>(Wt_s + 4 * i);
+  }
+};
+__device__ __forceinline__ void basis_dynamics_dev(const BfWeights &Wr, const float *phi, float *d)
+{
+  f32x2 acc01[kBfYThreads], acc23[kBfYThreads];
+#pragma unroll
+  for (int y = 0; y < kBfYThreads; y++) acc01[y] = acc23[y] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < kNumBfs; i++) {
+    const f32x4 w = Wr.col[i];
+    const f32x2 p = {phi[i], phi[i]};
+    acc01[i % kBfYThreads] = __builtin_elementwise_fma(f32x2{w[0], w[1]}, p, acc01[i % kBfYThreads]);
+    acc23[i % kBfYThreads] = __builtin_elementwise_fma(f32x2{w[2], w[3]}, p, acc23[i % kBfYThreads]);
+  }
+  f32x2 s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+#pragma unroll
+  for (int y = 0; y < kBfYThreads; y++) {
+    s01 = s01 + acc01[y];
+    s23 = s23 + acc23[y];
+  }
+  d[0] = s01.x; d[1] = s01.y; d[2] = s23.x; d[3] = s23.y;
+}
+
 // computeStateDeriv: kinematics with the yaw rate always negated (generalized_linear.cu:212-217)
-__device__ __forceinline__ void bf_state_deriv(const float *W_s, const float *s, float u0, float u1, float cpsi,
+__device__ __forceinline__ void bf_state_deriv(const BfWeights &W_s, const float *s, float u0, float u1, float cpsi,
                                                float spsi, float *sd)
 {
   sd[0] = fmaf(cpsi, s[4], -(spsi * s[5]));
@@ -40,17 +72,19 @@ __device__ __forceinline__ void bf_state_deriv(const float *W_s, const float *s,
   BasisShared c;
   basis_shared_fast(s, u0, c);
   basis_funcs_from(s, u1, c, phi);
-  basis_dynamics(W_s, phi, sd + 3);
+  basis_dynamics_dev(W_s, phi, sd + 3);
 }
 
 __global__ __launch_bounds__(kBfLanes) void rollout_bf_kernel(const RolloutArgs a)
 {
-  __shared__ float W_s[4 * kNumBfs];
+  __shared__ __attribute__((aligned(16))) float W_s[4 * kNumBfs];  // transposed: [25][4]
   const int lane = threadIdx.x;
-  for (int i = lane; i < 4 * kNumBfs; i += kBfLanes) W_s[i] = a.wpack[i];
+  for (int i = lane; i < 4 * kNumBfs; i += kBfLanes) W_s[(i % kNumBfs) * 4 + i / kNumBfs] = a.wpack[i];
   __syncthreads();
   const int k = blockIdx.x * kBfLanes + lane;
   if (k >= a.K) return;  // K % 64 == 0: never splits a wave
+  BfWeights Wr;
+  Wr.load(W_s);
 
   float s[kStateDim];
 #pragma unroll
@@ -88,7 +122,7 @@ __global__ __launch_bounds__(kBfLanes) void rollout_bf_kernel(const RolloutArgs 
       else track_fetch<false>(a.cost, s, cpsi, spsi, tf, tb);
     }
     float sd[kStateDim];
-    bf_state_deriv(W_s, s, u0, u1, cpsi, spsi, sd);
+    bf_state_deriv(Wr, s, u0, u1, cpsi, spsi, sd);
     if (t > 0) {
       const float c = a.cost.need_control_cost
                           ? cost_finish<true>(a.cost, a.nu, s[4], s[5], tf, tb, u0, u1, du0, du1, crash)
@@ -119,12 +153,12 @@ constexpr int kBfRing = 16;  // power of two
 
 __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const RolloutArgs a)
 {
-  __shared__ float W_s[4 * kNumBfs];
+  __shared__ __attribute__((aligned(16))) float W_s[4 * kNumBfs];  // transposed: [25][4]
   __shared__ float rec[kBfRing][8][kBfLanes];  // [slot][field][lane]: s3 s4 s5 s6 u0 u1 du0 du1
   __shared__ int pub[kBfLanes], done[kBfLanes];
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;  // wave-uniform
-  for (int i = threadIdx.x; i < 4 * kNumBfs; i += 2 * kBfLanes) W_s[i] = a.wpack[i];
+  for (int i = threadIdx.x; i < 4 * kNumBfs; i += 2 * kBfLanes) W_s[(i % kNumBfs) * 4 + i / kNumBfs] = a.wpack[i];
   if (role == 0) { pub[lane] = 0; done[lane] = 0; }
   __syncthreads();  // the only barrier
   const int k = blockIdx.x * kBfLanes + lane;
@@ -135,6 +169,8 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
   if (role == 0) {
     // ------------------------------ dynamics wave ------------------------------
     const uint32_t a_mypub = lds_addr(&pub[lane]);
+    BfWeights Wr;
+    Wr.load(W_s);
     float s[kStateDim];
 #pragma unroll
     for (int i = 0; i < kStateDim; i++) s[i] = a.state[i];
@@ -171,7 +207,7 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
       BasisShared c;
       basis_shared_fast(s, u0, c);
       basis_funcs_from(s, u1, c, phi);
-      basis_dynamics(W_s, phi, d);
+      basis_dynamics_dev(Wr, phi, d);
 #pragma unroll
       for (int i = 0; i < 4; i++) s[3 + i] = fmaf(d[i], a.dt, s[3 + i]);
     }
@@ -235,9 +271,9 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
 __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, const float *states,
                                                                const float *controls, float *ders, int n)
 {
-  __shared__ float W_s[4 * kNumBfs];
+  __shared__ __attribute__((aligned(16))) float W_s[4 * kNumBfs];  // transposed: [25][4]
   const int lane = threadIdx.x;
-  for (int i = lane; i < 4 * kNumBfs; i += kBfLanes) W_s[i] = W[i];
+  for (int i = lane; i < 4 * kNumBfs; i += kBfLanes) W_s[(i % kNumBfs) * 4 + i / kNumBfs] = W[i];
   __syncthreads();
   const int idx = blockIdx.x * kBfLanes + lane;
   if (idx >= n) return;
@@ -247,7 +283,9 @@ __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, c
   float spsi, cpsi;
   sincos_fast(s[2], spsi, cpsi);
   float sd[kStateDim];
-  bf_state_deriv(W_s, s, controls[idx * 2], controls[idx * 2 + 1], cpsi, spsi, sd);
+  BfWeights Wr;
+  Wr.load(W_s);
+  bf_state_deriv(Wr, s, controls[idx * 2], controls[idx * 2 + 1], cpsi, spsi, sd);
 #pragma unroll
   for (int i = 0; i < kStateDim; i++) ders[idx * kStateDim + i] = sd[i];
 }
