@@ -230,14 +230,35 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     eta = a.scal[1];
     for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = a.w[base + q];
   } else {
+    // The K <= kRedChunk costs, 16 per thread, are requested with four 16-B loads that are in flight
+    // together (and together with the row above): one memory round trip for the min and the exp pass.
+    constexpr int kCostV = kRedChunk / 4 / kTailThreads;
+    const float4 *c4 = reinterpret_cast<const float4 *>(a.costs);
+    const int K4 = K / 4;
+    float4 cv[kCostV];
+#pragma unroll
+    for (int i = 0; i < kCostV; i++) {
+      const int q = i * kTailThreads + tid;
+      cv[i] = (q < K4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    }
     float m = INFINITY;
-    for (int k = tid; k < K; k += kTailThreads) m = fminf(m, a.costs[k]);
+#pragma unroll
+    for (int i = 0; i < kCostV; i++) m = fminf(fminf(m, fminf(cv[i].x, cv[i].y)), fminf(cv[i].z, cv[i].w));
     const float beta = block_min(m, red, &bc);
     float part = 0.0f;
-    for (int k = tid; k < K; k += kTailThreads) {
-      const float e = expf(-a.gamma * (a.costs[k] - beta));  // normExpKernel :201
-      wtile[k + (k >> 6)] = e;
-      part += e;
+#pragma unroll
+    for (int i = 0; i < kCostV; i++) {
+      const int q = i * kTailThreads + tid;
+      if (q < K4) {
+        const int k = 4 * q;  // k .. k+3 lie in one 64-rollout group
+        const float e0 = expf(-a.gamma * (cv[i].x - beta));  // normExpKernel :201
+        const float e1 = expf(-a.gamma * (cv[i].y - beta));
+        const float e2 = expf(-a.gamma * (cv[i].z - beta));
+        const float e3 = expf(-a.gamma * (cv[i].w - beta));
+        float *wt = &wtile[k + (k >> 6)];
+        wt[0] = e0; wt[1] = e1; wt[2] = e2; wt[3] = e3;
+        part += (e0 + e1) + (e2 + e3);
+      }
     }
     eta = block_sum(part, red, &bc);
     if (extra) {
