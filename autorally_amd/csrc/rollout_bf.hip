@@ -178,14 +178,17 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
     const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
     const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
     const bool pure_noise_k = (k >= a.k99);  // :141
-    float2 e_next = noise[(size_t)k];
-    float2 U_next = Useq[0];
+    // eps and U are requested two steps ahead: a step of this wave is shorter than an L2 round trip
+    float2 e_n1 = noise[(size_t)k], e_n2 = noise[(size_t)min(1, T - 1) * K + k];
+    float2 U_n1 = Useq[0], U_n2 = Useq[min(1, T - 1)];
     int seen = 0;  // steps the cost wave has consumed
     for (int t = 0; t < T; t++) {
-      const float2 e = e_next, Ut = U_next;
-      const int tn = min(t + 1, T - 1);
-      e_next = noise[(size_t)tn * K + k];
-      U_next = Useq[tn];
+      const float2 e = e_n1, Ut = U_n1;
+      const int tn = min(t + 2, T - 1);
+      e_n1 = e_n2;
+      U_n1 = U_n2;
+      e_n2 = noise[(size_t)tn * K + k];
+      U_n2 = Useq[tn];
       float du0, du1, u0, u1;
       if (noise_free_k || t < a.opt_delay) {
         du0 = 0.0f; du1 = 0.0f; u0 = Ut.x; u1 = Ut.y;

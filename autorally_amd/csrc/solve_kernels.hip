@@ -228,7 +228,24 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   float eta;
   if (a.pre) {
     eta = a.scal[1];
-    for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = a.w[base + q];
+    // the chunk's weights: four 16-B loads per thread, in flight together
+    constexpr int kWV = kRedChunk / 4 / kTailThreads;
+    const float4 *w4 = reinterpret_cast<const float4 *>(a.w + base);
+    float4 wv[kWV];
+#pragma unroll
+    for (int i = 0; i < kWV; i++) {
+      const int q = i * kTailThreads + tid;
+      wv[i] = (q < n / 4) ? w4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < kWV; i++) {
+      const int q = i * kTailThreads + tid;
+      if (q < n / 4) {
+        const int k = 4 * q;
+        float *wt = &wtile[k + (k >> 6)];
+        wt[0] = wv[i].x; wt[1] = wv[i].y; wt[2] = wv[i].z; wt[3] = wv[i].w;
+      }
+    }
   } else {
     // The K <= kRedChunk costs, 16 per thread, are requested with four 16-B loads that are in flight
     // together (and together with the row above): one memory round trip for the min and the exp pass.
