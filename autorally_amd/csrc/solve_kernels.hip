@@ -373,6 +373,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
   if (!a.last_iter) return;       // more iterations follow: U stays the raw weighted mean
   float *X = dyn + (K / 64) * 2;  // [(T+4)][2]
+  float *Y = X + (T + 4) * 2;     // [T][2] smoothed sequence
   for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
     const int r = i >> 1, j = i & 1;
     float v;
@@ -395,9 +396,9 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
       p = f0 * X[i + 8];
       acc = acc + p;
       a.U[i] = acc;  // the device copy the next solve perturbs (the host computes the same values itself)
+      Y[i] = acc;    // and in LDS for the slid copy below
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // Leave a copy of [U | hist]
@@ -405,19 +406,15 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   // the other buffer, so that the control loop's slide -> solve costs no kernel and no upload.
   if (a.slid != nullptr) {
     const int st = a.slide_stride;
-    for (int i = tid; i < 2 * T; i += kTailThreads) X[i] = a.U[i];  // smoothed sequence (own stores)
-    float hold = 0.0f;
-    if (tid < 4) hold = a.hist[tid];
-    const float hold2 = __shfl(hold, (tid + 2) & 63);  // all lanes active: lane i gets hist[i + 2]
-    __syncthreads();
+    // hist rows sit in X[0..3] (the smoothing's left padding)
     for (int i = tid; i < 2 * T; i += kTailThreads) {
       const int r = i >> 1, j = i & 1;
-      a.slid[i] = (r < T - st) ? X[(r + st) * 2 + j] : (j ? a.init1 : a.init0);
+      a.slid[i] = (r < T - st) ? Y[(r + st) * 2 + j] : (j ? a.init1 : a.init0);
     }
     if (tid < 4) {
       float hv;
-      if (st == 1) hv = (tid < 2) ? hold2 : X[tid - 2];
-      else hv = X[(st - 2) + tid];  // flat-index quirk (Q15)
+      if (st == 1) hv = (tid < 2) ? X[tid + 2] : Y[tid - 2];
+      else hv = Y[(st - 2) + tid];  // flat-index quirk (Q15)
       a.slid[2 * T + tid] = hv;
     }
   }
@@ -533,7 +530,7 @@ hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const
   a.slid = slid; a.slide_stride = slide_stride; a.init0 = init0; a.init1 = init1;
   a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter; a.part = part;
   a.K = K; a.T = T; a.gamma = gamma; a.last_iter = last_iter; a.seq = seq;
-  const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2) * sizeof(float);
+  const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2 + (size_t)T * 2) * sizeof(float);
   const int C = (K + kRedChunk - 1) / kRedChunk;
   if (C > 1 && part == nullptr) return hipErrorInvalidValue;
   a.pre = (C > 1) ? 1 : 0;
