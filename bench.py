@@ -33,7 +33,7 @@ ROLLOUT_BYTES_INLINE_NOISE = 8
 ROLLOUT_BYTES_BUFFERED_NOISE = 16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc_final.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic_pmc_final.json")
 
 
 def measured_traffic(cfg, variant):
@@ -276,7 +276,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(cfg, variant),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_h_hbm_traffic_pmc_final.json)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_i_hbm_traffic_pmc_final.json)",
                 "kernel": "rollout (%s)" % variant, "kernel_ms": rollout_s * 1e3,
                 "flop_per_state_update": fl, "state_updates_per_launch": K * T,
                 "algorithmic_bytes_per_launch": bpu * K * T,
