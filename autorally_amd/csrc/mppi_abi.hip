@@ -409,20 +409,24 @@ int upload_controls_if_dirty(mppi_handle *h)
 int wait_pending(mppi_handle *h)
 {
   if (!h->pending) return MPPI_OK;
-  // The tail kernel writes T+1 entries of 16 B into host-mapped memory -- row t: [u0, u1, 0, seq], then
-  // [beta, eta, trajectory cost, seq] -- each as one store whose last word is this solve's sequence
-  // number.  The solve is complete for the host once every entry carries it.
+  // The tail kernel writes T+2 entries of 16 B into host-mapped memory -- row t: [u0, seq, u1, seq], then
+  // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq] -- each as one store.  An entry is complete
+  // once words 1 and 3 carry this solve's sequence number (either 8-byte half may land first); the solve
+  // is complete for the host once every entry is.
   const volatile unsigned *words = reinterpret_cast<const volatile unsigned *>(h->h_res);
-  const int n_entries = h->T + 1;
+  const int n_entries = h->T + 2;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long spins = 0;
   int next = 0;  // entries [0, next) have been seen with the sequence number
   for (;;) {
-    while (next < n_entries && __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) == h->seq) next++;
+    while (next < n_entries && __atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) == h->seq &&
+           __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) == h->seq)
+      next++;
     if (next == n_entries) break;
     __builtin_ia32_pause();
     if ((++spins & 0xFFFFF) == 0) {
-      if (hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq)
+      if (hipStreamQuery(h->stream) == hipSuccess && (__atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) != h->seq ||
+                                                      __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq))
         return fail(h, MPPI_ERR_HIP, "solve finished without publishing its result block");
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         return fail(h, MPPI_ERR_HIP, "timed out waiting for the solve");
@@ -430,8 +434,8 @@ int wait_pending(mppi_handle *h)
   }
   h->pending = false;
   h->baseline = h->h_res[4 * h->T + 0];
-  h->eta = h->h_res[4 * h->T + 1];
-  h->traj_cost = h->h_res[4 * h->T + 2];
+  h->eta = h->h_res[4 * h->T + 2];
+  h->traj_cost = h->h_res[4 * (h->T + 1) + 0];
   {
     // savitskyGolay (mppi_controller.cu:468-499) on the host, the same operations in the same order as
     // the tail kernel applies to the device copy (this file is compiled with -ffp-contract=off):
@@ -442,7 +446,7 @@ int wait_pending(mppi_handle *h)
     for (int j = 0; j < 4; j++) X[j] = h->hist[j];
     for (int t = 0; t < T; t++) {
       X[(t + 2) * 2 + 0] = h->h_res[4 * t + 0];
-      X[(t + 2) * 2 + 1] = h->h_res[4 * t + 1];
+      X[(t + 2) * 2 + 1] = h->h_res[4 * t + 2];
     }
     for (int r = T + 2; r < T + 4; r++)
       for (int j = 0; j < 2; j++) X[r * 2 + j] = X[(T + 1) * 2 + j];
@@ -688,8 +692,8 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_sub, sizeof(uint32_t) * 18 * 32));
   CR(hipMalloc(&h->d_one, sizeof(uint32_t) * 18 * 64));
   CR(hipHostMalloc(&h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipHostMallocDefault));
-  CR(hipHostMalloc(&h->h_res, sizeof(float) * 4 * ((size_t)h->T + 1), hipHostMallocMapped));
-  memset(h->h_res, 0, sizeof(float) * 4 * ((size_t)h->T + 1));
+  CR(hipHostMalloc(&h->h_res, sizeof(float) * 4 * ((size_t)h->T + 2), hipHostMallocMapped));
+  memset(h->h_res, 0, sizeof(float) * 4 * ((size_t)h->T + 2));
   {
     void *dp = nullptr;
     CR(hipHostGetDevicePointer(&dp, h->h_res, 0));

@@ -26,7 +26,7 @@ namespace mppi {
 // arrives last at the row's counter adds them in order; beta, eta and the weights then come from
 // weights_kernel (one launch more, but no K exps per workgroup -- the single-launch form is the
 // latency path of K <= 4096).  On the last iteration every row workgroup writes its raw weighted mean
-// straight into host-mapped memory (one 16-B entry carrying the solve's sequence number; the extra
+// straight into host-mapped memory (16-B entries carrying the solve's sequence number; the extra
 // workgroup / weights_kernel does the same for beta, eta and the trajectory cost): the host needs no D2H
 // copy and no stream synchronise, it polls the T+1 entries and applies the 5-tap smoothing itself.
 // The workgroup that finishes last (agent-scope arrival counter, MI355X guide G16) smooths the DEVICE
@@ -82,12 +82,13 @@ __device__ __forceinline__ float block_sum(float v, float *red, float *bc)
   return r;
 }
 
-// One result entry (16 B) straight into host-mapped memory: uncached system-scope store, the sequence
-// number in the last word, so that a reader that sees the new sequence number sees the three values
-// (one PCIe write; if it were split, the halves stay in order).
-__device__ __forceinline__ void publish_entry(float *res, int entry, float v0, float v1, float v2, unsigned seq)
+// One result entry (16 B) straight into host-mapped memory: [v0, seq, v1, seq], one uncached
+// system-scope store.  Both 8-byte halves carry the solve's sequence number, so a reader that finds
+// it in words 1 and 3 has both values even if the write reached memory as two 8-byte pieces in
+// either order.
+__device__ __forceinline__ void publish_entry(float *res, int entry, float v0, float v1, unsigned seq)
 {
-  const f32x4 v = {v0, v1, v2, __uint_as_float(seq)};
+  const f32x4 v = {v0, __uint_as_float(seq), v1, __uint_as_float(seq)};
   float *p = res + 4 * (size_t)entry;
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__
   const float traj = bcast(tc, false);
   if (tid == 0) {
     scal[0] = beta; scal[1] = eta; scal[2] = traj;
-    if (res) publish_entry(res, res_entry, beta, eta, traj, seq);  // last iteration: the host's copy
+    if (res) {  // last iteration: the host's copy
+      publish_entry(res, res_entry, beta, eta, seq);
+      publish_entry(res, res_entry + 1, traj, 0.0f, seq);
+    }
   }
 }
 
@@ -177,7 +181,8 @@ struct TailArgs {
   const float *hist;    // [4]
   float *w;             // [K] exp weights (for mppi_get_results)
   float *scal;          // [3] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup)
-  float *res;           // host-mapped result block, T+1 entries of 16 B: rows [u0, u1, 0, seq], then [beta, eta, traj, seq]
+  float *res;           // host-mapped result block, T+2 entries of 16 B: rows [u0, seq, u1, seq], then
+                        // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq]
   unsigned *counter;    // [1 + T] arrival counters (all rows, then per row), zero on entry, reset by the last arriver
   float *part;          // [T][K/64][2] chain results when a row is spread over several workgroups (K > kRedChunk)
   int pre;              // K > kRedChunk: beta, eta, trajectory cost and w[] were computed by weights_kernel
@@ -290,7 +295,10 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
         __hip_atomic_store(&a.scal[0], beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.scal[1], eta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.scal[2], traj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.last_iter) publish_entry(a.res, T, beta, eta, traj, a.seq);
+        if (a.last_iter) {
+          publish_entry(a.res, T, beta, eta, a.seq);
+          publish_entry(a.res, T + 1, traj, 0.0f, a.seq);
+        }
       }
     }
   }
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
     // soon as all T rows and the scalars carry this solve's sequence number, so nothing below -- the
     // arrival counter, the device-side smoothing for the next solve -- is on its critical path.
     const float u1 = __shfl(u, 1);  // all lanes of wave 0 active
-    if (tid == 0 && !extra && a.last_iter) publish_entry(a.res, t, u, u1, 0.0f, a.seq);
+    if (tid == 0 && !extra && a.last_iter) publish_entry(a.res, t, u, u1, a.seq);
   }
   // ---- arrival: the last workgroup smooths and publishes.  Hand-off form R1 of the MI355X guide
   // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
