@@ -94,6 +94,13 @@ int main(int argc, char **argv)
            c.width_, c.height_, c.params_.r_c1[0], c.params_.r_c1[1], c.params_.r_c1[2], c.params_.r_c2[0],
            c.params_.r_c2[1], c.params_.r_c2[2], c.params_.trs[0], c.params_.trs[1], c.params_.trs[2],
            c.track_costs_[0], c.track_costs_[4 * ((size_t)c.width_ * c.height_ - 1)], sum, c.track_costs_[1]);
+    // all four channels of the float4 texture (costs.cu:207-222): per-channel sums and one texel
+    double cs[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < (size_t)c.width_ * c.height_; i++)
+      for (int ch = 0; ch < 4; ch++) cs[ch] += c.track_costs_[4 * i + ch];
+    const size_t mid = (size_t)c.width_ * (c.height_ / 2) + c.width_ / 3;
+    printf("costmap4 sums=[%.9g %.9g %.9g %.9g] texel%zu=[%.9g %.9g %.9g %.9g]\n", cs[0], cs[1], cs[2], cs[3], mid,
+           c.track_costs_[4 * mid], c.track_costs_[4 * mid + 1], c.track_costs_[4 * mid + 2], c.track_costs_[4 * mid + 3]);
   }
   printf("host selftest OK (%zu params)\n", p.size());
   return 0;

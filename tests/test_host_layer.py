@@ -42,6 +42,18 @@ def test_host_selftest(bins, golden_dir, tmp_path):
     assert "r_c1=[0.125 0 0]" in line and "trs=[0.375 0.444444448 1]" in line  # costs.cu:224-229
     assert "ch0[0]=%.9g" % vals[0] in line and "ch0[last]=%.9g" % vals[-1] in line
     assert "sum0=%.9g" % float(np.sum(vals.astype(np.float64))) in line and "ch1max=0" in line
+    # and on the four-channel file the reference's track_generator.py wrote (gen_costmap_image_golden.py)
+    cmap4 = os.path.join(golden_dir, "costmap_track_generator.npz")
+    r = subprocess.run([bins["host_selftest"], os.path.join(golden_dir, "models", "autorally_nnet_09_12_2018.npz"),
+                        LAUNCH, str(tmp_path), cmap4], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    z = np.load(cmap4)
+    line = [l for l in r.stdout.splitlines() if l.startswith("costmap4 ")][0]
+    sums = [float(np.sum(z["channel%d" % c].astype(np.float64))) for c in range(4)]
+    assert "sums=[%.9g %.9g %.9g %.9g]" % tuple(sums) in line
+    mid = 20 * (12 // 2) + 20 // 3
+    assert "texel%d=[%.9g %.9g %.9g %.9g]" % ((mid,) + tuple(float(z["channel%d" % c][mid]) for c in range(4))) in line
+    assert "W=20 H=12" in r.stdout
 
 
 def _params_dir(tmp_path, golden_dir, model_file, map_file):

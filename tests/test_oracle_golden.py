@@ -184,3 +184,46 @@ def test_costmap_file_written_by_reference_track_converter(golden_dir):
         b = vals[min(H - 1, max(0, int((py - y0) * ppm))) * W + min(W - 1, max(0, int((px - 0.5 - x0) * ppm)))]
         got = o2.compute_cost(s, np.zeros(2, np.float32), np.zeros(2, np.float32))[0]
         assert abs(got - (abs(f) + abs(b)) / 2) < 1e-6, (px, py, got, f, b)
+
+
+def test_costmap_file_written_by_reference_track_generator(golden_dir):
+    """tests/golden/costmap_track_generator.npz was written by the reference's image converter
+    (scripts/track_generator.py:gen_costmap, run by tests/golden/gen_costmap_image_golden.py) from the
+    committed costmap_image.png + costmap_image_config.txt, with all four channels populated.  The
+    loader restating MPPICosts::loadTrackData (costs.cu:190-232) must put channel c of the file in
+    component c of texel (row, column) -- checked against the image's own pixels."""
+    import ast
+    import os
+    from PIL import Image
+    from autorally_amd import params as P
+    cfg = ast.literal_eval(open(os.path.join(golden_dir, "costmap_image_config.txt")).read())
+    m, r_c1, r_c2, trs = P.load_costmap_npz(os.path.join(golden_dir, "costmap_track_generator.npz"))
+    x0, x1 = cfg["xBounds"]
+    y0, y1 = cfg["yBounds"]
+    W, H = int((x1 - x0) * cfg["pixelsPerMeter"]), int((y1 - y0) * cfg["pixelsPerMeter"])
+    assert m.shape == (H, W, 4)
+    px = np.array(Image.open(os.path.join(golden_dir, "costmap_image.png")), dtype=np.float32)
+    assert px.shape == (H, W, 4) and cfg["imageRotation"] == 180 and cfg["flip"]
+    px = px[::-1, ::-1]  # the 180 degree rotation
+    off = [cfg[k + "Offset"] for k in "rgba"]
+    nrm = [cfg[k + "Normalizer"] for k in "rgba"]
+    for i in range(4):  # image channel i lands in costmap channel channelMap[i], flipped vertically
+        want = ((px[:, :, i] + np.float32(off[i])) / np.float32(nrm[i]))[::-1]
+        np.testing.assert_allclose(m[:, :, cfg["channelMap"][i]], want, rtol=1e-6, atol=0)
+    np.testing.assert_allclose(r_c1, [1.0 / (x1 - x0), 0, 0], rtol=1e-7)
+    np.testing.assert_allclose(trs, [-x0 / (x1 - x0), -y0 / (y1 - y0), 1], rtol=1e-7)
+    # the restated lookup returns component 0 of that texture (costs.cu:359-393 use .x only)
+    from oracle import oracle as O
+    from autorally_amd import synthetic as S
+    base = S.make_config(64, 4)
+    c = dict(base["cost"], track_coeff=1.0, speed_coeff=0.0, crash_coeff=0.0, slip_penalty=0.0,
+             boundary_threshold=1e9, desired_speed=0.0)
+    orc = O.Oracle(dict(base, map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs, cost=c))
+    ppm = cfg["pixelsPerMeter"]
+    for (qx, qy) in [(-1.3, -0.4), (0.6, 0.9), (2.1, 1.7)]:
+        s = np.array([qx, qy, 0, 0, 0, 0, 0], np.float32)
+        row = min(H - 1, max(0, int((qy - y0) * ppm)))
+        f = m[row, min(W - 1, max(0, int((qx + 0.5 - x0) * ppm))), 0]
+        b = m[row, min(W - 1, max(0, int((qx - 0.5 - x0) * ppm))), 0]
+        got = orc.compute_cost(s, np.zeros(2, np.float32), np.zeros(2, np.float32))[0]
+        assert abs(got - (abs(f) + abs(b)) / 2) < 1e-5 * max(1.0, abs(got)), (qx, qy, got, f, b)
