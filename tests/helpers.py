@@ -32,3 +32,15 @@ def rel_err(a, b, floor=1.0):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def load_nn_golden(golden_dir):
+    """The reference-generated NN vectors as one dict: the shipped models read through the reference's
+    reader (gen_golden.py) and the model written by its training pipeline's writer
+    (gen_model_writer_golden.py)."""
+    import os
+    g = {}
+    for f in ("nn_dynamics_golden.npz", "nn_writer_golden.npz"):
+        z = np.load(os.path.join(golden_dir, f))
+        g.update({k: z[k] for k in z.files})
+    return g

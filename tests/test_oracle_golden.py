@@ -1,6 +1,8 @@
 """Pins the CPU oracle's NN dynamics step against outputs of the reference's own
 Python restatement (tests/golden/gen_golden.py, scripts/ml_pipeline/utils.py) and its
-RNG against L'Ecuyer's published MRG32k3a constants."""
+RNG against L'Ecuyer's published MRG32k3a constants.  "trained_writer_6_16_24_4" is a model the
+reference's training pipeline WROTE (torch_model_to_npz, tests/golden/gen_model_writer_golden.py),
+with a layer list none of the shipped files has."""
 import os
 
 import numpy as np
@@ -9,9 +11,10 @@ import pytest
 from autorally_amd import params as P
 from autorally_amd import synthetic as S
 from oracle import oracle as O
+from tests.helpers import load_nn_golden
 
 MODELS = ["autorally_nnet_09_12_2018", "gazebo_nnet_09_12_2018", "shallow_network_08_20_2020",
-          "wider_deeper_network_08_20_2020"]
+          "wider_deeper_network_08_20_2020", "trained_writer_6_16_24_4"]
 
 
 def _oracle_for(golden_dir, name, g, fma_mode):
@@ -32,7 +35,7 @@ def test_num_params(golden_dir):
 
 
 def test_sample_from_survey(golden_dir):
-    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    g = load_nn_golden(golden_dir)
     orc = _oracle_for(golden_dir, MODELS[0], g, 1)
     out = orc.nn_forward(g["sample_in"])
     np.testing.assert_allclose(out, g["sample_out"], atol=1e-5, rtol=0)
@@ -43,7 +46,7 @@ def test_sample_from_survey(golden_dir):
 @pytest.mark.parametrize("name", MODELS)
 @pytest.mark.parametrize("fma_mode", [0, 1])
 def test_state_deriv_matches_reference_python(golden_dir, name, fma_mode):
-    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    g = load_nn_golden(golden_dir)
     orc = _oracle_for(golden_dir, name, g, fma_mode)
     states, ctrls, ders = g[name + "/states"], g[name + "/controls"], g[name + "/state_ders"]
     worst = 0.0
@@ -57,7 +60,7 @@ def test_state_deriv_matches_reference_python(golden_dir, name, fma_mode):
 
 @pytest.mark.parametrize("name", MODELS)
 def test_open_loop_trajectory(golden_dir, name):
-    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    g = load_nn_golden(golden_dir)
     orc = _oracle_for(golden_dir, name, g, 1)
     traj, tctrl = g[name + "/traj_states"], g[name + "/traj_controls"]
     s = traj[0].astype(np.float32)
@@ -67,7 +70,7 @@ def test_open_loop_trajectory(golden_dir, name):
 
 
 def test_fma_and_nofma_variants_agree(golden_dir):
-    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    g = load_nn_golden(golden_dir)
     a = _oracle_for(golden_dir, MODELS[0], g, 0)
     b = _oracle_for(golden_dir, MODELS[0], g, 1)
     for s, u in zip(g[MODELS[0] + "/states"], g[MODELS[0] + "/controls"]):

@@ -16,12 +16,12 @@ from autorally_amd import capi
 from autorally_amd import params as P
 from autorally_amd import synthetic as S
 from oracle import oracle as O
-from tests.helpers import noise_for, rel_err, warm_U
+from tests.helpers import load_nn_golden, noise_for, rel_err, warm_U
 
 pytestmark = pytest.mark.gpu
 
 MODELS = ["autorally_nnet_09_12_2018", "gazebo_nnet_09_12_2018", "shallow_network_08_20_2020",
-          "wider_deeper_network_08_20_2020"]
+          "wider_deeper_network_08_20_2020", "trained_writer_6_16_24_4"]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -55,7 +55,7 @@ def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
 @pytest.mark.parametrize("name", MODELS)
 @pytest.mark.parametrize("variant", ["auto", "valu"])
 def test_dynamics_golden_on_gpu(golden_dir, name, variant):
-    g = np.load(os.path.join(golden_dir, "nn_dynamics_golden.npz"))
+    g = load_nn_golden(golden_dir)
     layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", name + ".npz"))
     cfg = S.make_config(64, 10, layers=layers, theta=theta,
                         negate_yaw_der=bool(g[name + "/negate_yaw_der"][0]))
@@ -365,3 +365,18 @@ def test_solve_with_the_other_shipped_models(golden_dir, name, negate):
     err = rel_err(q["costs"], ref["costs"])
     assert int(np.sum(err > 1e-4)) <= 3 and float(np.percentile(err, 95)) < 1e-5
     assert np.max(np.abs(q["U"] - ref["U"])) <= 1e-4
+
+
+def test_solve_with_a_model_written_by_the_reference_trainer(golden_dir):
+    """The 6-16-24-4 network the reference's torch_model_to_npz wrote (gen_model_writer_golden.py): not an
+    MFMA shape, so the whole solve runs on the generic VALU kernel."""
+    layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", "trained_writer_6_16_24_4.npz"))
+    assert layers == [6, 16, 24, 4]
+    cfg = S.make_config(512, 40, layers=layers, theta=theta, track="oval")
+    U0 = np.tile(np.array([0.0, 0.25], np.float32), (40, 1))
+    ref, got = _solve_both(cfg, U0=U0)
+    assert got["variant"] == "valu_lds"
+    np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
+    err = rel_err(got["costs"], ref["costs"])
+    assert int(np.sum(err > 1e-4)) <= 5 and float(np.percentile(err, 95)) < 1e-5
+    assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
