@@ -380,3 +380,69 @@ def test_solve_with_a_model_written_by_the_reference_trainer(golden_dir):
     err = rel_err(got["costs"], ref["costs"])
     assert int(np.sum(err > 1e-4)) <= 5 and float(np.percentile(err, 95)) < 1e-5
     assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
+
+
+@pytest.mark.parametrize("T", [2, 3, 5, 15, 16, 17, 33, 65, 301])
+@pytest.mark.parametrize("family", ["nn", "bf"])
+def test_horizon_edge_cases(golden_dir, T, family):
+    """Horizons around the kernels' internal granularities (4-step noise chunks, 16-step hand-over rings,
+    one-step software pipelining) and a long one, K = 64 (a single wavefront group) and 192: every kernel
+    form against the oracle and bit-identical to the others.  T = 1 is rejected by mppi_create."""
+    extra = {}
+    if family == "bf":
+        extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    variants = ["quad", "fused", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
+    for K in (64, 192):
+        cfg = S.make_config(K, T, track="oval", **extra)
+        U0 = warm_U(cfg)
+        hist = np.array([0.01, 0.2, -0.02, 0.25], np.float32)
+        first = None
+        for v in variants:
+            ref, got = _solve_both(cfg, U0=U0, hist=hist, variant=v)
+            np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
+            assert float(np.percentile(rel_err(got["costs"], ref["costs"]), 90)) < 2e-5
+            assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
+            if first is None:
+                first = got
+            else:
+                np.testing.assert_array_equal(got["costs"].view(np.uint32), first["costs"].view(np.uint32))
+                np.testing.assert_array_equal(got["U"].view(np.uint32), first["U"].view(np.uint32))
+    with pytest.raises(capi.MppiError):
+        capi.Solver(S.make_config(64, 1, track="oval", **extra))
+
+
+@pytest.mark.parametrize("opt", [1, 3, 16])
+@pytest.mark.parametrize("variant", ["quad", "fused", "valu"])
+def test_slide_strides_up_to_the_horizon(opt, variant):
+    """Device-resident loops (in-kernel generator, slid copy left by the tail kernel or made by the slide
+    kernel, host re-upload every other tick) with optimization strides and slide strides from 1 to T,
+    T = 17 (one more than the hand-over ring).  A stride beyond T is refused: the reference would index
+    before U_ (mppi_controller.cu:545-552)."""
+    K, T = 192, 17
+    for sl in (opt, 1, T):
+        cfg = S.make_config(K, T, track="ring", opt_stride=opt)
+        orc = O.Oracle(cfg, fma_mode=1, nthreads=8)
+        sol = capi.Solver(cfg)
+        sol.set_rollout_variant(variant)
+        sol.seed(77, 0)
+        U = np.zeros((T, 2), np.float32)
+        hist = np.zeros(4, np.float32)
+        state = cfg["start_state"].copy()
+        for it in range(4):
+            eps = O.generate_noise(77, 2 * T * it, K, T)[None]
+            ref = orc.compute_control(state, U, hist, eps)
+            sol.compute_control(state)
+            got = sol.get_results(with_vectors=False)
+            assert np.max(np.abs(got["U"] - ref["U"])) <= 2e-4, (sl, it)
+            U, hist = orc.slide_control_seq(ref["U"], hist, cfg["init_u"], sl)
+            if it % 2 == 1:  # continue from the oracle's sequence: host slide + upload
+                sol.set_control_seq(ref["U"])
+                sol.slide_control_seq(sl)
+                np.testing.assert_array_equal(sol.get_control_seq(), U)
+            else:            # continue from the device copy
+                sol.slide_control_seq(sl)
+                np.testing.assert_allclose(sol.get_control_seq(), U, atol=2e-4)
+                U, hist = sol.get_control_seq().copy(), sol.get_control_hist().copy()
+        with pytest.raises(capi.MppiError):
+            sol.slide_control_seq(T + 1)
+        sol.close()
