@@ -248,7 +248,9 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
       if (q < n / 4) {
         const int k = 4 * q;
         float *wt = &wtile[k + (k >> 6)];
-        wt[0] = wv[i].x; wt[1] = wv[i].y; wt[2] = wv[i].z; wt[3] = wv[i].w;
+        // weight = w/normalizer (:244) by the thread that owns the element: the normalising loop below
+        // walks elements other threads wrote and there is no barrier in between on this path
+        wt[0] = wv[i].x / eta; wt[1] = wv[i].y / eta; wt[2] = wv[i].z / eta; wt[3] = wv[i].w / eta;
       }
     }
   } else {
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
         tile[o + 0] = pre[i].x; tile[o + 1] = pre[i].y; tile[o + 2] = pre[i].z; tile[o + 3] = pre[i].w;
       }
     }
-    for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = wtile[q + (q >> 6)] / eta;  // weight = w/normalizer, :244
+    if (!a.pre)  // (block_sum above put a barrier between the exp pass and this one)
+      for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = wtile[q + (q >> 6)] / eta;  // weight = w/normalizer, :244
     __syncthreads();
     for (int c = tid; c < (n / 64) * 2; c += kTailThreads) {
       const int ml = c >> 1, j = c & 1;

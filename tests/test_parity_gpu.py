@@ -446,3 +446,28 @@ def test_slide_strides_up_to_the_horizon(opt, variant):
         with pytest.raises(capi.MppiError):
             sol.slide_control_seq(T + 1)
         sol.close()
+
+
+@pytest.mark.parametrize("K", [8256, 65600, 131072])
+def test_many_chunk_rows_are_reduced_correctly(K):
+    """K far beyond one reduction chunk (4096 rollouts per workgroup, a ragged last chunk at 8256 / 65600,
+    700-1300 workgroups at T = 40): several fresh handles, every solve against the oracle.  (A missing
+    barrier between staging and normalising the chunk's weights used to corrupt about one row in a
+    hundred solves at these sizes -- found by a sweep over K, never by the K <= 16384 cases.)"""
+    T = 40
+    cfg = S.make_config(K, T, track="oval")
+    eps = noise_for(cfg)
+    U0 = warm_U(cfg)
+    hist = np.array([0.01, 0.2, -0.02, 0.25], np.float32)
+    ref = O.Oracle(cfg, fma_mode=1, nthreads=16).compute_control(cfg["start_state"], U0, hist, eps)
+    for fresh in range(3):
+        sol = capi.Solver(cfg)
+        for rep in range(4):
+            sol.set_control_seq(U0)
+            sol.set_control_hist(hist)
+            sol.set_noise(eps)
+            sol.compute_control(cfg["start_state"])
+            got = sol.get_results(with_vectors=False)
+            assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4, (fresh, rep)
+            assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"])
+        sol.close()
