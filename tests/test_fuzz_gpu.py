@@ -1,0 +1,109 @@
+"""Randomised whole-solve parity: configurations drawn over K, T, layer lists (MFMA shapes, generic shapes,
+the basis-function model), kernel forms, iterations, optimization stride, cost parameters, control limits,
+sampling variance, gamma and start states -- HIP solve against the oracle on the same inputs.
+
+Criterion per case.  Applied controls of a single iteration are bit-exact.  A rollout whose cost differs
+by more than 1e-4 (relative) is one whose nearest-texel lookup or crash / slip threshold flipped on an
+ulp difference of tanh / sin / cos (the oracle's own two arithmetic modes flip the same way); such
+rollouts must be few, and the control sequence may differ from the oracle's by at most the weight mass
+they carry: |dU| <= 2e-4 + 4 * mass (controls are bounded by 1), i.e. 2e-4 wherever no weight-bearing
+rollout flipped."""
+import os
+
+import numpy as np
+import pytest
+
+from autorally_amd import capi, params as P, synthetic as S
+from oracle import oracle as O
+from tests.helpers import noise_for, rel_err, warm_U
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = [None, None, [6, 64, 64, 4], [6, 32, 32, 32, 32, 4], [6, 64, 64, 64, 64, 4], [6, 16, 8, 4], [6, 24, 4],
+          [6, 5, 7, 4], [6, 40, 4], [6, 8, 8, 8, 8, 8, 4], "bf"]
+
+
+def _draw(golden_dir, seed):
+    rng = np.random.RandomState(seed)
+    K = 64 * int(rng.choice([1, 2, 3, 5, 8, 16, 17, 32, 64, 65, 100]))
+    T = int(rng.choice([2, 3, 5, 9, 16, 20, 33, 47, 60, 100]))
+    layers = LAYERS[rng.randint(len(LAYERS))]
+    iters = int(rng.choice([1, 1, 1, 2, 3]))
+    opt = min(int(rng.choice([1, 1, 2, 3, max(1, T - 1)])), T - 1)
+    cost = dict(P.DEFAULT_COST)
+    if rng.rand() < 0.4:
+        cost.update(l1_cost=bool(rng.rand() < 0.5), steering_coeff=float(rng.choice([0, 0.3, 2.0])),
+                    throttle_coeff=float(rng.choice([0, 0.25])))
+    if rng.rand() < 0.3:
+        cost.update(track_slop=float(rng.choice([0.0, 0.05, 0.3])), boundary_threshold=float(rng.choice([0.3, 0.65, 0.95])))
+    if rng.rand() < 0.3:
+        cost.update(desired_speed=float(rng.choice([2.0, 6.0, 15.0])), speed_coeff=float(rng.choice([0.0, 4.25, 20.0])))
+    if rng.rand() < 0.3:
+        cost.update(max_slip_ang=float(rng.choice([0.2, 0.8, 1.25])), slip_penalty=float(rng.choice([0.0, 10.0, 100.0])),
+                    crash_coeff=float(rng.choice([0.0, 1000.0, 10000.0])))
+    if rng.rand() < 0.2:
+        cost.update(discount=float(rng.choice([0.0, 0.1, 0.5])))
+    over = dict(cost=cost, num_iters=iters, opt_stride=opt, gamma=float(rng.choice([0.05, 0.15, 0.5])),
+                nu=(float(rng.choice([0.1, 0.275, 0.9])), float(rng.choice([0.1, 0.3, 0.9]))),
+                negate_yaw_der=bool(rng.rand() < 0.7),
+                init_u=(float(rng.choice([0.0, 0.1])), float(rng.choice([0.0, 0.2]))))
+    if rng.rand() < 0.3:
+        over.update(u_lo=(-0.6, -0.3), u_hi=(0.7, 0.4))
+    track = str(rng.choice(["ring", "oval"]))
+    if layers == "bf":
+        W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+        cfg = S.make_config(K, T, track=track, bf_W=W, **over)
+        variants = ["auto", "fused"]
+    else:
+        cfg = S.make_config(K, T, layers=layers, track=track, **over)
+        variants = ["auto", "quad", "fused", "valu", "valu_lds"]
+    st = cfg["start_state"].copy()
+    st[4], st[5], st[6], st[3] = rng.uniform(0.05, 12.0), rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.2, 0.2)
+    if rng.rand() < 0.2:
+        st[0] += rng.uniform(-3, 3)
+        st[1] += rng.uniform(-3, 3)
+    cfg["start_state"] = st.astype(np.float32)
+    variant = variants[rng.randint(len(variants))]
+    hist = rng.uniform(-0.3, 0.3, 4).astype(np.float32)
+    return cfg, variant, hist
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_configurations_match_the_oracle(golden_dir, block):
+    worst_clean = 0.0
+    for seed in range(block * 25, block * 25 + 25):
+        cfg, variant, hist = _draw(golden_dir, seed)
+        iters = cfg["num_iters"]
+        eps = noise_for(cfg)
+        U0 = warm_U(cfg, seed=seed)
+        ref = O.Oracle(cfg, fma_mode=1, nthreads=16).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
+        sol = capi.Solver(cfg)
+        try:
+            sol.set_rollout_variant(variant)
+        except capi.MppiError:
+            pass  # a form this layer list does not have: the automatic choice stays
+        sol.set_control_seq(U0)
+        sol.set_control_hist(hist)
+        sol.set_noise(eps)
+        sol.compute_control(cfg["start_state"])
+        got = sol.get_results()
+        V = sol.get_applied_controls()
+        sol.close()
+        tag = (seed, cfg["K"], cfg["T"], cfg.get("layers"), variant, iters)
+        err = rel_err(got["costs"], ref["costs"])
+        flipped = err > 1e-4
+        assert float(np.mean(flipped)) <= 0.03, tag
+        w = ref["w"] / ref["w"].sum()
+        wg = got["w"] / got["w"].sum()
+        mass = float(np.sum(np.maximum(w, wg)[flipped]))
+        bound = 2e-4 + 4.0 * mass * iters
+        dU = float(np.max(np.abs(got["U"] - ref["U"])))
+        assert dU <= bound, tag + (dU, mass)
+        if mass == 0.0:
+            worst_clean = max(worst_clean, dU)
+            assert abs(got["traj_cost"] - ref["traj_cost"]) <= 2e-4 * max(abs(ref["traj_cost"]), 1e-3), tag
+        if iters == 1:
+            np.testing.assert_array_equal(V.view(np.uint32), ref["V"][-1].view(np.uint32), err_msg=str(tag))
+        else:
+            assert float(np.max(np.abs(V - ref["V"][-1]))) <= bound, tag
+    assert worst_clean <= 2e-4
