@@ -107,3 +107,111 @@ def test_random_configurations_match_the_oracle(golden_dir, block):
         else:
             assert float(np.max(np.abs(V - ref["V"][-1]))) <= bound, tag
     assert worst_clean <= 2e-4
+
+
+def _update_model_layout(layers, theta):
+    """packed [W1|b1|W2|b2|..] -> updateModel's [W1|W2|..|b1|b2|..] (neural_net_model.cu:152-180)"""
+    Ws, bs, o = [], [], 0
+    for nin, nout in zip(layers[:-1], layers[1:]):
+        Ws.append(theta[o:o + nin * nout])
+        o += nin * nout
+        bs.append(theta[o:o + nout])
+        o += nout
+    return np.concatenate(Ws + bs).astype(np.float32)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_call_sequences_match_the_oracle(block):
+    """Stateful: 14 random ABI calls per handle (solves in generator / explicit / asynchronous mode,
+    slides by several strides, sequence / history / limits / cost / model updates, kernel-form switches,
+    rollout_only), mirrored step by step by the oracle holding its own U, history and generator offset."""
+    for sq in range(block * 8, block * 8 + 8):
+        rng = np.random.RandomState(424200 + sq)
+        K = 64 * int(rng.choice([1, 3, 8, 16, 64, 96]))
+        T = int(rng.choice([5, 16, 17, 33, 60]))
+        layers = [None, [6, 64, 64, 4], [6, 32, 32, 32, 32, 4], [6, 24, 4]][rng.randint(4)]
+        iters = int(rng.choice([1, 1, 2]))
+        opt = min(int(rng.choice([1, 1, 2, 3])), T - 1)
+        cfg = S.make_config(K, T, layers=layers, track=str(rng.choice(["ring", "oval"])), num_iters=iters, opt_stride=opt)
+        seed = int(rng.randint(1, 1 << 30))
+        sol = capi.Solver(cfg)
+        sol.seed(seed, 0)
+        orc = O.Oracle(cfg, fma_mode=1, nthreads=16)
+        U, hist, off = np.zeros((T, 2), np.float32), np.zeros(4, np.float32), 0
+        state = cfg["start_state"].copy()
+        log = []
+        for step in range(14):
+            op = str(rng.choice(["solve", "solve", "solve", "slide", "slide", "setU", "sethist", "reset", "cost", "model",
+                                 "variant", "rollout_only", "async", "limits", "explicit"]))
+            log.append(op)
+            tag = (sq, K, T, cfg["layers"], iters, opt, " ".join(log))
+            if op in ("solve", "async", "explicit"):
+                if op == "explicit":
+                    eps = np.stack([O.generate_noise(999, 2 * T * i + 7 * step * T, K, T) for i in range(iters)])
+                    sol.set_noise(eps)
+                else:
+                    eps = np.stack([O.generate_noise(seed, off + 2 * T * i, K, T) for i in range(iters)])
+                    off += 2 * T * iters
+                ref = orc.compute_control(state, U, hist, eps, num_iters=iters)
+                if op == "async":
+                    sol.compute_control_async(state)
+                    sol.synchronize()
+                else:
+                    sol.compute_control(state)
+                got = sol.get_results()
+                flipped = rel_err(got["costs"], ref["costs"]) > 1e-4
+                w = ref["w"] / ref["w"].sum()
+                mass = float(np.maximum(w, got["w"] / got["w"].sum())[flipped].sum())
+                assert float(np.mean(flipped)) <= 0.03, tag
+                assert float(np.max(np.abs(got["U"] - ref["U"]))) <= 2e-4 + 4 * mass * iters, tag
+                U = got["U"].copy()  # the mirror continues from the device's values
+                gs, _ = sol.nominal_traj(state)
+                rs, _ = orc.nominal_traj(state, U)
+                assert np.max(np.abs(gs - rs)) <= 1e-4, tag
+                state = rs[min(opt, T - 1)].copy()
+            elif op == "slide":
+                st = int(rng.choice([opt, opt, 1, 2, T]))
+                U, hist = orc.slide_control_seq(U, hist, cfg["init_u"], st)
+                sol.slide_control_seq(st)
+                np.testing.assert_array_equal(sol.get_control_seq(), U, err_msg=str(tag))
+                np.testing.assert_array_equal(sol.get_control_hist(), hist, err_msg=str(tag))
+            elif op == "setU":
+                U = warm_U(cfg, seed=step + sq)
+                sol.set_control_seq(U)
+            elif op == "sethist":
+                hist = rng.uniform(-0.3, 0.3, 4).astype(np.float32)
+                sol.set_control_hist(hist)
+            elif op == "reset":  # resetControls (mppi_controller.cu:448-458) leaves the history alone
+                sol.reset_controls()
+                U = np.tile(np.array(cfg["init_u"], np.float32), (T, 1))
+                np.testing.assert_array_equal(sol.get_control_seq(), U)
+                np.testing.assert_array_equal(sol.get_control_hist(), hist)
+            elif op == "cost":
+                cost = dict(cfg["cost"], desired_speed=float(rng.choice([4.0, 8.0, 12.0])),
+                            track_coeff=float(rng.choice([100.0, 200.0])), steering_coeff=float(rng.choice([0.0, 0.5])),
+                            l1_cost=bool(rng.rand() < 0.3))
+                cfg = dict(cfg, cost=cost)
+                sol.set_cost_params(cost)
+                orc = O.Oracle(cfg, fma_mode=1, nthreads=16)
+            elif op == "model":
+                th = (cfg["theta"] * (1.0 + 0.02 * rng.standard_normal(cfg["theta"].shape))).astype(np.float32)
+                cfg = dict(cfg, theta=th)
+                sol.update_model(cfg["layers"], _update_model_layout(cfg["layers"], th))
+                orc = O.Oracle(cfg, fma_mode=1, nthreads=16)
+            elif op == "limits":
+                lo, hi = (-0.8, -0.5), (0.9, float(rng.choice([0.3, 0.65])))
+                cfg = dict(cfg, u_lo=lo, u_hi=hi)
+                sol.set_control_limits(lo, hi)
+                orc = O.Oracle(cfg, fma_mode=1, nthreads=16)
+            elif op == "variant":
+                try:
+                    sol.set_rollout_variant(str(rng.choice(["auto", "quad", "fused", "valu", "valu_lds"])))
+                except capi.MppiError:
+                    pass
+            elif op == "rollout_only":  # rolloutKernel alone: one draw of the generator
+                eps1 = O.generate_noise(seed, off, K, T)[None]
+                off += 2 * T
+                c = sol.rollout_only(state)
+                rc = orc.compute_control(state, U, hist, eps1, num_iters=1)["costs"]
+                assert float(np.mean(rel_err(c, rc) > 1e-4)) <= 0.03, tag
+        sol.close()
