@@ -166,3 +166,52 @@ def test_product_matches_oracle(T, layers, negate):
     with pytest.raises(capi.MppiError):
         sol.set_ddp_weights(Q, np.array([0.0, 1.0], np.float32), Qf)
     sol.close()
+
+
+@pytest.mark.gpu
+def test_product_matches_oracle_on_random_problems(golden_dir):
+    """80 drawn problems: layer lists (MFMA and generic shapes), T = 2 ... 250, control rate, limits,
+    negate_yaw_der, start states, control sequences, DDP weights (zero entries included), targets on and off
+    the nominal trajectory.  The basis-function model uses the numerical Jacobian (ddp_dynamics.h:71-84),
+    whose float32 differences are amplified by the Riccati recursion: looser bound, T <= 100."""
+    import os
+    from autorally_amd import capi, params as P
+    W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    shapes = [None, [6, 64, 64, 4], [6, 32, 32, 32, 32, 4], [6, 16, 8, 4], [6, 24, 4], [6, 5, 7, 4], [6, 8, 8, 8, 8, 8, 4], "bf"]
+    for case in range(80):
+        rng = np.random.RandomState(5000 + case)
+        T = int(rng.choice([2, 3, 5, 17, 40, 100, 250]))
+        layers = shapes[rng.randint(len(shapes))]
+        over = dict(negate_yaw_der=bool(rng.rand() < 0.6), hz=int(rng.choice([20, 50, 100])))
+        if rng.rand() < 0.3:
+            over.update(u_lo=(-0.6, -0.3), u_hi=(0.7, 0.4))
+        if layers == "bf":
+            cfg = S.make_config(64, min(T, 100), track="oval", bf_W=W, **over)
+        else:
+            cfg = S.make_config(64, T, layers=layers, track="oval", seed_model=int(rng.randint(100)), **over)
+        x0 = cfg["start_state"].copy()
+        x0[4], x0[5], x0[6] = rng.uniform(0.05, 12), rng.uniform(-1, 1), rng.uniform(-1.5, 1.5)
+        x0[3], x0[2] = rng.uniform(-0.2, 0.2), rng.uniform(-3, 3)
+        U = np.clip(warm_U(cfg, seed=case) * rng.uniform(0.2, 2.0), cfg["u_lo"], cfg["u_hi"]).astype(np.float32)
+        Q = (rng.uniform(0, 1, 7) * (rng.rand(7) < 0.8)).astype(np.float32)
+        R = rng.uniform(0.5, 20, 2).astype(np.float32)
+        Qf = (rng.uniform(0, 2, 7) * (rng.rand() < 0.5)).astype(np.float32)
+        orc = O.Oracle(cfg)
+        sol = capi.Solver(cfg)
+        sol.set_control_seq(U)
+        sol.set_ddp_weights(Q, R, Qf)
+        xs, us = orc.nominal_traj(x0, U)
+        if rng.rand() < 0.5:
+            tx = xs + rng.normal(0, 0.1, xs.shape).astype(np.float32)
+            got = sol.compute_feedback_gains(x0, tx, us)
+            ref = orc.ddp_feedback_gains(x0, tx, us, Q, R, Qf)
+        else:
+            got = sol.compute_feedback_gains(x0)
+            ref = orc.ddp_feedback_gains(x0, xs, us, Q, R, Qf)
+        sol.close()
+        tol = 3e-2 if layers == "bf" else 2e-4
+        tag = (case, T, layers)
+        assert np.all(np.isfinite(got["feedback"])), tag
+        assert np.max(np.abs(got["feedback"] - ref["feedback"])) <= tol * max(np.abs(ref["feedback"]).max(), 1e-6), tag
+        assert np.max(np.abs(got["feedforward"] - ref["feedforward"])) <= tol * max(1e-3, np.abs(ref["feedforward"]).max()), tag
+        assert np.max(np.abs(got["x"] - ref["x"])) <= 1e-4, tag

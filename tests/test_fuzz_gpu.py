@@ -215,3 +215,80 @@ def test_random_call_sequences_match_the_oracle(block):
                 rc = orc.compute_control(state, U, hist, eps1, num_iters=1)["costs"]
                 assert float(np.mean(rel_err(c, rc) > 1e-4)) <= 0.03, tag
         sol.close()
+
+
+def _check_against_oracle(cfg, variants):
+    eps = noise_for(cfg)
+    U0 = warm_U(cfg)
+    hist = np.array([0.01, 0.2, -0.02, 0.25], np.float32)
+    ref = O.Oracle(cfg, fma_mode=1, nthreads=16).compute_control(cfg["start_state"], U0, hist, eps)
+    for v in variants:
+        sol = capi.Solver(cfg)
+        sol.set_rollout_variant(v)
+        sol.set_control_seq(U0)
+        sol.set_control_hist(hist)
+        sol.set_noise(eps)
+        sol.compute_control(cfg["start_state"])
+        got = sol.get_results()
+        V = sol.get_applied_controls()
+        sol.close()
+        np.testing.assert_array_equal(V.view(np.uint32), ref["V"][-1].view(np.uint32), err_msg=v)
+        flipped = rel_err(got["costs"], ref["costs"]) > 1e-4
+        w = ref["w"] / ref["w"].sum()
+        mass = float(np.maximum(w, got["w"] / got["w"].sum())[flipped].sum())
+        assert float(np.mean(flipped)) <= 0.03, v
+        assert float(np.max(np.abs(got["U"] - ref["U"]))) <= 2e-4 + 4 * mass, v
+
+
+@pytest.mark.parametrize("K,T", [(256, 1000), (64, 4000)])
+def test_long_horizons(golden_dir, K, T):
+    """20 s / 80 s of horizon at 50 Hz: rings wrap hundreds of times, the smoothing buffers grow with T."""
+    _check_against_oracle(S.make_config(K, T, track="ring"), ("quad", "fused", "valu", "valu_lds"))
+    W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    _check_against_oracle(S.make_config(K, T, track="ring", bf_W=W), ("auto", "fused"))
+
+
+@pytest.mark.parametrize("W,H,ppm", [(1, 1, 1), (2, 2, 1), (7, 3, 1), (640, 20, 10), (3000, 3000, 50)])
+def test_degenerate_and_large_costmaps(W, H, ppm):
+    """One texel, a few texels, a strip, 36 MB of float4: every lookup clamps into the map (costs.cu:359-393)."""
+    rng = np.random.RandomState(W * 31 + H)
+    m = np.zeros((H, W, 4), np.float32)
+    m[:, :, 0] = rng.uniform(0, 1.2, (H, W))
+    m[:, :, 1:] = rng.uniform(0, 1, (H, W, 3))
+    xw, yh = W / ppm, H / ppm
+    r_c1, r_c2, trs = P.costmap_transform(-xw / 2 + 9.0, xw / 2 + 9.0, -yh / 2, yh / 2)
+    cfg = dict(S.make_config(256, 30, track="ring"), map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs)
+    _check_against_oracle(cfg, ("quad", "fused", "valu"))
+
+
+def test_handles_driven_from_concurrent_host_threads():
+    """Six handles (K = 256 ... 65 536), each driven by its own host thread (ctypes releases the GIL inside
+    the calls): 40 solve + slide ticks each, bit-identical to the same loops run one after the other."""
+    import threading
+    shapes = [(4096, 100, "oval"), (1024, 50, "ring"), (8192, 40, "oval"), (256, 77, "oval"), (65536, 20, "oval"),
+              (2048, 100, "ring")]
+    cfgs = [S.make_config(K, T, track=tr, instance=i) for i, (K, T, tr) in enumerate(shapes)]
+
+    def loop(cfg, out, idx):
+        sol = capi.Solver(cfg)
+        sol.seed(11 + idx, 0)
+        Us = []
+        for _ in range(40):
+            sol.compute_control(cfg["start_state"])
+            Us.append(sol.get_results(False)["U"].copy())
+            sol.slide_control_seq(1)
+        sol.close()
+        out[idx] = np.stack(Us)
+
+    single = {}
+    for i, c in enumerate(cfgs):
+        loop(c, single, i)
+    for _ in range(2):
+        multi = {}
+        th = [threading.Thread(target=loop, args=(c, multi, i)) for i, c in enumerate(cfgs)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for i in range(len(cfgs)):
+            np.testing.assert_array_equal(single[i].view(np.uint32), multi[i].view(np.uint32))
