@@ -56,7 +56,7 @@ SYMBOLS = [
     "mppi_set_costmap", "mppi_set_costmap_channel", "mppi_set_cost_params", "mppi_reset_controls",
     "mppi_set_control_seq", "mppi_get_control_seq", "mppi_set_control_hist", "mppi_get_control_hist",
     "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
-    "mppi_compute_control", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
+    "mppi_compute_control", "mppi_control_ticks", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
     "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
     "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_debug_cost_raster", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
@@ -107,6 +107,7 @@ def lib():
         L.mppi_generate_noise.argtypes = [hp, fp, C.c_size_t]
         L.mppi_compute_control.argtypes = [hp, fp]
         L.mppi_compute_control_async.argtypes = [hp, fp]
+        L.mppi_control_ticks.argtypes = [hp, fp, C.c_int, C.c_int]
         L.mppi_synchronize.argtypes = [hp]
         L.mppi_get_results.argtypes = [hp, fp, fp, fp, fp]
         L.mppi_get_applied_controls.argtypes = [hp, fp, C.c_size_t]
@@ -284,6 +285,10 @@ class Solver:
         def run(_keep=buf):
             ck(fn(h, ptr))
         return run
+
+    def control_ticks(self, state, n_ticks, stride=1):
+        """n_ticks x (compute_control + slide_control_seq(stride)) inside one library call."""
+        self._ck(self.L.mppi_control_ticks(self.h, _fp(_f32(state, (7,))), int(n_ticks), int(stride)))
 
     def compute_control_async(self, state):
         self._ck(self.L.mppi_compute_control_async(self.h, _fp(_f32(state, (7,)))))

@@ -1023,6 +1023,20 @@ int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM])
   return mppi_synchronize(h);
 }
 
+int mppi_control_ticks(mppi_handle *h, const float state[MPPI_STATE_DIM], int n_ticks, int stride)
+{
+  if (!h || n_ticks < 0 || stride < 0) return MPPI_ERR_INVALID;
+  for (int i = 0; i < n_ticks; i++) {
+    int rc = mppi_compute_control(h, state);
+    if (rc) return rc;
+    if (stride > 0) {
+      rc = mppi_slide_control_seq(h, stride);
+      if (rc) return rc;
+    }
+  }
+  return MPPI_OK;
+}
+
 int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, float *weights)
 {
   if (!h) return MPPI_ERR_INVALID;

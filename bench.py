@@ -177,6 +177,8 @@ def main():
                          "its build uses K=2560), with the shipped basis_function_09_12_2018.npz")
     ap.add_argument("--variant", type=str, default="auto")
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--loop", choices=("native", "python"), default="native",
+                    help="timed steps inside one library call (mppi_control_ticks) or one ctypes call per ABI call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the multi-process driver with gloo and the CPU oracle (no GPU, not a benchmark)")
@@ -219,8 +221,19 @@ def main():
         solve()
         sol.slide_control_seq(1)
 
-    for _ in range(args.warmup):
-        step()
+    native = cuda and args.loop == "native"
+
+    def run_steps(n):
+        # one step = computeControl(state) + slideControlSeq(1), result on the host before the next one
+        # starts.  "native": the n steps run inside one library call (mppi_control_ticks), as they would
+        # under a C++ caller like the reference's runControlLoop; "python": one ctypes call per ABI call.
+        if native:
+            sol.control_ticks(state, n, 1)
+        else:
+            for _ in range(n):
+                step()
+
+    run_steps(args.warmup)
     if cuda:
         sol.enable_stage_timing(16)  # HIP events on every 16th solve of the timed region
         sol.reset_stage_times()
@@ -228,8 +241,7 @@ def main():
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     sync()
     if dist is not None:
         dist.barrier()
@@ -260,6 +272,8 @@ def main():
                                       else "-".join(map(str, cfg["layers"])) + " NN"),
                        "K": K, "T": T, "layers": [] if cfg.get("bf_W") is not None else cfg["layers"], "num_iters": iters,
                        "rollout_variant": sol.rollout_variant() if cuda else "none",
+                       "step": "computeControl + slideControlSeq(1), result on the host before the next step",
+                       "timed_loop": ("native (mppi_control_ticks)" if native else "python (one ctypes call per ABI call)"),
                        "parallelism": "replicas x%d (no collective)" % world},
             "state_updates_per_s": value * T,
             "instances": instances,

@@ -153,6 +153,11 @@ int mppi_generate_noise(mppi_handle *h, float *eps_out, size_t n);
 /* MPPIController::computeControl(state) up to and including savitskyGolay()
  * (mppi_controller.cu:600-671); computeNominalTraj is mppi_nominal_traj. Blocking. */
 int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM]);
+/* n_ticks times { mppi_compute_control(state); mppi_slide_control_seq(stride) } without returning to the
+ * caller in between: the body of runControlLoop's tick for one controller (run_control_loop.cuh:207-219)
+ * for callers -- bench.py -- whose own per-call overhead (an interpreter, an FFI) would otherwise sit
+ * inside the solve-to-solve time.  stride = 0 skips the slide.  Stops at the first error. */
+int mppi_control_ticks(mppi_handle *h, const float state[MPPI_STATE_DIM], int n_ticks, int stride);
 /* Same solve, enqueued only; results are valid after mppi_synchronize. */
 int mppi_compute_control_async(mppi_handle *h, const float state[MPPI_STATE_DIM]);
 int mppi_synchronize(mppi_handle *h);

@@ -239,3 +239,25 @@ def test_debug_cost_raster_matches_oracle():
     with pytest.raises(capi.MppiError):
         sol._ck(sol.L.mppi_debug_cost_raster(sol.h, 0.0, 0.0, 0.0, 10, 10, 50, capi._fp(np.zeros(4, np.float32)), 4))
     sol.close()
+
+
+def test_control_ticks_equals_the_call_by_call_loop():
+    """mppi_control_ticks(n, stride) == n x (compute_control + slide_control_seq(stride)), bit for bit."""
+    cfg = S.make_config(1024, 50, track="ring")
+    a, b = capi.Solver(cfg), capi.Solver(cfg)
+    a.seed(99, 0)
+    b.seed(99, 0)
+    for _ in range(7):
+        a.compute_control(cfg["start_state"])
+        a.slide_control_seq(2)
+    b.control_ticks(cfg["start_state"], 7, 2)
+    np.testing.assert_array_equal(a.get_control_seq().view(np.uint32), b.get_control_seq().view(np.uint32))
+    np.testing.assert_array_equal(a.get_control_hist().view(np.uint32), b.get_control_hist().view(np.uint32))
+    assert a.get_results(False)["traj_cost"] == b.get_results(False)["traj_cost"]
+    b.control_ticks(cfg["start_state"], 0, 1)  # nothing
+    b.control_ticks(cfg["start_state"], 1, 0)  # solve without slide
+    a.compute_control(cfg["start_state"])
+    np.testing.assert_array_equal(a.get_control_seq().view(np.uint32), b.get_control_seq().view(np.uint32))
+    with pytest.raises(capi.MppiError):
+        b.control_ticks(cfg["start_state"], -1, 1)
+    a.close(); b.close()
