@@ -292,3 +292,33 @@ def test_handles_driven_from_concurrent_host_threads():
             t.join()
         for i in range(len(cfgs)):
             np.testing.assert_array_equal(single[i].view(np.uint32), multi[i].view(np.uint32))
+
+
+@pytest.mark.parametrize("family", ["nn", "bf"])
+def test_non_finite_and_huge_start_states(golden_dir, family):
+    """NaN / Inf / 1e30 in the measured state (a diverged state estimator): costs.cu:405-407 caps NaN and
+    > 1e12 costs at 1e12, positions outside the map clamp, the crash flags stick -- the kernels must follow
+    the oracle through every one of those branches and keep the control sequence finite."""
+    extra = {}
+    if family == "bf":
+        extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    variants = ["quad", "fused", "valu"] if family == "nn" else ["auto", "fused"]
+    for which, val in [(4, np.nan), (0, np.inf), (2, np.nan), (6, -np.inf), (4, 1e30), (0, 1e20)]:
+        cfg = S.make_config(256, 20, track="oval", **extra)
+        st = cfg["start_state"].copy()
+        st[which] = val
+        eps = noise_for(cfg)
+        U0 = warm_U(cfg)
+        ref = O.Oracle(cfg, fma_mode=1).compute_control(st, U0, np.zeros(4, np.float32), eps)
+        assert np.all(np.isfinite(ref["U"])) and np.all(ref["costs"] <= 1e12)
+        for v in variants:
+            sol = capi.Solver(cfg)
+            sol.set_rollout_variant(v)
+            sol.set_control_seq(U0)
+            sol.set_noise(eps)
+            sol.compute_control(st)
+            got = sol.get_results()
+            sol.close()
+            assert np.all(np.isfinite(got["U"])), (which, val, v)
+            np.testing.assert_allclose(got["costs"], ref["costs"], rtol=1e-5, err_msg=str((which, val, v)))
+            assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4, (which, val, v)
