@@ -10,6 +10,8 @@
 #include <limits>
 #include <memory>
 
+#include <immintrin.h>
+
 namespace mppi {
 namespace {
 
@@ -52,62 +54,79 @@ struct HostModel {
   }
 };
 
-// Host network: forward pass keeping the pre-activations (computeDynamics, neural_net_model.cu:201-230)
+// Host network: forward pass keeping the pre-activations (computeDynamics, neural_net_model.cu:201-230).
+// Eight output neurons (forward) / eight input neurons (backward) per AVX2 register; every sum keeps its
+// k-ascending order and its separate multiply and add (this file is compiled with -ffp-contract=off), so
+// the values are those of the plain loops -- only eight of them advance per instruction.
 struct HostNet : HostModel {
   const DdpNet &n;
-  std::vector<std::vector<float>> z;  // weighted_in_[l]
-  std::vector<std::vector<float>> th;  // tanh(weighted_in_[l]) of the hidden layers, kept for computeGrad
-  std::vector<size_t> woff, boff;
-  std::vector<float> a_, b_, d_, dn_;  // scratch (no allocation per call: this runs T times per solve)
-  explicit HostNet(const DdpNet &net)
-      : n(net), a_(net.max_width), b_(net.max_width), d_((size_t)net.max_width * 4), dn_((size_t)net.max_width * 4)
+  int L;                                // weight matrices
+  std::vector<int> pin, pout;           // layer widths rounded up to 8
+  std::vector<std::vector<float>> Wt;   // [l]: W^T, [nin][pout]   (forward: 8 outputs share a[k])
+  std::vector<std::vector<float>> Wp;   // [l]: W,   [nout][pin]   (backward: 8 inputs share d[k][c])
+  std::vector<std::vector<float>> bp;   // [l]: bias, [pout]
+  std::vector<std::vector<float>> th;   // tanh(weighted_in_[l]) of the hidden layers, kept for computeGrad
+  std::vector<float> a_, b_;            // activations (padded)
+  std::vector<float> d_, dn_;           // delta, struct of arrays: [4][pmax]
+  int pmax;
+  explicit HostNet(const DdpNet &net) : n(net), L(net.n_layers - 1)
   {
+    pmax = 8;
     size_t off = 0;
-    for (int l = 0; l + 1 < n.n_layers; l++) {
-      woff.push_back(off);
-      boff.push_back(off + (size_t)n.layers[l] * n.layers[l + 1]);
-      off += (size_t)n.layers[l] * n.layers[l + 1] + n.layers[l + 1];
-      z.emplace_back(n.layers[l + 1]);
-      th.emplace_back(n.layers[l + 1]);
+    for (int l = 0; l < L; l++) {
+      const int nin = n.layers[l], nout = n.layers[l + 1];
+      const int pi = (nin + 7) & ~7, po = (nout + 7) & ~7;
+      pin.push_back(pi);
+      pout.push_back(po);
+      pmax = std::max(pmax, std::max(pi, po));
+      const float *W = n.theta + off, *bias = W + (size_t)nin * nout;
+      off += (size_t)nin * nout + nout;
+      Wt.emplace_back((size_t)nin * po, 0.0f);
+      Wp.emplace_back((size_t)nout * pi, 0.0f);
+      bp.emplace_back(po, 0.0f);
+      for (int j = 0; j < nout; j++) {
+        bp[l][j] = bias[j];
+        for (int k = 0; k < nin; k++) {
+          Wt[l][(size_t)k * po + j] = W[(size_t)j * nin + k];
+          Wp[l][(size_t)j * pi + k] = W[(size_t)j * nin + k];
+        }
+      }
+      th.emplace_back(po, 0.0f);
     }
+    a_.assign(pmax, 0.0f);
+    b_.assign(pmax, 0.0f);
+    d_.assign((size_t)4 * pmax, 0.0f);
+    dn_.assign((size_t)4 * pmax, 0.0f);
   }
   // out[4] = network(s3..s6, u0, u1)
   void forward(const float *x, const float *u, float *out)
   {
-    std::vector<float> &a = a_, &b = b_;
+    float *a = a_.data(), *b = b_.data();
     for (int i = 0; i < 4; i++) a[i] = x[3 + i];
     a[4] = u[0];
     a[5] = u[1];
-    const int L = n.n_layers - 1;
     for (int l = 0; l < L; l++) {
-      const int nin = n.layers[l], nout = n.layers[l + 1];
-      const float *W = n.theta + woff[l], *bias = n.theta + boff[l];
-      // four output neurons at a time: four independent k-ascending chains (same sums, 4x the ILP)
-      int j = 0;
-      for (; j + 4 <= nout; j += 4) {
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        const float *w0 = W + (size_t)j * nin, *w1 = w0 + nin, *w2 = w1 + nin, *w3 = w2 + nin;
+      const int nin = n.layers[l], nout = n.layers[l + 1], po = pout[l];
+      const float *W = Wt[l].data(), *bias = bp[l].data();
+      // up to four registers of outputs advance together: four independent chains hide the add latency
+      for (int j0 = 0; j0 < po; j0 += 32) {
+        const int nb = std::min(4, (po - j0) / 8);
+        __m256 s[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
         for (int k = 0; k < nin; k++) {
-          const float ak = a[k];
-          s0 += w0[k] * ak;
-          s1 += w1[k] * ak;
-          s2 += w2[k] * ak;
-          s3 += w3[k] * ak;
+          const __m256 ak = _mm256_set1_ps(a[k]);
+          const float *w = W + (size_t)k * po + j0;
+          for (int q = 0; q < nb; q++) s[q] = _mm256_add_ps(s[q], _mm256_mul_ps(_mm256_loadu_ps(w + 8 * q), ak));
         }
-        const float sv[4] = {s0 + bias[j], s1 + bias[j + 1], s2 + bias[j + 2], s3 + bias[j + 3]};
-        for (int q = 0; q < 4; q++) {
-          z[l][j + q] = sv[q];
-          b[j + q] = (l < L - 1) ? (th[l][j + q] = std::tanh(sv[q])) : sv[q];
-        }
+        for (int q = 0; q < nb; q++)
+          _mm256_storeu_ps(b + j0 + 8 * q, _mm256_add_ps(s[q], _mm256_loadu_ps(bias + j0 + 8 * q)));
       }
-      for (; j < nout; j++) {
-        float s = 0.0f;
-        for (int k = 0; k < nin; k++) s += W[j * nin + k] * a[k];
-        s += bias[j];
-        z[l][j] = s;
-        b[j] = (l < L - 1) ? (th[l][j] = std::tanh(s)) : s;
+      if (l < L - 1) {
+        float *t = th[l].data();
+        // tanhf as in the reference's host code (MPPI_NNET_NONLINEARITY): the Riccati recursion amplifies a
+        // 1e-7 difference in these values to 1e-3 of the feedforward term at T = 250, so no fast substitute
+        for (int j = 0; j < nout; j++) b[j] = t[j] = std::tanh(b[j]);
       }
-      a.swap(b);
+      std::swap(a, b);
     }
     for (int i = 0; i < 4; i++) out[i] = a[i];
   }
@@ -126,7 +145,7 @@ struct HostNet : HostModel {
     forward(x, u, out);  // "First do the forward pass", neural_net_model.cu:243-244
     jacobian_after_f(p, x, u, J);
   }
-  // z / th hold the forward pass of this very (x, u): computeGrad's own forward pass would recompute them
+  // th holds the forward pass of this very (x, u): computeGrad's own forward pass would recompute it
   void jacobian_after_f(const DdpProblem &, const float *x, const float *, Mat<kDdpS, kDdpSC> &J) override
   {
     J.zero();
@@ -134,53 +153,37 @@ struct HostNet : HostModel {
     J.v[0][2] = -sn * x[4] - cs * x[5]; J.v[0][4] = cs; J.v[0][5] = -sn;
     J.v[1][2] = cs * x[4] - sn * x[5];  J.v[1][4] = sn; J.v[1][5] = cs;
     J.v[2][6] = -1.0f;  // regardless of negate_yaw_der (reference quirk)
-    const int L = n.n_layers - 1;  // weight matrices
-    // delta: [width of layer l+1... ][4], starts as the 4x4 identity at the output
-    std::vector<float> &d = d_, &dn = dn_;
-    std::fill(d.begin(), d.begin() + 16, 0.0f);
-    for (int i = 0; i < 4; i++) d[i * 4 + i] = 1.0f;
-    int rows = 4;  // == layers[L]
-    for (int l = L - 1; l > 0; l--) {
-      // delta <- (W_l^T delta) .* tanh'(z_{l-1})
-      const int nin = n.layers[l], nout = n.layers[l + 1];
-      const float *W = n.theta + woff[l];
-      // dn = W^T d, accumulated over k in ascending order for every (i, c) (rows of W are contiguous)
-      std::fill(dn.begin(), dn.begin() + (size_t)nin * 4, 0.0f);
-      for (int k = 0; k < nout; k++) {
-        const float *wk = W + (size_t)k * nin;
-        const float d0 = d[k * 4 + 0], d1 = d[k * 4 + 1], d2 = d[k * 4 + 2], d3 = d[k * 4 + 3];
-        for (int i = 0; i < nin; i++) {
-          const float wv = wk[i];
-          dn[i * 4 + 0] += wv * d0;
-          dn[i * 4 + 1] += wv * d1;
-          dn[i * 4 + 2] += wv * d2;
-          dn[i * 4 + 3] += wv * d3;
+    // delta[c][k]: derivative of output c wrt the (pre-activation of) neuron k of the current layer;
+    // starts as the 4 x 4 identity at the output
+    float *d = d_.data(), *dn = dn_.data();
+    const int P = pmax;
+    for (int c = 0; c < 4; c++)
+      for (int k = 0; k < 4; k++) d[c * P + k] = (c == k) ? 1.0f : 0.0f;
+    for (int l = L - 1; l >= 0; l--) {
+      // delta <- (W_l^T delta) [.* tanh'(z_{l-1}) for l > 0], accumulated over k in ascending order
+      const int nout = n.layers[l + 1], pi = pin[l];
+      const float *W = Wp[l].data();
+      for (int i = 0; i < pi; i += 8) {
+        // the four outputs' chains for these eight neurons advance together
+        __m256 s[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
+        for (int k = 0; k < nout; k++) {
+          const __m256 w = _mm256_loadu_ps(W + (size_t)k * pi + i);
+          for (int c = 0; c < 4; c++) s[c] = _mm256_add_ps(s[c], _mm256_mul_ps(w, _mm256_set1_ps(d[c * P + k])));
         }
+        if (l > 0) {
+          // MPPI_NNET_NONLINEARITY_DERIV: 1 - powf(tanh(z), 2); tanh(z) is the value the forward pass
+          // computed from the same z, and powf(x, 2) is the correctly rounded x*x
+          const __m256 tz = _mm256_loadu_ps(th[l - 1].data() + i);
+          const __m256 zp = _mm256_sub_ps(_mm256_set1_ps(1.0f), _mm256_mul_ps(tz, tz));
+          for (int c = 0; c < 4; c++) s[c] = _mm256_mul_ps(s[c], zp);
+        }
+        for (int c = 0; c < 4; c++) _mm256_storeu_ps(dn + c * P + i, s[c]);
       }
-      for (int i = 0; i < nin; i++) {
-        // MPPI_NNET_NONLINEARITY_DERIV: 1 - powf(tanh(z), 2); tanh(z) is the value the forward pass above
-        // just computed from the same z, and powf(x, 2) is the correctly rounded x*x
-        const float tz = th[l - 1][i];
-        const float zp = 1.0f - tz * tz;
-        for (int c = 0; c < 4; c++) dn[i * 4 + c] = dn[i * 4 + c] * zp;
-      }
-      d.swap(dn);
-      rows = nin;
+      std::swap(d, dn);
     }
-    (void)rows;
-    {
-      const int nin = n.layers[0], nout = n.layers[1];
-      const float *W = n.theta + woff[0];
-      std::fill(dn.begin(), dn.begin() + (size_t)nin * 4, 0.0f);
-      for (int k = 0; k < nout; k++) {
-        const float *wk = W + (size_t)k * nin;
-        for (int i = 0; i < nin; i++)
-          for (int c = 0; c < 4; c++) dn[i * 4 + c] += wk[i] * d[k * 4 + c];
-      }
-    }
-    // bottom-right 4 x 6 block += delta^T: rows = outputs, columns = [s3..s6, u0, u1]
+    // bottom-right 4 x 6 block += delta: rows = outputs, columns = [s3..s6, u0, u1]
     for (int o = 0; o < 4; o++)
-      for (int i = 0; i < 6; i++) J.v[3 + o][3 + i] += dn[i * 4 + o];
+      for (int i = 0; i < 6; i++) J.v[3 + o][3 + i] += d[o * P + i];
   }
 };
 
