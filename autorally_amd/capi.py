@@ -61,6 +61,7 @@ SYMBOLS = [
     "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_debug_cost_raster", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
+    "mppi_debug_inject_handover_fault",
 ]
 
 _lib = None
@@ -125,10 +126,12 @@ def lib():
         L.mppi_rollout_variant.argtypes = [hp]
         L.mppi_set_rollout_variant.argtypes = [hp, C.c_char_p]
         L.mppi_debug_dynamics.argtypes = [hp, C.c_int, fp, fp, fp]
-        for s in SYMBOLS:
-            fn = getattr(L, s)
-            if fn.restype is C.c_int and s not in ("mppi_abi_version", "mppi_device_count"):
-                pass
+        if hasattr(L, "mppi_debug_inject_handover_fault") or not os.environ.get("MPPI_LIB_PATH"):
+            # (an older library given through MPPI_LIB_PATH for a kernel A/B may lack this test hook)
+            L.mppi_debug_inject_handover_fault.argtypes = [hp, C.c_int, C.c_int]
+        for s in SYMBOLS:  # every declared symbol must be there (except in an older A/B library)
+            if s != "mppi_debug_inject_handover_fault" or not os.environ.get("MPPI_LIB_PATH"):
+                getattr(L, s)
         _lib = L
     return _lib
 
@@ -350,6 +353,9 @@ class Solver:
         out = np.zeros_like(states)
         self._ck(self.L.mppi_debug_dynamics(self.h, states.shape[0], _fp(states), _fp(controls), _fp(out)))
         return out
+
+    def debug_inject_handover_fault(self, wave, spin_budget):
+        self._ck(self.L.mppi_debug_inject_handover_fault(self.h, int(wave), int(spin_budget)))
 
     # --- measurement ---
     def enable_stage_timing(self, on=1):

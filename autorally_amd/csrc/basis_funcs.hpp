@@ -9,7 +9,7 @@
 // single IEEE operation carried out in double and rounded to float equals the fp32 operation
 // (p_double >= 2 p_float + 2); that quotient is computed with div_const (exact, see below).  The two sub-expressions that chain double operations --
 //   s5/s4 + .45*s6/s4   and   s5/s4 - .35*s6/s4
-// -- are evaluated in double as written.  powf(x, 2|3) are written as products.
+// -- are evaluated in double as written.  powf(x, 2|3): pow_2 / pow_3 below.
 #pragma once
 
 #include <math.h>
@@ -42,6 +42,30 @@ MPPI_HD double div_const_d(double x, double c, double rc)
   const double q0 = x * rc;
   const double r = fma(-q0, c, x);
   return fma(r, rc, q0);
+}
+
+// powf(x, 2) and powf(x, 3) of the source (car_bfs.cuh:63-64, 90-91, 103, 117-123).  The reference's host code
+// (GeneralizedLinear::computeDynamics on the host, generalized_linear.cu:140-167, behind updateState and the
+// numerical Jacobian of the DDP, ddp_dynamics.h:71-84) is compiled by g++ and calls the C library's powf;
+// the host replays here do the same, so that they evaluate f(z +- h) with the statement of the source (the
+// fp32 central differences turn every ulp of f into 1e-4 .. 1e-2 of a Jacobian entry, which 250 Riccati
+// steps amplify to tens of percent of a gain).  The device has no powf of that pedigree (CUDA's device
+// powf is a different, <= 2-ulp routine); the rollout kernel takes the correctly rounded products.
+MPPI_HD float pow_2(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return x * x;
+#else
+  return powf(x, 2);
+#endif
+}
+MPPI_HD float pow_3(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (x * x) * x;
+#else
+  return powf(x, 3);
+#endif
 }
 
 // The sub-expressions every basis function shares.
@@ -79,7 +103,7 @@ MPPI_HD void basis_funcs_from(const float *s, float u1, const BasisShared &c, fl
   const bool big = c.big;
   const float su = c.su, A = c.A, r54 = c.r54;
   const double B = c.B;
-  const float A3 = (A * A) * A;
+  const float A3 = pow_3(A);
   phi[0] = u1;
   phi[1] = MPPI_DIVC(s4, 10.0f);
   phi[2] = MPPI_DIVC(su * A, 1200.0f);
@@ -96,16 +120,16 @@ MPPI_HD void basis_funcs_from(const float *s, float u1, const BasisShared &c, fl
   phi[13] = big ? (float)div_const_d(B, 40.0, 1.0 / 40.0) : 0.0f;
   phi[14] = big ? (float)div_const_d(B * fabs(B), 1600.0, 1.0 / 1600.0) : 0.0f;
   const float Bf = (float)B;
-  phi[15] = big ? MPPI_DIVC((Bf * Bf) * Bf, 64000.0f) : 0.0f;
+  phi[15] = big ? MPPI_DIVC(pow_3(Bf), 64000.0f) : 0.0f;
   phi[16] = MPPI_DIVC(s6 * s4, 50.0f);
   phi[17] = s3;
   phi[18] = s3 * s6;
   phi[19] = MPPI_DIVC(s3 * s4, 3.0f);
   phi[20] = MPPI_DIVC(s3 * s4 * s6, 5.0f);
-  phi[21] = MPPI_DIVC(s4 * s4, 100.0f);
-  phi[22] = MPPI_DIVC((s4 * s4) * s4, 1000.0f);
-  phi[23] = u1 * u1;
-  phi[24] = (u1 * u1) * u1;
+  phi[21] = MPPI_DIVC(pow_2(s4), 100.0f);
+  phi[22] = MPPI_DIVC(pow_3(s4), 1000.0f);
+  phi[23] = pow_2(u1);
+  phi[24] = pow_3(u1);
 }
 
 // phi[0..24] = basisFuncX(i, s, u), host form

@@ -120,6 +120,7 @@ struct mppi_handle {
   bool pending_timed = false;
   float traj_cost = 0.0f, baseline = 0.0f, eta = 0.0f;
 
+  int spin_budget = 0, fault_wave = 0;  // mppi_debug_inject_handover_fault (0, 0: kSpinBudget, no fault)
   bool timing = false;
   int timing_every = 1;      // record stage events on every Nth solve only (events add launch gaps)
   unsigned timing_count = 0;
@@ -231,7 +232,11 @@ int effective_block(const mppi_handle *h)
   if (h->block_threads != 0) return h->block_threads;
   const int groups = h->K / kRolloutsPerWave;
   const int budget = (h->hidden <= 32) ? 2 * h->num_simds : h->num_simds;
-  return (4 * groups <= budget) ? 512 : 64;
+  // single-wave form in workgroups of FOUR waves: the dispatcher spreads the waves of one workgroup over
+  // the four SIMDs of a CU, whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD
+  // on paper (K = 16384) -- sometimes two on one SIMD and none on its neighbour, which doubles the kernel
+  // time (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us)
+  return (4 * groups <= budget) ? 512 : 256;
 }
 
 // basis-function model: dynamics wave + cost wave per 64 rollouts ("fused" / "block64" force the one-wave form)
@@ -300,6 +305,8 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.rng_in = nullptr;
   a.rng_out = nullptr;
   a.inline_noise = 0;
+  a.spin_budget = h->spin_budget;
+  a.fault_wave = h->fault_wave;
   fill_cost_args(h, a.cost);
 }
 
@@ -901,6 +908,10 @@ int mppi_get_control_seq(mppi_handle *h, float *U, size_t n)
 int mppi_set_control_hist(mppi_handle *h, const float hist[4])
 {
   if (!h || !hist) return MPPI_ERR_INVALID;
+  if (h->pending) {  // the pending solve's host-side smoothing still reads the old history
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
   memcpy(h->hist.data(), hist, 4 * sizeof(float));
   h->u_dirty = true;
   h->slid_valid = false;
@@ -916,11 +927,16 @@ int mppi_get_control_hist(mppi_handle *h, float hist[4])
 
 int mppi_slide_control_seq(mppi_handle *h, int stride)
 {
-  if (!h || stride < 1 || stride > h->T) return MPPI_ERR_INVALID;
+  if (!h || stride < 0 || stride > h->T) return MPPI_ERR_INVALID;
   if (h->pending) {
     int rc = mppi_synchronize(h);
     if (rc) return rc;
   }
+  // stride 0 (a control tick in which no new pose arrived, run_control_loop.cuh:208-216 calls
+  // slideControlAndStateSeq only for stride >= 0): the reference's loops copy U onto itself, overwrite
+  // nothing with init_u and -- taking its stride != 1 branch with t = -2 -- read control_hist_ from
+  // before U_; nothing is defined to change, so nothing changes here.
+  if (stride == 0) return MPPI_OK;
   // mppi_controller.cu:527-554
   float *U = h->U.data(), *hist = h->hist.data();
   const int T = h->T;
@@ -1312,6 +1328,17 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   else if (strcmp(name, "fused") == 0 || strcmp(name, "block64") == 0) h->block_threads = 64;
   else if (strcmp(name, "block256") == 0) h->block_threads = 256;
   else return fail(h, MPPI_ERR_INVALID, "unknown variant");
+  return MPPI_OK;
+}
+
+/* Debug/test entry (not part of the drop-in surface): one wavefront role of the multi-wavefront rollout
+ * kernels starts with an exhausted poll budget (it never waits), to prove that a starved wave -- whichever
+ * it is -- turns into MPPI_ERR_HIP and not into finite, wrong costs. */
+int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget)
+{
+  if (!h || wave < 0 || wave > 8 || spin_budget < 0) return MPPI_ERR_INVALID;
+  h->fault_wave = wave;
+  h->spin_budget = spin_budget;
   return MPPI_OK;
 }
 

@@ -49,6 +49,10 @@ struct RolloutArgs {
   int K, T, opt_delay, k99;
   float nu[2], u_lo[2], u_hi[2], dt;
   int negate_yaw_der;
+  // hand-over waits (multi-wavefront kernels): polls a wave may spend on all its waits (0: kSpinBudget),
+  // and -- tests only -- the wavefront role (1-based, 0 = none) that starts with that budget exhausted
+  // (mppi_debug_inject_handover_fault)
+  int spin_budget, fault_wave;
   CostArgs cost;
 };
 
@@ -229,8 +233,14 @@ __device__ __forceinline__ float running_mean(float J, float c, int t, double rt
 }
 
 // ---- hand-over between the wavefronts of a workgroup through LDS sequence words ----
-// Every spin loop draws on a per-wave budget; when it is exhausted the wave stops waiting and the costs
-// are poisoned with NaN (a loud failure instead of a hung GPU).
+// Every wait draws on the wave's budget of polls (RolloutArgs::spin_budget, kSpinBudget + 64 T by default).
+// A wave whose budget runs out stops waiting for good -- a loud failure instead of a hung GPU: it carries
+// on with whatever the LDS holds (so the other waves never starve because of it) and, when it is through
+// its T steps, raises the WORKGROUP'S FAIL WORD and then its own "finished" word.  The cost wave, the one
+// that writes the results, waits for the finished words of all other waves of the group (that costs it
+// nothing: the kernel cannot end before they do) and poisons the costs of the whole group with NaN if the
+// fail word is up or its own budget ran out -- whichever wave starved.  The host turns the NaN into
+// MPPI_ERR_HIP (eta is not >= 1).
 constexpr int kSpinBudget = 1 << 22;
 
 // The hand-over instructions are written as ds_* assembly: they must reach the LDS in exactly this
@@ -255,5 +265,20 @@ __device__ __forceinline__ int lds_peek(uint32_t addr)
   int v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
   return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Budget of one wavefront's waits (all of them together): `while (<not yet there> && --budget > 0) poll;`.
+// fault_wave (tests) starts one role with an exhausted budget: it then never waits for anybody, which is
+// exactly what a wave that gave up does, and is reported like one.
+__device__ __forceinline__ int spin_budget_init(int spin_budget, int T, bool inject_fault)
+{
+  if (inject_fault) return 0;
+  return (spin_budget > 0 ? spin_budget : kSpinBudget) + 64 * T;
+}
+// Last thing a wave does: raise the fail word if any of its waits gave up, then its "finished" word.
+__device__ __forceinline__ void spin_finish(int budget, uint32_t a_fail, uint32_t a_fin)
+{
+  if (budget <= 0) lds_publish(a_fail, 1);
+  lds_publish(a_fin, 1);
 }
 }  // namespace mppi

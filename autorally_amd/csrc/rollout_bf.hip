@@ -155,16 +155,16 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
 {
   __shared__ __attribute__((aligned(16))) float W_s[4 * kNumBfs];  // transposed: [25][4]
   __shared__ float rec[kBfRing][8][kBfLanes];  // [slot][field][lane]: s3 s4 s5 s6 u0 u1 du0 du1
-  __shared__ int pub[kBfLanes], done[kBfLanes];
+  __shared__ int pub[kBfLanes], done[kBfLanes], fail[4], fin[4];
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;  // wave-uniform
   for (int i = threadIdx.x; i < 4 * kNumBfs; i += 2 * kBfLanes) W_s[(i % kNumBfs) * 4 + i / kNumBfs] = a.wpack[i];
-  if (role == 0) { pub[lane] = 0; done[lane] = 0; }
+  if (role == 0) { pub[lane] = 0; done[lane] = 0; fail[lane & 3] = 0; fin[lane & 3] = 0; }
   __syncthreads();  // the only barrier
   const int k = blockIdx.x * kBfLanes + lane;
   const int K = a.K, T = a.T;
   const uint32_t a_pub = lds_addr(&pub[0]), a_done = lds_addr(&done[0]);
-  int budget = kSpinBudget;
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == role + 1);  // mppi_device.hpp
 
   if (role == 0) {
     // ------------------------------ dynamics wave ------------------------------
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
 #pragma unroll
       for (int i = 0; i < 4; i++) s[3 + i] = fmaf(d[i], a.dt, s[3 + i]);
     }
+    spin_finish(budget, lds_addr(&fail[0]), lds_addr(&fin[0]));
   } else {
     // -------------------------------- cost wave --------------------------------
     const uint32_t a_mydone = lds_addr(&done[lane]);
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
       }
       tf_p = tf; tb_p = tb; ct_p = ct; rc_p = rc; rt_p = rt;
     }
-    if (budget <= 0) J = __builtin_nanf("");  // a hand-over never arrived: poison, do not hang
+    // a hand-over that never arrived, in either wave: poison, do not hang (mppi_device.hpp)
+    while (lds_peek(lds_addr(&fin[0])) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    if (budget <= 0 || lds_peek(lds_addr(&fail[0])) != 0) J = __builtin_nanf("");
     a.costs[k] = J + 0.0f;
   }
 }

@@ -266,8 +266,9 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
 //     per step they read one LDS word (their layer-0 B operand [u0,u1,0,0][g]);
 //   * wave 2 is the cost wave, software-pipelined by one step around its two costmap fetches.
 // Rings of kRing steps decouple the waves; in steady state only the two dynamics waves wait, and
-// only for each other.  Every spin loop draws on a per-wave budget; when it is exhausted the wave
-// stops waiting and the costs are poisoned with NaN (a loud failure instead of a hung GPU).
+// only for each other.  Every spin loop draws on a per-wave budget; a wave that exhausts it stops
+// waiting and raises the group's fail word, and the cost wave poisons the costs with NaN
+// (mppi_device.hpp): a loud failure instead of a hung GPU, whichever of the four waves starved.
 // Arithmetic and its order are those of the other kernel forms: results are bit-identical.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 16;  // steps in flight between the waves (power of two)
@@ -311,6 +312,8 @@ struct QuadShared {
   float ctl_b1[kRing][64];                 // layer-0 B operand of k-step 1, [u0c, u1c, 0, 0][g] per rollout
   float ctl_rec[kRing][kRolloutsPerWave][4];  // clamped u0, u1, du0, du1 for the cost wave
   int ctl_pub[64];                         // steps published by the control wave
+  int fail[4];                             // word 0: raised by a wave whose waits ran out of budget (mppi_device.hpp)
+  int fin[4];                              // word r: wave r is through its T steps
 };
 
 template <int H, int NHID, int W>
@@ -354,7 +357,7 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
   constexpr uint32_t kXbParity = 2 * 64 * NX * 4, kB1Slot = 64 * 4;
 
   float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
-  int budget = kSpinBudget;
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == W + 1);
   while (lds_peek(a_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   float b1_next = sh.ctl_b1[0][lane];
   int cd = 0;  // last value seen of the cost wave's consumption counter
@@ -461,6 +464,7 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
     s5 = fmaf(o[2] + BL[2], a.dt, s5);
     s6 = fmaf(o[3] + BL[3], a.dt, s6);
   }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[W]));
 }
 
 template <int H, int NHID, bool AFFINE, bool CTRL>
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
   const int k = blockIdx.x * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
   // sequence words start at 0, the constant rows of the layer-0 operand at 0; the only barrier
-  if (role == 0) { sh.xseq[0][lane] = 0; sh.xseq[1][lane] = 0; sh.cost_done[lane] = 0; sh.ctl_pub[lane] = 0; }
+  if (role == 0) { sh.xseq[0][lane] = 0; sh.xseq[1][lane] = 0; sh.cost_done[lane] = 0; sh.ctl_pub[lane] = 0; sh.fail[lane & 3] = 0; sh.fin[lane & 3] = 0; }
   if (role == 3)
     for (int q = 0; q < kRing; q++) sh.ctl_b1[q][lane] = 0.0f;
   __syncthreads();
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
     const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]), a_seq1 = lds_addr(&sh.xseq[1][0]);
     const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
     const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
-    int budget = kSpinBudget;
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == 4);
     int seen_x = 0, seen_c = 0;  // swaps published by both dynamics waves / steps consumed by the cost wave
     for (int t0 = 0; t0 < T; t0 += kCtlChunk) {
       // the chunk's nominal controls and (explicit noise) eps are requested together
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
       a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
       a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
     }
+    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[3]));
   } else if (role == 2) {
     // -------------------------------- cost wave --------------------------------
     // Software-pipelined by one step: the costmap texels of step t are requested in iteration t and
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
     const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]);
     const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
     float x = a.state[0], y = a.state[1], yaw = a.state[2];
-    int crash = 0, budget = kSpinBudget, seen = 0;
+    int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == 3), seen = 0;
     float J = 0.0f;
     float tf_p = 0.0f, tb_p = 0.0f;
     CostTerms ct_p{0.0f, 0.0f, 0.0f};
@@ -600,7 +605,13 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
       }
       tf_p = tf; tb_p = tb; ct_p = ct; rc_p = rc; rt_p = rt;
     }
-    if (budget <= 0) J = __builtin_nanf("");  // a hand-over never arrived: poison, do not hang
+    // a hand-over that never arrived, in ANY wave of the group: poison, do not hang (mppi_device.hpp).
+    // The other three raise the fail word before their finished word; the kernel cannot end before they do.
+    {
+      const uint32_t a_f0 = lds_addr(&sh.fin[0]), a_f1 = lds_addr(&sh.fin[1]), a_f3 = lds_addr(&sh.fin[3]);
+      while ((lds_peek(a_f0) & lds_peek(a_f1) & lds_peek(a_f3)) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+      if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
+    }
     a.costs[k] = J + 0.0f;
   } else if (role == 0) {
     quad_dynamics<H, NHID, 0>(a, sh);

@@ -179,6 +179,13 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--loop", choices=("native", "python"), default="native",
                     help="timed steps inside one library call (mppi_control_ticks) or one ctypes call per ABI call")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="timed blocks of --steps steps; the FIRST is the reported value / ms_per_step, all of them "
+                         "give median / min / max (extra keys)")
+    ap.add_argument("--latency-solves", type=int, default=200,
+                    help="separate pass after the timed region: steps timed one by one (median solve latency)")
+    ap.add_argument("--event-solves", type=int, default=64,
+                    help="separate pass after the timed region: solves with HIP events around every stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the multi-process driver with gloo and the CPU oracle (no GPU, not a benchmark)")
@@ -233,19 +240,45 @@ def main():
             for _ in range(n):
                 step()
 
+    def timed_block():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        return max_over_ranks(dist, time.perf_counter() - t0, cuda)
+
     run_steps(args.warmup)
+    # the contract's timed region: no event records, no per-step host timing inside it
+    elapsed = timed_block()
+    # the same block repeated (off the headline number): spread of the measurement
+    block_s = [elapsed] + [timed_block() for _ in range(max(0, args.repeats - 1))]
+    # separate pass 1: every step timed on its own (one ctypes call per ABI call): median solve latency
+    per_solve_ms = None
+    if cuda and rank == 0 and args.latency_solves > 0:
+        lat = []
+        for _ in range(args.latency_solves):
+            t1 = time.perf_counter()
+            step()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        lat = np.sort(np.asarray(lat))
+        per_solve_ms = {"n": int(lat.size), "median": float(np.median(lat)), "p10": float(lat[int(0.1 * lat.size)]),
+                        "p90": float(lat[int(0.9 * lat.size)]), "min": float(lat[0]), "max": float(lat[-1])}
+    # separate pass 2: HIP events around the stages of every solve (they lengthen the launch gaps, so
+    # they stay out of the timed region); the rollout kernel's duration feeds the roofline block
     if cuda:
-        sol.enable_stage_timing(16)  # HIP events on every 16th solve of the timed region
+        sol.enable_stage_timing(1)
         sol.reset_stage_times()
+        run_steps(args.event_solves)
+        sync()
+        stage_times = sol.get_stage_times()
+        sol.enable_stage_timing(0)
     if dist is not None:
         dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = max_over_ranks(dist, time.perf_counter() - t0, cuda)
 
     # what every rank ran (proves the instances are distinct), gathered off the timed region
     mine = {"rank": rank, "start_state": [round(float(x), 4) for x in cfg["start_state"]],
@@ -276,10 +309,16 @@ def main():
                        "timed_loop": ("native (mppi_control_ticks)" if native else "python (one ctypes call per ABI call)"),
                        "parallelism": "replicas x%d (no collective)" % world},
             "state_updates_per_s": value * T,
+            "repeats": len(block_s),
+            "median_ms_per_step": 1e3 * float(np.median(block_s)) / args.steps,
+            "min_ms_per_step": 1e3 * min(block_s) / args.steps,
+            "max_ms_per_step": 1e3 * max(block_s) / args.steps,
+            "median_value": K * iters * args.steps * world / float(np.median(block_s)),
+            "per_solve_ms": per_solve_ms,
             "instances": instances,
         }
         if cuda:
-            st = sol.get_stage_times()
+            st = stage_times
             n = max(1, st["n_solves"])
             rollout_s = st["rollout_ms"] * 1e-3 / n / iters
             fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
@@ -287,6 +326,7 @@ def main():
             variant = sol.rollout_variant()
             bpu = ROLLOUT_BYTES_INLINE_NOISE if ("quad" in variant) else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
+            out["stage_ms"]["note"] = "HIP events on the handle's stream around every stage of %d solves, separate pass after the timed region" % n
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(cfg, variant),

@@ -218,6 +218,15 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name);
  * computeDynamics, neural_net_model.cu:346-410); ders is [n][7]. */
 int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float *controls, float *ders);
 
+/* Test hook (not part of the drop-in surface): from the next solve on, wavefront role `wave` of the
+ * multi-wavefront rollout kernels starts with an exhausted poll budget, i.e. it never waits for its
+ * partners -- the state of a wave that gave up on a hand-over -- and every other wave may spend
+ * spin_budget + 64 T polls in total (0: the default).  Roles of the four-wavefront network kernel: 1, 2 =
+ * dynamics waves, 3 = cost wave, 4 = control wave; of the two-wavefront basis-function kernel: 1 = dynamics,
+ * 2 = cost.  The solve must then end in MPPI_ERR_HIP ("hand-over failed"), never in finite costs.
+ * wave = 0 and spin_budget = 0 restore normal operation. */
+int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
+
 #ifdef __cplusplus
 }
 #endif

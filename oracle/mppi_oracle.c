@@ -80,6 +80,18 @@ void orc_nn_forward(const float *theta, const int *layers, int n_layers, const f
 /* CarBasisFuncs::basisFuncX, car_bfs.cuh:44-120.  Literals like 10.0 / .45 are double in the
  * source, so those sub-expressions are evaluated in double and rounded on assignment to the float
  * phi, exactly as a C compiler does; 1960000 / 2744000000 are integer literals (float division). */
+/* Test knob: 1 = powf(x, 2|3) evaluated as the correctly rounded products x*x, (x*x)*x instead of the C
+ * library's powf -- an ulp-level restatement of 7 of the 25 functions, used by tests/test_ddp.py to show how
+ * far such a change moves the feedback gains through the fp32 numerical Jacobian (the product's host replays
+ * follow the source and call powf; its device kernel takes the products). */
+static int g_bf_pow_products = 0;
+void orc_set_bf_pow_products(int on) { g_bf_pow_products = on; }
+static inline float orc_powf(float x, int n)
+{
+  if (!g_bf_pow_products) return powf(x, n);
+  return n == 2 ? x * x : (x * x) * x;
+}
+
 float orc_basis_func(int idx, const float *s, const float *u)
 {
   float phi = 0;
@@ -91,8 +103,8 @@ float orc_basis_func(int idx, const float *s, const float *u)
     case 3: phi = (s[4] > .1) ? sinf(u[0]) * tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]) *
                                     fabsf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0])) / 1440000.0
                               : sinf(u[0]) * tanf(-u[0]) * fabsf(tanf(-u[0])) / 1440000.0; break;
-    case 4: phi = (s[4] > .1) ? sinf(u[0]) * powf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]), 3) / 1728000000.0
-                              : sinf(u[0]) * powf(tanf(-u[0]), 3) / 1728000000.0; break;
+    case 4: phi = (s[4] > .1) ? sinf(u[0]) * orc_powf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]), 3) / 1728000000.0
+                              : sinf(u[0]) * orc_powf(tanf(-u[0]), 3) / 1728000000.0; break;
     case 5: phi = s[6] * s[5] / 25.0; break;
     case 6: phi = s[6] / 10.0; break;
     case 7: phi = s[5] / 10.0; break;
@@ -103,20 +115,20 @@ float orc_basis_func(int idx, const float *s, const float *u)
     case 11: phi = (s[4] > .1) ? tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]) *
                                      fabsf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0])) / 1960000
                                : tanf(-u[0]) * fabsf(tanf(-u[0])) / 1960000; break;
-    case 12: phi = (s[4] > .1) ? powf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]), 3) / 2744000000
-                               : powf(tanf(-u[0]), 3) / 2744000000; break;
+    case 12: phi = (s[4] > .1) ? orc_powf(tanf(atanf(s[5] / s[4] + .45 * s[6] / s[4]) - u[0]), 3) / 2744000000
+                               : orc_powf(tanf(-u[0]), 3) / 2744000000; break;
     case 13: phi = (s[4] > .1) ? (s[5] / s[4] - .35 * s[6] / s[4]) / 40.0 : 0; break;
     case 14: phi = (s[4] > .1) ? (s[5] / s[4] - .35 * s[6] / s[4]) * fabs(s[5] / s[4] - .35 * s[6] / s[4]) / 1600.0 : 0; break;
-    case 15: phi = (s[4] > .1) ? powf(s[5] / s[4] - .35 * s[6] / s[4], 3) / 64000.0 : 0; break;
+    case 15: phi = (s[4] > .1) ? orc_powf(s[5] / s[4] - .35 * s[6] / s[4], 3) / 64000.0 : 0; break;
     case 16: phi = s[6] * s[4] / 50.0; break;
     case 17: phi = s[3]; break;
     case 18: phi = s[3] * s[6]; break;
     case 19: phi = s[3] * s[4] / 3.0; break;
     case 20: phi = s[3] * s[4] * s[6] / 5.0; break;
-    case 21: phi = powf(s[4], 2) / 100.0; break;
-    case 22: phi = powf(s[4], 3) / 1000.0; break;
-    case 23: phi = powf(u[1], 2); break;
-    case 24: phi = powf(u[1], 3); break;
+    case 21: phi = orc_powf(s[4], 2) / 100.0; break;
+    case 22: phi = orc_powf(s[4], 3) / 1000.0; break;
+    case 23: phi = orc_powf(u[1], 2); break;
+    case 24: phi = orc_powf(u[1], 3); break;
   }
   return phi;
 }

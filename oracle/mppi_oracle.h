@@ -79,6 +79,7 @@ typedef struct {
 #define ORC_NUM_BFS 25
 /* CarBasisFuncs::basisFuncX, car_bfs.cuh:44-120 (source types kept: double where the literal is) */
 float orc_basis_func(int idx, const float *s, const float *u);
+void orc_set_bf_pow_products(int on); /* test knob, see mppi_oracle.c */
 
 /* OpenMP team size used by loops that have no orc_problem (weighted reduction). */
 void orc_set_num_threads(int n);

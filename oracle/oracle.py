@@ -118,6 +118,7 @@ def lib():
         L.orc_box_muller.argtypes = [C.c_float, C.c_float, fp, fp]
         L.orc_generate_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, fp]
         L.orc_basis_func.restype = C.c_float
+        L.orc_set_bf_pow_products.argtypes = [C.c_int]
         L.orc_basis_func.argtypes = [C.c_int, fp, fp]
         L.orc_ddp_feedback_gains.restype = C.c_int
         L.orc_ddp_feedback_gains.argtypes = [fp, ip, C.c_int, C.c_int, C.c_float, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp,

@@ -44,7 +44,8 @@ def test_error_convention_and_call_order():
     assert L.mppi_get_control_seq(h, _fp(U), 39) == capi.ERR_INVALID
     assert np.all(U == 7.0)  # outputs untouched on error
     assert L.mppi_set_noise(h, _fp(np.zeros(10, np.float32)), 10) == capi.ERR_INVALID
-    assert L.mppi_slide_control_seq(h, 0) == capi.ERR_INVALID
+    assert L.mppi_slide_control_seq(h, -1) == capi.ERR_INVALID
+    assert L.mppi_slide_control_seq(h, 21) == capi.ERR_INVALID
     assert L.mppi_set_rollout_variant(h, b"nonsense") == capi.ERR_INVALID
     assert L.mppi_destroy(h) == capi.OK
     assert L.mppi_destroy(None) == capi.ERR_INVALID
@@ -261,3 +262,62 @@ def test_control_ticks_equals_the_call_by_call_loop():
     with pytest.raises(capi.MppiError):
         b.control_ticks(cfg["start_state"], -1, 1)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2)])
+def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, family, wave):
+    """The multi-wavefront rollout kernels hand data over through LDS sequence words; a wave whose wait runs
+    out of its poll budget carries on with whatever the LDS holds.  Whichever role that is -- a dynamics
+    wave, the cost wave, the control wave -- the workgroup's fail word must poison the costs, so that the
+    solve returns MPPI_ERR_HIP instead of finite, wrong controls (round 1 poisoned from the cost wave only).
+    The hook starts one role with an exhausted poll budget: it never waits for its partners."""
+    import os
+    extra = {}
+    if family == "bf":
+        extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    elif family == "nn64":
+        l, th = P.synthetic_model([6, 64, 64, 4], seed=4)
+        extra = dict(layers=l, theta=th)
+    cfg = S.make_config(256, 40, track="oval", **extra)
+    sol = capi.Solver(cfg)
+    if family != "bf":
+        sol.set_rollout_variant("quad")
+    sol.compute_control(cfg["start_state"])          # healthy
+    good = sol.get_results()
+    assert np.all(np.isfinite(good["costs"])) and np.all(np.isfinite(good["U"]))
+    sol.debug_inject_handover_fault(wave, 32)
+    with pytest.raises(capi.MppiError) as e:
+        sol.compute_control(cfg["start_state"])
+    assert e.value.status == capi.ERR_HIP and "hand-over" in str(e.value)
+    costs = sol.rollout_only(cfg["start_state"])     # the kernel alone: every workgroup poisoned its costs
+    assert np.all(np.isnan(costs))
+    sol.debug_inject_handover_fault(0, 0)            # back to normal: the handle keeps working
+    sol.reset_controls()
+    sol.seed(cfg.get("seed", 1234), 0)
+    sol.compute_control(cfg["start_state"])
+    again = sol.get_results()
+    np.testing.assert_array_equal(again["costs"].view(np.uint32), good["costs"].view(np.uint32))
+    np.testing.assert_array_equal(again["U"].view(np.uint32), good["U"].view(np.uint32))
+    sol.close()
+
+
+def test_slide_by_zero_is_a_no_op_and_hist_waits_for_a_pending_solve():
+    """stride 0 (a tick without a new pose, run_control_loop.cuh:208-216) changes nothing; set_control_hist
+    during an asynchronous solve waits for it, so that solve is still smoothed with the history it ran with."""
+    cfg = S.make_config(512, 30, track="ring")
+    sol = capi.Solver(cfg)
+    U0 = warm_U(cfg)
+    hist = np.array([0.01, 0.2, -0.02, 0.25], np.float32)
+    sol.set_control_seq(U0)
+    sol.set_control_hist(hist)
+    sol.slide_control_seq(0)
+    np.testing.assert_array_equal(sol.get_control_seq(), U0)
+    np.testing.assert_array_equal(sol.get_control_hist(), hist)
+    eps = noise_for(cfg)
+    sol.set_noise(eps)
+    sol.compute_control_async(cfg["start_state"])
+    sol.set_control_hist(np.zeros(4, np.float32))  # must not leak into the pending solve's smoothing
+    got = sol.get_results(with_vectors=False)
+    ref = O.Oracle(cfg, fma_mode=1).compute_control(cfg["start_state"], U0, hist, eps)
+    assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
+    sol.close()

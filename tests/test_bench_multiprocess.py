@@ -19,6 +19,9 @@ def test_bench_two_ranks_gloo():
     assert len(lines) == 1, r.stdout  # rank 0 prints ONE json line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    # the timed block is repeated off the headline number: the first block is `ms_per_step`, all give the spread
+    assert d["repeats"] == 10 and d["min_ms_per_step"] <= d["median_ms_per_step"] <= d["max_ms_per_step"]
+    assert d["min_ms_per_step"] <= d["ms_per_step"] <= d["max_ms_per_step"]
     # whole-job aggregate: units of ALL ranks over the max-over-ranks time
     assert abs(d["value"] - 128 * 3 * 2 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
     a, b = d["instances"]

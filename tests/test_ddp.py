@@ -128,6 +128,44 @@ def test_oracle_jacobian_quirk_and_fd():
     assert np.max(np.abs(r["feedback"] - K64)) > 1e-2 * np.abs(K64).max()
 
 
+def test_bf_numerical_jacobian_is_ulp_sensitive(golden_dir):
+    """Why the host replays of the basis-function model must evaluate f with the statement of the source.
+    GeneralizedLinear has no computeGrad, so DDP takes fp32 central differences with h = sqrt(eps)|z|
+    (ddp_dynamics.h:71-84): a one-ulp change of f is 1e-4 ... 1e-2 of a Jacobian entry, and the Riccati
+    recursion amplifies it with the horizon.  Here the oracle is run twice on the drawn problem of round 1's
+    failing fuzz case (T = 250, hz = 100): with the C library's powf(x, 2|3) as in car_bfs.cuh, and with the
+    correctly rounded products x*x, (x*x)*x -- identical to <= 1 ulp in 7 of the 25 functions.  The gains move
+    by percent at T = 250 and by far less at short horizons: two faithful restatements on different math
+    libraries cannot agree better than this, so the product's host code follows the source literally (powf)
+    and is then bit-identical to the oracle (test_product_matches_oracle_on_random_problems, T = 250 included).
+    This spread, not 3e-2, is the parity bound of row f2 for this model against any other libm."""
+    import os
+    W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    spread = {}
+    for T in (5, 40, 100, 250):
+        rng = np.random.RandomState(5033)
+        cfg = S.make_config(64, T, track="oval", bf_W=W, negate_yaw_der=True, hz=100)
+        x0 = cfg["start_state"].copy()
+        x0[4], x0[5], x0[6], x0[3], x0[2] = rng.uniform(0.5, 12), rng.uniform(-1, 1), rng.uniform(-1.5, 1.5), rng.uniform(-0.2, 0.2), rng.uniform(-3, 3)
+        U = np.clip(warm_U(cfg, seed=33) * 1.3, cfg["u_lo"], cfg["u_hi"]).astype(np.float32)
+        Q = rng.uniform(0.1, 1, 7).astype(np.float32)
+        R = rng.uniform(0.5, 20, 2).astype(np.float32)
+        Qf = np.zeros(7, np.float32)
+        orc = O.Oracle(cfg)
+        xs, us = orc.nominal_traj(x0, U)
+        a = orc.ddp_feedback_gains(x0, xs, us, Q, R, Qf)
+        O.lib().orc_set_bf_pow_products(1)
+        try:
+            xs2, us2 = orc.nominal_traj(x0, U)
+            b = orc.ddp_feedback_gains(x0, xs, us, Q, R, Qf)
+        finally:
+            O.lib().orc_set_bf_pow_products(0)
+        assert np.max(np.abs(xs2 - xs)) < 1e-4          # the trajectories themselves agree to rounding
+        spread[T] = float(np.max(np.abs(a["feedback"] - b["feedback"])) / np.abs(a["feedback"]).max())
+    assert spread[5] < 5e-3 and spread[250] > 10 * spread[5], spread   # grows with the horizon
+    assert spread[250] > 2e-4, spread                       # far above the 2e-4 the network model is held to
+
+
 # ------------------------------------------------------------------ product (needs a device handle)
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,layers,negate", [(100, None, True), (30, [6, 64, 64, 4], True), (25, [6, 16, 8, 4], False)])
@@ -173,7 +211,10 @@ def test_product_matches_oracle_on_random_problems(golden_dir):
     """80 drawn problems: layer lists (MFMA and generic shapes), T = 2 ... 250, control rate, limits,
     negate_yaw_der, start states, control sequences, DDP weights (zero entries included), targets on and off
     the nominal trajectory.  The basis-function model uses the numerical Jacobian (ddp_dynamics.h:71-84),
-    whose float32 differences are amplified by the Riccati recursion: looser bound, T <= 100."""
+    whose float32 differences the Riccati recursion amplifies (test_bf_numerical_jacobian_is_ulp_sensitive):
+    round 1 saw 8 % / 28 % at T = 250 because the host replay wrote powf(x, 3) as (x*x)*x.  It now calls powf
+    like the source and like the oracle, every other operation already matched, so this model is held to the
+    same bound as the network at every horizon."""
     import os
     from autorally_amd import capi, params as P
     W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
@@ -186,7 +227,7 @@ def test_product_matches_oracle_on_random_problems(golden_dir):
         if rng.rand() < 0.3:
             over.update(u_lo=(-0.6, -0.3), u_hi=(0.7, 0.4))
         if layers == "bf":
-            cfg = S.make_config(64, min(T, 100), track="oval", bf_W=W, **over)
+            cfg = S.make_config(64, T, track="oval", bf_W=W, **over)
         else:
             cfg = S.make_config(64, T, layers=layers, track="oval", seed_model=int(rng.randint(100)), **over)
         x0 = cfg["start_state"].copy()
@@ -209,7 +250,7 @@ def test_product_matches_oracle_on_random_problems(golden_dir):
             got = sol.compute_feedback_gains(x0)
             ref = orc.ddp_feedback_gains(x0, xs, us, Q, R, Qf)
         sol.close()
-        tol = 3e-2 if layers == "bf" else 2e-4
+        tol = 2e-4
         tag = (case, T, layers)
         assert np.all(np.isfinite(got["feedback"])), tag
         assert np.max(np.abs(got["feedback"] - ref["feedback"])) <= tol * max(np.abs(ref["feedback"]).max(), 1e-6), tag

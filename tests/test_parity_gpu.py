@@ -128,6 +128,31 @@ def test_rollout_costs_and_controls(K, T, track, layers, variant):
     assert abs(tc - got["traj_cost"]) <= 1e-5 * abs(tc)
 
 
+@pytest.mark.parametrize("instance", range(8))
+def test_config5_eight_independent_instances(instance):
+    """BASELINE.json configs[4]: eight MPPI instances (distinct start states + costmaps: the oval rotated
+    by 0.35 rad and shifted per instance, each inside its own recentred map), K=4096 T=100 each.  On the
+    8-GPU node they run one per GPU with no collective (bench.py --gpus 8 uses exactly
+    make_config(..., instance=rank, seed=1234+rank)); here they run one after another on one device, each
+    against the oracle with the criteria of test_rollout_costs_and_controls."""
+    cfg = S.make_config(4096, 100, track="oval", instance=instance, seed=1234 + instance)
+    m = cfg["map_rgba"][:, :, 0]
+    on = m < 1.0  # the drivable band must lie inside the map, away from its border
+    assert not (on[0].any() or on[-1].any() or on[:, 0].any() or on[:, -1].any())
+    U0 = warm_U(cfg, seed=7 + instance)
+    ref, got = _solve_both(cfg, U0=U0, seed=1234 + instance)
+    assert "quad" in got["variant"]
+    np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
+    err = rel_err(got["costs"], ref["costs"])
+    assert int(np.sum(err > 1e-4)) <= cfg["K"] // 200, (instance, float(err.max()))
+    assert float(np.percentile(err, 99)) < 5e-6
+    assert float(np.abs(got["w"] - ref["w"]).sum()) / float(ref["w"].sum()) < 1e-4
+    assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
+    assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"])
+    # non-degenerate: the start pose is on the centre-line (most rollouts stay on the track, weights spread)
+    assert float(np.mean(ref["costs"] < 5000.0)) > 0.5 and float(ref["w"].sum()) > 4.0
+
+
 @pytest.mark.parametrize("layers,variant", [([6, 16, 8, 4], "auto"), ([6, 24, 4], "auto"), (None, "valu_lds"),
                                             ([6, 64, 64, 64, 64, 4], "valu")])
 def test_generic_and_register_valu_kernels(layers, variant):
@@ -185,10 +210,18 @@ def test_cold_start_zero_controls():
 def test_two_iterations():
     cfg = S.make_config(512, 50, track="ring", num_iters=2)
     ref, got = _solve_both(cfg, U0=warm_U(cfg))
-    np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32)) \
-        if np.max(np.abs(got["U"] - ref["U"])) == 0 else None
     assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
     assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"])
+    # The second iteration's applied controls are (raw weighted mean of iteration 1) + nu * eps: not
+    # bit-exact (the mean carries the ulp-level cost differences of iteration 1), but bounded like the
+    # fuzz test bounds them for iters > 1: 2e-4 + 4 x the weight mass of the rollouts whose cost flipped.
+    err = rel_err(got["costs"], ref["costs"])
+    flipped = err > 1e-4
+    w, wg = ref["w"] / ref["w"].sum(), got["w"] / got["w"].sum()
+    mass = float(np.sum(np.maximum(w, wg)[flipped]))
+    assert float(np.max(np.abs(got["V"] - ref["V"][-1]))) <= 2e-4 + 8.0 * mass
+    # and the noise-free rollout 0 applies exactly the mean both sides fed back
+    assert float(np.max(np.abs(got["V"][0] - ref["V"][-1][0]))) <= 1e-4
 
 
 def test_cost_branches_l1_control_cost_and_opt_stride():
