@@ -75,7 +75,9 @@ struct mppi_handle {
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 0;    // 0: auto; 512: quad (2 dynamics + cost + control waves per 16 rollouts); 64, 256: single-wave form
+  int block_threads = 0;    // 0: auto; 512: quad (2 dynamics + cost + control waves per 16 rollouts); 64, 256: single-wave form;
+                            // 1000 + ND: multi form (ND dynamics waves of 16 rollouts + cost wave + control wave), ND = 1, 2, 4
+  bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
   int num_simds = 1024;     // 4 per CU
   hipStream_t stream = nullptr;
   int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
@@ -222,35 +224,57 @@ bool use_mfma(const mppi_handle *h)
 // "valu" on a standard shape runs the register/scalar-operand kernel; "valu_lds" forces the generic one
 bool use_valu_reg(const mppi_handle *h) { return !h->basis && !use_mfma(h) && h->valu_reg_ok && h->variant_pref != 3; }
 
-// Kernel form for the MFMA path.  The quad form spends four wavefronts per 16 rollouts (the network
-// itself on two SIMDs, a cost wave, a control/noise wave); it wins while the recurrence is latency
-// bound, i.e. while the SIMDs are not yet full of dynamics waves; after that one wave per 16 rollouts
-// is best.  Measured on MI355X (rollout kernel, T=100): 6-32-32-4 K=4096 quad 71 us / single-wave
-// 117 us; K=8192 114 / 120 us; K=12288 159 / 121 us.  6-64-64-4: K=4096 138 / 217 us; K=8192 247 / 233 us.
+// Kernel form for the MFMA path, by the number of 16-rollout groups against the machine (MI355X: 256 CUs of
+// 4 SIMDs).  Measured rollout-kernel times (this file's forms are bit-identical, so only time decides):
+//   * up to one group per CU (K <= 4096): the QUAD form -- the network itself split over two SIMDs, plus a
+//     cost and a control wave; the T-step recurrence is latency bound and this is the shortest chain
+//     (6-32-32-4, T=100, K=4096: quad 71 us, multi1 / multi2 83 us, single-wave 122 us);
+//   * up to two groups per CU (K <= 8192): MULTI2 -- two dynamics waves (whole network each), one cost wave,
+//     one control wave with the in-kernel generator, every wave on a SIMD of its own (K=8192: 83 us; quad
+//     112 us, single-wave 123 us; 6-64-64-4, T=150: 277 us vs 359 / 339 us);
+//   * beyond: MULTI4 with eps from the stand-alone generator kernel -- four dynamics waves per workgroup, one
+//     per SIMD, the cost and control waves riding along (K=16384: 106 us vs 124 us single-wave;
+//     6-64-64-4, T=150: 306 us vs 341 us; the in-kernel generator would load one SIMD too much: 341 us).
+// Shapes the multi form does not have (6-64x4-4: its weights do not fit a wave of a six-wave workgroup) keep
+// the quad form while its four waves per group fit the SIMDs and the single-wave form after that -- in
+// workgroups of FOUR waves: the dispatcher spreads the waves of one workgroup over the four SIMDs of a CU,
+// whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD on paper (K = 16384) --
+// sometimes two on one SIMD and none on its neighbour, which doubles the kernel time
+// (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us).
 int effective_block(const mppi_handle *h)
 {
   if (h->block_threads != 0) return h->block_threads;
   const int groups = h->K / kRolloutsPerWave;
-  const int budget = (h->hidden <= 32) ? 2 * h->num_simds : h->num_simds;
-  // single-wave form in workgroups of FOUR waves: the dispatcher spreads the waves of one workgroup over
-  // the four SIMDs of a CU, whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD
-  // on paper (K = 16384) -- sometimes two on one SIMD and none on its neighbour, which doubles the kernel
-  // time (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us)
-  return (4 * groups <= budget) ? 512 : 256;
+  const int cus = h->num_simds / 4;
+  if (multi_variant_supported(h->hidden, h->n_hidden)) {
+    if (groups <= cus) return 512;
+    if (groups <= 2 * cus) return 1002;
+    return 1004;
+  }
+  return (4 * groups <= h->num_simds) ? 512 : 256;
+}
+
+// multi form: eps from the stand-alone generator kernel (forced by "_gen", and the automatic choice for ND = 4)
+bool multi_gen(const mppi_handle *h)
+{
+  if (h->block_threads != 0) return h->multi_standalone_noise;
+  return effective_block(h) == 1004;
 }
 
 // basis-function model: dynamics wave + cost wave per 64 rollouts ("fused" / "block64" force the one-wave form)
 bool bf_two_waves(const mppi_handle *h)
 {
-  if (h->block_threads == 64) return false;
+  if (h->block_threads == 64 || h->block_threads == 256) return false;
   if (h->block_threads == 512) return true;
   return 2 * (h->K / 64) <= 2 * h->num_simds;
 }
 
-// the quad MFMA kernel carries its own control/noise wavefront
+// the quad and multi MFMA kernels carry their own control/noise wavefront
 bool has_noise_wave(const mppi_handle *h)
 {
-  return use_mfma(h) && effective_block(h) == 512;
+  if (!use_mfma(h)) return false;
+  const int b = effective_block(h);
+  return b == 512 || (b > 1000 && !multi_gen(h));
 }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
@@ -314,6 +338,8 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
 {
   // basis-function model: the two-wave form while both waves of a group get a SIMD of their own
   hipError_t e = h->basis ? launch_rollout_bf(a, bf_two_waves(h), h->stream)
+                 : (use_mfma(h) && effective_block(h) > 1000)
+                     ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
                  : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
                                    : launch_rollout_valu(h->net, a, h->stream);
@@ -1307,8 +1333,12 @@ const char *mppi_rollout_variant(const mppi_handle *h)
   if (!use_mfma(h)) return use_valu_reg(h) ? "valu_reg_lds" : "valu_lds";
   static thread_local char buf[64];
   const int b = effective_block(h);
-  snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
-           b == 512 ? "quad4w" : (b == 256 ? "fused_b256" : "fused_b64"));
+  if (b > 1000)
+    snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi%d%s", h->hidden, h->n_hidden, b - 1000,
+             multi_gen(h) ? "_gen" : "");
+  else
+    snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
+             b == 512 ? "quad4w" : (b == 256 ? "fused_b256" : "fused_b64"));
   return buf;
 }
 
@@ -1325,8 +1355,18 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
   else if (strcmp(name, "valu_lds") == 0) h->variant_pref = 3;
   else if (strcmp(name, "quad") == 0) h->block_threads = 512;
-  else if (strcmp(name, "fused") == 0 || strcmp(name, "block64") == 0) h->block_threads = 64;
-  else if (strcmp(name, "block256") == 0) h->block_threads = 256;
+  else if (strncmp(name, "multi", 5) == 0) {
+    const int nd = name[5] - '0';
+    const bool gen = strcmp(name + 6, "_gen") == 0;
+    if ((nd != 1 && nd != 2 && nd != 4) || (name[6] != 0 && !gen)) return fail(h, MPPI_ERR_INVALID, "unknown variant");
+    if (h->K % (16 * nd) != 0) return fail(h, MPPI_ERR_UNSUPPORTED, "multi form needs K to be a multiple of 16 ND");
+    if (!h->mfma_ok || !multi_variant_supported(h->hidden, h->n_hidden))
+      return fail(h, MPPI_ERR_UNSUPPORTED, "multi form exists for 6-32x2-4, 6-32x4-4 and 6-64x2-4");
+    h->block_threads = 1000 + nd;
+    h->multi_standalone_noise = gen;
+  }
+  else if (strcmp(name, "fused") == 0 || strcmp(name, "block256") == 0) h->block_threads = 256;
+  else if (strcmp(name, "block64") == 0) h->block_threads = 64;
   else return fail(h, MPPI_ERR_INVALID, "unknown variant");
   return MPPI_OK;
 }

@@ -13,6 +13,10 @@ hipError_t launch_dynamics_mfma(int hidden, int n_hidden, const float *wpack, co
                                 const float *controls, float *ders, int n, int negate_yaw_der,
                                 hipStream_t stream);
 
+// rollout_multi.hip: nd dynamics waves (16 rollouts each) + cost wave + control wave per workgroup, nd in {1, 2, 4}
+bool multi_variant_supported(int hidden, int n_hidden);
+hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, int nd, hipStream_t stream);
+
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {
   int n_layers;

@@ -1,0 +1,323 @@
+// rollout_multi.hip -- rolloutKernel (PI/mppi_controller.cu:72-184) for gfx950, the form for K beyond
+// the latency regime: ND "dynamics" wavefronts (16 rollouts each, the whole network on the matrix
+// instruction, mfma_net.hpp) + ONE cost wavefront + ONE control wavefront per workgroup of 16 ND rollouts.
+//
+// Why: in the single-wave form (rollout_mfma_kernel) every lane of a 16-rollout wave carries the scalar
+// work of its rollout -- controls, sin/cos, two costmap fetches, MPPICosts::computeCost, the f64 running
+// mean -- 4x redundantly (4 lanes per rollout), and the f32 matrix instruction shares the vector datapath,
+// so that work ADDS to the network's cycles: ~1 700 of ~5 750 cycles per step at 6-64-64-4.  Here
+//   * a dynamics wave does the network and the Euler update of [roll, u_x, u_y, yaw_mder] only; per step
+//     it reads one LDS word (its layer-0 operand [u0, u1, 0, 0][g], prefetched a step ahead) and writes one
+//     (the state record of the cost wave); it touches no global memory inside the T loop;
+//   * the cost wave serves all 16 ND rollouts with ONE LANE PER ROLLOUT: x, y, yaw kinematics, sin/cos,
+//     costmap fetches, computeCost, running mean, crash flags -- software-pipelined by one step around the
+//     fetches, exactly the cost wave of the quad kernel with 64 useful lanes instead of 16;
+//   * the control wave, one lane per rollout: eps (explicit buffer, requested 4 steps ahead, or the
+//     in-kernel MRG32k3a), the perturbed control, its write-back before the clamp (Q3), the clamp, the
+//     records of the other waves; it runs up to kRing steps ahead.
+// Rings of kRing steps and LDS sequence words decouple the waves (mppi_device.hpp): no barrier in the T
+// loop, nobody waits in steady state.  Same arithmetic in the same order as the other forms: bit-identical.
+// The waves of one workgroup are spread over the four SIMDs of a CU by the dispatcher, so with ND = 4 and
+// one workgroup per CU every SIMD runs exactly one dynamics wave (K = 16384: 256 workgroups).
+#include "mfma_net.hpp"
+#include "noise_device.hpp"
+
+namespace mppi {
+
+constexpr int kMRing = 16;    // steps in flight between the waves (power of two)
+constexpr int kMCtlChunk = 4;  // steps of U / explicit eps the control wave requests at once
+
+template <int ND>
+struct MultiShared {
+  static constexpr int NR = 16 * ND;       // rollouts per workgroup
+  float rec[kMRing][NR][4];                // s3..s6 before the update of step t (dynamics waves)
+  float ctl_rec[kMRing][NR][4];            // clamped u0, u1, du0, du1 (control wave -> cost wave)
+  float ctl_b1[kMRing][ND][64];            // layer-0 operand of k-step 1, [u0c, u1c, 0, 0][g] in lane order
+  int dyn_pub[4][64];                      // steps published by dynamics wave w (written per lane, word 0 read)
+  int cost_done[64];                       // steps consumed by the cost wave
+  int ctl_pub[64];                         // steps published by the control wave
+  int fail[4];                             // word 0: raised by a wave whose waits ran out of budget
+  int fin[8];                              // word r: wave r is through its T steps
+};
+
+__device__ __forceinline__ void lds_put1(uint32_t addr, float v)
+{
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// one word per lane, not made uniform
+__device__ __forceinline__ int lds_peek_lanes(uint32_t addr)
+{
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// smallest of the ND dynamics waves' publication counts (lane l reads the word of wave l % ND)
+template <int ND>
+__device__ __forceinline__ int dyn_pub_min(uint32_t a_lane_word)
+{
+  const int v = lds_peek_lanes(a_lane_word);
+  int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+  for (int w = 1; w < ND; w++) m = min(m, __builtin_amdgcn_readlane(v, w));
+  return m;
+}
+
+template <int H, int NHID, int ND>
+__device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared<ND> &sh, const int w)
+{
+  using N = MfmaNet<H, NHID>;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int T = a.T;
+  float A[N::nA], Bi[N::nBias];
+  load_weights<H, NHID>(a.wpack, lane, A, Bi);
+
+  const uint32_t a_mypub = lds_addr(&sh.dyn_pub[w][lane]);
+  const uint32_t a_rec = lds_addr(&sh.rec[0][16 * w + j][g]);
+  constexpr uint32_t kRecSlot = MultiShared<ND>::NR * 16, kB1Slot = ND * 64 * 4;
+  // LDS-typed volatile pointers: plain ds_read instructions in program order, the compiler keeps track of
+  // their completion itself (s_waitcnt at the first use), so a value requested early costs nothing later
+  typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
+  typedef const volatile float __attribute__((address_space(3))) *lds_float_p;
+  const lds_int_p p_pub = (lds_int_p)&sh.ctl_pub[0];
+  const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
+  const lds_float_p p_b1 = (lds_float_p)&sh.ctl_b1[0][w][lane];
+
+  float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == 1 + w);
+  while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+  float b1_next = *p_b1;
+  int cd = 0;  // last value seen of the cost wave's consumption counter
+  for (int t = 0; t < T; t++) {
+    const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
+    const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
+    // record for the cost wave: the state BEFORE this step's update; its ring slot held step t - kMRing
+    while (cd < t - kMRing + 1 && --budget > 0) cd = __builtin_amdgcn_readfirstlane(*p_cd);
+    lds_put1(a_rec + (uint32_t)(t & (kMRing - 1)) * kRecSlot, b0);
+    lds_publish(a_mypub, t + 1);  // also: this wave is done with the control record of step t
+    // requested now, used after the network: the control wave's count, then this lane's layer-0 operand
+    // of step t+1 (valid if the count read before it is >= t+2), and the cost wave's progress
+    const int tn = (t + 1) & (kMRing - 1);
+    int cp = *p_pub;
+    float b1n = p_b1[tn * (kB1Slot / 4)];
+    int cdn = *p_cd;
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests up here: the scheduler would sink them to their use
+
+    f32x4 acc[N::MT];
+    nn_layer0_ops<H, NHID>(A, b0, b1, acc);
+    nn_hidden<H, NHID>(A, Bi, acc);
+    float d[4];
+    nn_last<H, NHID>(A, Bi, acc, d);
+    s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
+    s4 = fmaf(d[1], a.dt, s4);
+    s5 = fmaf(d[2], a.dt, s5);
+    s6 = fmaf(d[3], a.dt, s6);
+
+    __builtin_amdgcn_sched_barrier(0);  // ... and their first use down here, behind the network
+    const int want = min(t + 2, T);
+    cp = __builtin_amdgcn_readfirstlane(cp);
+    while (cp < want && --budget > 0) {  // never in steady state: the control wave runs ahead
+      cp = __builtin_amdgcn_readfirstlane(*p_pub);
+      b1n = p_b1[tn * (kB1Slot / 4)];
+      cdn = *p_cd;
+    }
+    b1_next = b1n;
+    cd = __builtin_amdgcn_readfirstlane(cdn);
+  }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
+}
+
+template <int H, int NHID, int ND>
+__global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const RolloutArgs a)
+{
+  using SH = MultiShared<ND>;
+  constexpr int NR = SH::NR;
+  __shared__ __attribute__((aligned(16))) SH sh;
+  const int lane = threadIdx.x & 63;
+  // 0..ND-1 dynamics, ND cost, ND+1 control; made uniform for the compiler (budgets and waits stay scalar)
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int K = a.K, T = a.T;
+  // sequence words and the constant rows of the layer-0 operand start at 0; the only barrier
+  if (role == 0) {
+    for (int w = 0; w < 4; w++) sh.dyn_pub[w][lane] = 0;
+    sh.cost_done[lane] = 0;
+    sh.ctl_pub[lane] = 0;
+    sh.fail[lane & 3] = 0;
+    sh.fin[lane & 7] = 0;
+  }
+  if (role == ND + 1)
+    for (int q = 0; q < kMRing; q++)
+      for (int w = 0; w < ND; w++) sh.ctl_b1[q][w][lane] = 0.0f;
+  __syncthreads();
+
+  if (role < ND) {
+    multi_dynamics<H, NHID, ND>(a, sh, role);
+  } else if (role == ND + 1) {
+    // -------------------------------- control wave: one lane per rollout --------------------------------
+    const bool inl = a.inline_noise != 0;
+    const bool active = lane < NR;
+    const int r = active ? lane : NR - 1;
+    const int k = blockIdx.x * NR + r;
+    Mrg gsta{0, 0, 0, 0, 0, 0};
+    if (active && inl) {
+      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
+      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
+    }
+    float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+    const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+    const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
+    const bool pure_noise_k = (k >= a.k99);  // :141
+    const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
+    const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+    const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == ND + 2);
+    int seen_d = 0, seen_c = 0;  // steps published by all dynamics waves / consumed by the cost wave
+    for (int t0 = 0; t0 < T; t0 += kMCtlChunk) {
+      float2 Uq[kMCtlChunk], eq[kMCtlChunk];
+#pragma unroll
+      for (int q = 0; q < kMCtlChunk; q++) {
+        const int tq = min(t0 + q, T - 1);
+        Uq[q] = Useq[tq];
+        eq[q] = (active && !inl) ? noise[(size_t)tq * K + k] : make_float2(0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int q = 0; q < kMCtlChunk; q++) {
+        const int t = t0 + q;
+        if (t < T) {
+          // slot t % kMRing held step t - kMRing: a dynamics wave is done with it once it has published
+          // step t - kMRing, the cost wave once it has consumed it
+          const int need = t - kMRing + 1;
+          while ((seen_d < need || seen_c < need) && --budget > 0) {
+            seen_d = dyn_pub_min<ND>(a_dynw);
+            seen_c = lds_peek(a_cd);
+            if (seen_d < need || seen_c < need) __builtin_amdgcn_s_sleep(2);
+          }
+          if (active) {
+            const float2 e = inl ? noise_pair(gsta) : eq[q];
+            // control perturbation, mppi_controller.cu:136-153
+            const bool nf = noise_free_k | (t < a.opt_delay);
+            const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+            const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+            float u0 = nf ? Uq[q].x : (pure_noise_k ? n0 : Uq[q].x + n0);
+            float u1 = nf ? Uq[q].y : (pure_noise_k ? n1 : Uq[q].y + n1);
+            noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+            u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+            u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+            const int slot = t & (kMRing - 1);
+            sh.ctl_b1[slot][r >> 4][r & 15] = u0;
+            sh.ctl_b1[slot][r >> 4][16 + (r & 15)] = u1;
+            *reinterpret_cast<float4 *>(&sh.ctl_rec[slot][r][0]) = make_float4(u0, u1, du0, du1);
+          }
+          lds_publish(a_mypub, t + 1);
+        }
+      }
+    }
+    if (active && inl) {
+      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
+      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+    }
+    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[ND + 1]));
+  } else {
+    // -------------------------------- cost wave: one lane per rollout --------------------------------
+    // Software-pipelined by one step: the costmap texels of step t are requested in iteration t and
+    // consumed in iteration t+1, so their latency never stalls the consumption of the rings.
+    const bool active = lane < NR;
+    const int r = active ? lane : NR - 1;
+    const int k = blockIdx.x * NR + r;
+    const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
+    const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
+    const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == ND + 1), seen = 0;
+    float J = 0.0f;
+    float tf_p = 0.0f, tb_p = 0.0f;
+    CostTerms ct_p{0.0f, 0.0f, 0.0f};
+    int rc_p = 0;
+    double rt_p = 0.0;
+    for (int t = 0; t <= T; t++) {
+      float tf = 0.0f, tb = 0.0f;
+      CostTerms ct{0.0f, 0.0f, 0.0f};
+      int rc = 0;
+      double rt = 0.0;
+      if (t < T) {
+        rt = a.inv_t[t];
+        // rec(t) is written before a dynamics wave publishes step t; ctl(t) was published before the
+        // dynamics waves could start step t
+        while (seen < t + 1 && --budget > 0) {
+          seen = dyn_pub_min<ND>(a_dynw);
+          if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);      // s3 s4 s5 s6
+        const float4 r1 = *reinterpret_cast<const float4 *>(&sh.ctl_rec[t & (kMRing - 1)][r][0]);  // u0 u1 du0 du1
+        lds_publish(a_mydone, t + 1);  // executes after the two reads (the LDS runs a wave's instructions in order)
+        rc = (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
+        float spsi, cpsi;
+        sincos_fast(yaw, spsi, cpsi);
+        const float st[3] = {x, y, yaw};
+        if (affine) track_fetch<true>(a.cost, st, cpsi, spsi, tf, tb);
+        else track_fetch<false>(a.cost, st, cpsi, spsi, tf, tb);
+        if (ctrl) cost_terms_a<true>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+        else cost_terms_a<false>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+        // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
+        const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
+        const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
+        const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
+        x = fmaf(sd0, a.dt, x);
+        y = fmaf(sd1, a.dt, y);
+        yaw = fmaf(sd2, a.dt, yaw);
+      }
+      if (t > 0) {  // finish step t-1: running mean over 1..T-1 (Q5); the t = 0 evaluation is discarded
+        const int tp = t - 1;
+        crash |= rc_p;
+        int crash_new = crash;
+        const float c = cost_terms_b(a.cost, ct_p, tf_p, tb_p, crash_new);
+        const float Jn = running_mean(J, c, tp, rt_p);
+        J = (tp > 0) ? Jn : J;
+        crash = (tp > 0) ? crash_new : crash;
+      }
+      tf_p = tf; tb_p = tb; ct_p = ct; rc_p = rc; rt_p = rt;
+    }
+    // a hand-over that never arrived, in ANY wave of the group: poison, do not hang (mppi_device.hpp)
+    {
+      const uint32_t a_fin = lds_addr(&sh.fin[(lane < ND) ? lane : ND + 1]);  // lanes 0..ND-1: dynamics, the rest: control
+      for (;;) {
+        const int v = lds_peek_lanes(a_fin);
+        int all = __builtin_amdgcn_readlane(v, ND);
+#pragma unroll
+        for (int w = 0; w < ND; w++) all &= __builtin_amdgcn_readlane(v, w);
+        if (all != 0 || --budget <= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
+    }
+    if (active) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
+  }
+}
+
+template <int H, int NHID>
+static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
+{
+  if (nd == 4) hipLaunchKernelGGL((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
+  else if (nd == 2) hipLaunchKernelGGL((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
+  else if (nd == 1) hipLaunchKernelGGL((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// 6-64-64-64-64-4 is left to the other forms: its 284 weight registers per lane do not fit a wave of a
+// six-wave workgroup (256 VGPRs) without spilling
+bool multi_variant_supported(int hidden, int n_hidden)
+{
+  return (hidden == 32 && (n_hidden == 2 || n_hidden == 4)) || (hidden == 64 && n_hidden == 2);
+}
+
+hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, int nd, hipStream_t stream)
+{
+  if (a.K % (16 * nd) != 0) return hipErrorInvalidValue;
+  if (hidden == 32 && n_hidden == 2) return launch_multi_t<32, 2>(a, nd, stream);
+  if (hidden == 64 && n_hidden == 2) return launch_multi_t<64, 2>(a, nd, stream);
+  if (hidden == 32 && n_hidden == 4) return launch_multi_t<32, 4>(a, nd, stream);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace mppi

@@ -324,7 +324,8 @@ def main():
             fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            bpu = ROLLOUT_BYTES_INLINE_NOISE if ("quad" in variant) else ROLLOUT_BYTES_BUFFERED_NOISE
+            inline_noise = ("quad" in variant) or ("multi" in variant and not variant.endswith("_gen"))
+            bpu = ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
             out["stage_ms"]["note"] = "HIP events on the handle's stream around every stage of %d solves, separate pass after the timed region" % n
             out["roofline"] = {

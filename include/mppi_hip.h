@@ -210,7 +210,10 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
  * "basis_funcs25_valu". */
 const char *mppi_rollout_variant(const mppi_handle *h);
 /* Force a variant (A/B of SURVEY cfg 4 and of the kernel forms): "auto"; "mfma" | "valu" | "valu_lds"
- * (arithmetic unit); "quad" | "fused" | "block64" | "block256" (form of the MFMA kernel). */
+ * (arithmetic unit); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
+ * wavefront per 16 rollouts) | "multi4" | "multi2" | "multi1" (ND dynamics wavefronts of 16 rollouts + one
+ * cost + one control wavefront; "_gen" appended: eps from the stand-alone generator kernel) | "fused" =
+ * "block256" | "block64" (one wavefront per 16 rollouts does everything; workgroups of 4 or 1 waves). */
 int mppi_set_rollout_variant(mppi_handle *h, const char *name);
 
 /* Test hook (not part of the drop-in surface): d/dt of n independent (state[7], control[2])
@@ -224,7 +227,8 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
  * spin_budget + 64 T polls in total (0: the default).  Roles of the four-wavefront network kernel: 1, 2 =
  * dynamics waves, 3 = cost wave, 4 = control wave; of the two-wavefront basis-function kernel: 1 = dynamics,
  * 2 = cost.  The solve must then end in MPPI_ERR_HIP ("hand-over failed"), never in finite costs.
- * wave = 0 and spin_budget = 0 restore normal operation. */
+ * wave = 0 and spin_budget = 0 restore normal operation.
+ * Roles of the multi form: 1 .. ND = dynamics waves, ND+1 = cost wave, ND+2 = control wave. */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
 
 #ifdef __cplusplus

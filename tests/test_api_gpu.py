@@ -199,7 +199,7 @@ def test_baseline_config4_full_size_properties():
     eps = rng.standard_normal((1, K, T, 2)).astype(np.float32)
     ref_costs, _, _ = O.Oracle(small, nthreads=8).rollouts(cfg["start_state"], U0, eps[0, :64])
     outs = {}
-    for variant in ("auto", "quad"):
+    for variant in ("auto", "quad", "fused", "multi4"):
         sol = capi.Solver(cfg)
         sol.set_rollout_variant(variant)
         sol.set_control_seq(U0)
@@ -208,9 +208,12 @@ def test_baseline_config4_full_size_properties():
         outs[variant] = dict(sol.get_results(), V=sol.get_applied_controls(), name=sol.rollout_variant())
         sol.close()
     a = outs["auto"]
-    assert "fused" in a["name"] and "quad" in outs["quad"]["name"]  # auto picks the single-wave form here
-    np.testing.assert_array_equal(a["costs"].view(np.uint32), outs["quad"]["costs"].view(np.uint32))
-    np.testing.assert_array_equal(a["U"].view(np.uint32), outs["quad"]["U"].view(np.uint32))
+    # auto: four dynamics waves + cost + control wave per 64 rollouts, eps from the generator kernel
+    assert "multi4_gen" in a["name"] and "quad" in outs["quad"]["name"] and "fused" in outs["fused"]["name"]
+    for v in ("quad", "fused", "multi4"):
+        np.testing.assert_array_equal(a["costs"].view(np.uint32), outs[v]["costs"].view(np.uint32))
+        np.testing.assert_array_equal(a["V"].view(np.uint32), outs[v]["V"].view(np.uint32))
+        np.testing.assert_array_equal(a["U"].view(np.uint32), outs[v]["U"].view(np.uint32))
     assert float(np.percentile(rel_err(a["costs"][:64], ref_costs), 90)) < 1e-5
     w = a["w"]
     assert w.max() == 1.0 and np.all(w >= 0) and np.all(np.isfinite(a["U"]))
@@ -264,7 +267,8 @@ def test_control_ticks_equals_the_call_by_call_loop():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2)])
+@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2),
+                                         ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi2", 2), ("multi2", 3)])
 def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, family, wave):
     """The multi-wavefront rollout kernels hand data over through LDS sequence words; a wave whose wait runs
     out of its poll budget carries on with whatever the LDS holds.  Whichever role that is -- a dynamics
@@ -280,8 +284,8 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
         extra = dict(layers=l, theta=th)
     cfg = S.make_config(256, 40, track="oval", **extra)
     sol = capi.Solver(cfg)
-    if family != "bf":
-        sol.set_rollout_variant("quad")
+    if family != "bf":  # multi form: roles 1..ND = dynamics waves, ND+1 = cost wave, ND+2 = control wave
+        sol.set_rollout_variant(family if family.startswith("multi") else "quad")
     sol.compute_control(cfg["start_state"])          # healthy
     good = sol.get_results()
     assert np.all(np.isfinite(good["costs"])) and np.all(np.isfinite(good["U"]))

@@ -56,7 +56,7 @@ def _draw(golden_dir, seed):
         variants = ["auto", "fused"]
     else:
         cfg = S.make_config(K, T, layers=layers, track=track, **over)
-        variants = ["auto", "quad", "fused", "valu", "valu_lds"]
+        variants = ["auto", "quad", "fused", "multi4", "multi2", "multi1", "multi4_gen", "valu", "valu_lds"]
     st = cfg["start_state"].copy()
     st[4], st[5], st[6], st[3] = rng.uniform(0.05, 12.0), rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.2, 0.2)
     if rng.rand() < 0.2:

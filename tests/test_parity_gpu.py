@@ -198,6 +198,13 @@ def test_quad_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
     np.testing.assert_array_equal(a["costs"].view(np.uint32), c["costs"].view(np.uint32))
     np.testing.assert_array_equal(a["V"].view(np.uint32), c["V"].view(np.uint32))
     np.testing.assert_array_equal(a["U"].view(np.uint32), c["U"].view(np.uint32))
+    # the multi form (ND dynamics waves + one cost wave + one control wave per 16 ND rollouts), ND = 4, 2, 1
+    for v in ("multi4", "multi2", "multi1"):
+        _, m = _solve_both(cfg, U0=U0, variant=v)
+        assert v in m["variant"]
+        np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))
+        np.testing.assert_array_equal(a["V"].view(np.uint32), m["V"].view(np.uint32))
+        np.testing.assert_array_equal(a["U"].view(np.uint32), m["U"].view(np.uint32))
 
 
 def test_cold_start_zero_controls():
@@ -343,14 +350,16 @@ def test_quad_kernel_loops_are_reproducible(K, T, layers):
     hand-over would show up as a control sequence that differs run against run (or from the
     single-wave form on the same stream of draws), or as a poisoned (NaN) solve."""
     cfg = S.make_config(K, T, layers=layers, track="oval")
-    sols = [capi.Solver(dict(cfg, seed=7)) for _ in range(3)]
+    sols = [capi.Solver(dict(cfg, seed=7)) for _ in range(5)]
     sols[0].set_rollout_variant("quad")
     sols[1].set_rollout_variant("quad")
-    sols[2].set_rollout_variant("fused")
+    sols[2].set_rollout_variant("multi4")   # in-kernel generator in its control wave, like the quad form
+    sols[3].set_rollout_variant("multi2")
+    sols[4].set_rollout_variant("fused")    # stand-alone generator kernel: the same stream of draws
     x = cfg["start_state"]
     for it in range(300):
         us = []
-        for s in sols[:2] if it >= 40 else sols:
+        for s in sols[:4] if it >= 40 else sols:
             s.compute_control(x)
             us.append(s.get_control_seq())
             s.slide_control_seq(1)
@@ -361,7 +370,7 @@ def test_quad_kernel_loops_are_reproducible(K, T, layers):
         s.close()
 
 
-@pytest.mark.parametrize("variant", ["quad", "fused", "valu"])
+@pytest.mark.parametrize("variant", ["quad", "fused", "multi4", "valu"])
 def test_projective_costmap_transform(variant):
     """updateTransform (costs.cu:175-188) accepts a full homography: w = r_c1.z x + r_c2.z y + trs.z != 1
     takes the kernels' u/w, v/w path (the shipped maps are affine and skip the two divides)."""
@@ -424,7 +433,7 @@ def test_horizon_edge_cases(golden_dir, T, family):
     extra = {}
     if family == "bf":
         extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
-    variants = ["quad", "fused", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
+    variants = ["quad", "fused", "multi4", "multi1", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
     for K in (64, 192):
         cfg = S.make_config(K, T, track="oval", **extra)
         U0 = warm_U(cfg)
@@ -445,7 +454,7 @@ def test_horizon_edge_cases(golden_dir, T, family):
 
 
 @pytest.mark.parametrize("opt", [1, 3, 16])
-@pytest.mark.parametrize("variant", ["quad", "fused", "valu"])
+@pytest.mark.parametrize("variant", ["quad", "fused", "multi4", "valu"])
 def test_slide_strides_up_to_the_horizon(opt, variant):
     """Device-resident loops (in-kernel generator, slid copy left by the tail kernel or made by the slide
     kernel, host re-upload every other tick) with optimization strides and slide strides from 1 to T,
