@@ -150,6 +150,23 @@ __global__ __launch_bounds__(256) void rollout_mfma_kernel(const RolloutArgs a)
 // (mppi_device.hpp): a loud failure instead of a hung GPU, whichever of the four waves starved.
 // Arithmetic and its order are those of the other kernel forms: results are bit-identical.
 // ---------------------------------------------------------------------------------------------
+// Diagnostic build only (-DMPPI_STAMPS, tools/quad_stamps.sh): s_memtime stamps of the two dynamics waves of
+// workgroup 0, accumulated over the steps t >= 16 into a buffer nothing else reads.  The product build has
+// no stamp instruction (MI355X guide, "In-kernel stamps").
+#ifdef MPPI_STAMPS
+__device__ unsigned long long g_quad_stamps[2][8];
+#define QSTAMP(var)                                                                                   \
+  do {                                                                                                \
+    unsigned long long t__;                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    var = t__;                                                                                        \
+  } while (0)
+#else
+#define QSTAMP(var) do { } while (0)
+#endif
+
 constexpr int kRing = 16;  // steps in flight between the waves (power of two)
 constexpr int kCtlChunk = 4;  // steps of U / explicit eps the control wave requests at once
 
@@ -179,6 +196,25 @@ __device__ __forceinline__ void quad_poll(uint32_t a_seq, uint32_t a_x, uint32_t
   f = __builtin_amdgcn_readfirstlane(f);
   cp = __builtin_amdgcn_readfirstlane(cp);
   cd = __builtin_amdgcn_readfirstlane(cd);
+}
+
+// the swap alone: partner's sequence word, then its data (one round trip)
+template <int M2>
+__device__ __forceinline__ void quad_poll_swap(uint32_t a_seq, uint32_t a_x, int &f, f32x4 (&oth)[M2])
+{
+  static_assert(M2 == 1 || M2 == 2, "one or two M tiles per dynamics wave");
+  if constexpr (M2 == 1) {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(oth[0])
+                 : "v"(a_seq), "v"(a_x)
+                 : "memory");
+  } else {
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(oth[0]), "=&v"(oth[M2 - 1])
+                 : "v"(a_seq), "v"(a_x)
+                 : "memory");
+  }
+  f = __builtin_amdgcn_readfirstlane(f);
 }
 
 template <int H, int NHID>
@@ -240,7 +276,25 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
   while (lds_peek(a_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   float b1_next = sh.ctl_b1[0][lane];
   int cd = 0;  // last value seen of the cost wave's consumption counter
+  // Two forms of the per-step look at the control wave's and the cost wave's progress.  Classic: read with
+  // every poll of the swap (one batch of five LDS reads per poll).  Slim: the swap polls only the partner's
+  // sequence word and tile; the three other words are requested once after the swap and used after the
+  // output layer (LDS-typed volatile loads: plain ds_read instructions whose completion the compiler tracks).
+  // Measured (K=4096, T=100, same box): 6-32-32-4 classic 71.3 us / slim 73.3 us; 6-64-64-4 140.2 / 135.4;
+  // 6-32x4-4 128.0 / 121.8 -- the slim form wins where a poll carries more data or there are more swaps.
+  constexpr bool kSlimPoll = !(H == 32 && NHID == 2);
+  typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
+  typedef const volatile float __attribute__((address_space(3))) *lds_float_p;
+  const lds_int_p p_pub = (lds_int_p)&sh.ctl_pub[0];
+  const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
+  const lds_float_p p_b1 = (lds_float_p)&sh.ctl_b1[0][lane];
+  int cp_v = 0, cd_v = 0;
+  float b1n_v = 0.0f;
+#ifdef MPPI_STAMPS
+  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, qprev = 0, qa[6] = {0, 0, 0, 0, 0, 0};
+#endif
   for (int t = 0; t < T; t++) {
+    QSTAMP(q0);
     const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
     const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
     if (W == 0) {  // record for the cost wave: the state BEFORE this step's update
@@ -268,6 +322,7 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
     }
     f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 acc[M2];
+    QSTAMP(q1);  // layer 0 (MFMAs + tanh) done
 #pragma unroll
     for (int l = 1; l < NHID; l++) {
       // own M tiles of hidden layer l; after the first swap wave 0 arrives with k-steps 0..KS2-1
@@ -296,6 +351,7 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
         lds_put4(a_xmine + par + 16 * i, own[i]);
       }
       lds_publish(a_myseq, n);
+      if (l == 1) QSTAMP(q2);  // own tile of the hidden layer: MFMAs + tanh + store + publish done
       if (W == 0) {
         // k-steps 0..KS2-1 of the next layer read wave 0's own tiles: run them while the partner's half
         // is in flight
@@ -320,15 +376,33 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
       // after the first swap of a step only)
       const uint32_t a_b1n = a_b1 + (uint32_t)((t + 1) & (kRing - 1)) * kB1Slot;
       const int want_ctl = (l == 1) ? min(t + 2, T) : 0;
-      int f, cp, cdn;
-      float b1n;
-      for (;;) {
-        quad_poll<M2>(a_seq, a_xoth + par, a_pub, a_b1n, a_cd, f, oth, cp, b1n, cdn);
-        if (((f >= n) & (cp >= want_ctl)) || --budget <= 0) break;
-      }
-      if (l == 1) {
-        b1_next = b1n;
-        cd = cdn;
+      if constexpr (kSlimPoll) {
+        int f;
+        for (;;) {
+          quad_poll_swap<M2>(a_seq, a_xoth + par, f, oth);
+          if ((f >= n) || --budget <= 0) break;
+        }
+        if (l == 1) {
+          // requested now, used at the end of the step (behind the output layer's MFMAs): the control wave's
+          // count, then this lane's layer-0 operand of step t+1 (valid if the count read before it is
+          // >= t+2), and the cost wave's progress
+          cp_v = *p_pub;
+          b1n_v = p_b1[((t + 1) & (kRing - 1)) * 64];
+          cd_v = *p_cd;
+          QSTAMP(q3);
+        }
+      } else {
+        int f, cp, cdn;
+        float b1n;
+        for (;;) {
+          quad_poll<M2>(a_seq, a_xoth + par, a_pub, a_b1n, a_cd, f, oth, cp, b1n, cdn);
+          if (((f >= n) & (cp >= want_ctl)) || --budget <= 0) break;
+        }
+        if (l == 1) {
+          b1_next = b1n;
+          cd = cdn;
+          QSTAMP(q3);  // (wave 0: early output-layer MFMAs, then) the partner's tile has arrived
+        }
       }
       // activation of k-step s = 4m + r: from the wave that owns tile m
 #pragma unroll
@@ -342,7 +416,28 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
     s4 = fmaf(o[1] + BL[1], a.dt, s4);
     s5 = fmaf(o[2] + BL[2], a.dt, s5);
     s6 = fmaf(o[3] + BL[3], a.dt, s6);
+    if constexpr (kSlimPoll) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int want = min(t + 2, T);
+      int cp = __builtin_amdgcn_readfirstlane(cp_v);
+      while (cp < want && --budget > 0) {  // never in steady state: the control wave runs ahead
+        cp = __builtin_amdgcn_readfirstlane(*p_pub);
+        b1n_v = p_b1[((t + 1) & (kRing - 1)) * 64];
+        cd_v = *p_cd;
+      }
+      b1_next = b1n_v;
+      cd = __builtin_amdgcn_readfirstlane(cd_v);
+    }
+#ifdef MPPI_STAMPS
+    QSTAMP(q4);
+    if (t >= 16) { qa[0] += q1 - q0; qa[1] += q2 - q1; qa[2] += q3 - q2; qa[3] += q4 - q3; qa[4] += 1; qa[5] += q0 - qprev; }
+    qprev = q4;
+#endif
   }
+#ifdef MPPI_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 6; i++) g_quad_stamps[W][i] = qa[i];
+#endif
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[W]));
 }
 
@@ -594,3 +689,10 @@ hipError_t launch_dynamics_mfma(int hidden, int n_hidden, const float *wpack, co
 }
 
 }  // namespace mppi
+
+#ifdef MPPI_STAMPS
+extern "C" int mppi_debug_read_quad_stamps(unsigned long long *out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mppi::g_quad_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
