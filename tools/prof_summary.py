@@ -18,9 +18,11 @@ import sys
 
 
 def find(d, suffix):
-    fs = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    fs = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
     if not fs:
         raise SystemExit("no *%s under %s" % (suffix, d))
+    if len(fs) > 1:
+        raise SystemExit("several *%s under %s (stale output of an earlier run?): %s" % (suffix, d, fs))
     return fs[0]
 
 
@@ -60,6 +62,13 @@ def pmc(out, note, dirs):
         if "read_bytes_corrected" in e and "write_bytes" in e:
             e["traffic_bytes_per_launch"] = e["read_bytes_corrected"] + e["write_bytes"]
         res["kernels"][k] = e
+    bj = os.environ.get("PROF_BENCH_JSON")
+    if bj and os.path.exists(bj):  # the bench line of the --stats pass of the same command: names the workload
+        try:
+            c = json.loads([l for l in open(bj).read().splitlines() if l.startswith("{")][0])["config"]
+            res["workload"] = {"K": c["K"], "T": c["T"], "layers": c["layers"], "rollout_variant": c["rollout_variant"]}
+        except (IndexError, KeyError, ValueError):
+            pass
     with open(out, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     for k, e in res["kernels"].items():
