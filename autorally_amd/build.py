@@ -81,7 +81,7 @@ def build_host(force=False):
                                             "run_control_loop.hpp", "path_integral_main.hpp")] + [os.path.join(CSRC, "basis_funcs.hpp")] + [os.path.join(HERE, "..", "include", "mppi_hip.h")]
     outs = []
     link = ["-L" + HERE, "-lmppi_hip", "-Wl,-rpath,$ORIGIN/.."]
-    for name, libs in (("host_selftest", []), ("path_integral_nn", link), ("path_integral_bf", link)):
+    for name, libs in (("host_selftest", link), ("path_integral_nn", link), ("path_integral_bf", link)):
         src = os.path.join(HOST, name + ".cpp")
         out = os.path.join(BIN, name)
         outs.append(out)

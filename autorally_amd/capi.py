@@ -53,7 +53,7 @@ class StageTimes(C.Structure):
 SYMBOLS = [
     "mppi_abi_version", "mppi_strerror", "mppi_last_error", "mppi_device_count", "mppi_create",
     "mppi_destroy", "mppi_set_nn_params", "mppi_update_model", "mppi_set_control_limits",
-    "mppi_set_costmap", "mppi_set_costmap_channel", "mppi_set_cost_params", "mppi_reset_controls",
+    "mppi_set_costmap", "mppi_set_costmap_transform", "mppi_set_costmap_channel", "mppi_set_cost_params", "mppi_reset_controls",
     "mppi_set_control_seq", "mppi_get_control_seq", "mppi_set_control_hist", "mppi_get_control_hist",
     "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
     "mppi_compute_control", "mppi_control_ticks", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
@@ -95,6 +95,7 @@ def lib():
         L.mppi_update_model.argtypes = [hp, C.POINTER(C.c_int), C.c_int, fp, C.c_size_t]
         L.mppi_set_control_limits.argtypes = [hp, fp, fp]
         L.mppi_set_costmap.argtypes = [hp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.mppi_set_costmap_transform.argtypes = [hp, fp, fp, fp]
         L.mppi_set_costmap_channel.argtypes = [hp, C.c_int, fp, C.c_size_t]
         L.mppi_set_cost_params.argtypes = [hp, C.POINTER(CostParams)]
         L.mppi_reset_controls.argtypes = [hp]
@@ -269,6 +270,9 @@ class Solver:
         d = (C.c_int * len(description))(*[int(x) for x in description])
         data = _f32(data)
         self._ck(self.L.mppi_update_model(self.h, d, len(description), _fp(data), data.size))
+
+    def set_costmap_transform(self, r_c1, r_c2, trs):
+        self._ck(self.L.mppi_set_costmap_transform(self.h, _fp(_f32(r_c1, (3,))), _fp(_f32(r_c2, (3,))), _fp(_f32(trs, (3,)))))
 
     def set_costmap_channel(self, channel, data):
         data = _f32(data)

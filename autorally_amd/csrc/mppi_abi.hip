@@ -868,6 +868,18 @@ int mppi_set_costmap(mppi_handle *h, int width, int height, const float *rgba, c
   return MPPI_OK;
 }
 
+int mppi_set_costmap_transform(mppi_handle *h, const float r_c1[3], const float r_c2[3], const float trs[3])
+{
+  if (!h || !r_c1 || !r_c2 || !trs) return MPPI_ERR_INVALID;
+  if (!h->have_map) return fail(h, MPPI_ERR_STATE, "mppi_set_costmap has not been called");
+  for (int i = 0; i < 3; i++) {  // kernel arguments of the next launch; nothing on the device changes
+    h->r_c1[i] = r_c1[i];
+    h->r_c2[i] = r_c2[i];
+    h->trs[i] = trs[i];
+  }
+  return MPPI_OK;
+}
+
 int mppi_set_costmap_channel(mppi_handle *h, int channel, const float *data, size_t n)
 {
   if (!h || !data) return MPPI_ERR_INVALID;

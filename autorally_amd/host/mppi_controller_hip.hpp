@@ -18,6 +18,7 @@
 #include <array>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -94,37 +95,104 @@ class NeuralNetModel {
     version_++;
   }
 
-  // host twin of updateState (neural_net_model.cu:280-288): clamp, kinematics, NN, Euler step
-  void updateState(float *state, float *control) const
+  // ---- host twins of the Eigen members (neural_net_model.cu:191-288); Eigen does not exist here, so the
+  // public state_der_ / jac_ (neural_net_model.cuh:70,74) are plain arrays, jac_ row-major [7][9] over [x | u]
+  float state_der_[STATE_DIM] = {0, 0, 0, 0, 0, 0, 0};
+  float jac_[STATE_DIM][STATE_DIM + CONTROL_DIM] = {};
+
+  // enforceConstraints, :266-278
+  void enforceConstraints(float * /*state*/, float *control) const
   {
     for (int i = 0; i < CONTROL_DIM; i++) {
       if (control[i] < control_rngs_[i].x) control[i] = control_rngs_[i].x;
       else if (control[i] > control_rngs_[i].y) control[i] = control_rngs_[i].y;
     }
-    float sd[STATE_DIM];
+  }
+  // computeKinematics, :191-200 (products contracted like the device code, so that the host replay of a
+  // trajectory follows the rollouts' arithmetic)
+  void computeKinematics(const float *state)
+  {
     const float c = cosf(state[2]), s = sinf(state[2]);
-    sd[0] = fmaf(c, state[4], -(s * state[5]));
-    sd[1] = fmaf(s, state[4], c * state[5]);
-    sd[2] = negate_yaw_der ? -state[6] : state[6];
+    state_der_[0] = fmaf(c, state[4], -(s * state[5]));
+    state_der_[1] = fmaf(s, state[4], c * state[5]);
+    state_der_[2] = negate_yaw_der ? -state[6] : state[6];
+  }
+  // computeDynamics, :202-230: forward pass, keeps every layer's weighted input for computeGrad
+  void computeDynamics(const float *state, const float *control)
+  {
+    const size_t L = net_structure_.size() - 1;
+    weighted_in_.resize(L);
     std::vector<float> a(maxWidth()), b(maxWidth());
     a[0] = state[3]; a[1] = state[4]; a[2] = state[5]; a[3] = state[6]; a[4] = control[0]; a[5] = control[1];
     size_t off = 0;
-    for (size_t l = 0; l + 1 < net_structure_.size(); l++) {
+    for (size_t l = 0; l < L; l++) {
       const int nin = net_structure_[l], nout = net_structure_[l + 1];
       const float *W = &net_params_[off], *bias = &net_params_[off + (size_t)nin * nout];
+      weighted_in_[l].resize((size_t)nout);
       for (int j = 0; j < nout; j++) {
         float tmp = 0.0f;
         for (int k = 0; k < nin; k++) tmp = fmaf(W[j * nin + k], a[k], tmp);
         tmp += bias[j];
-        if (l + 2 < net_structure_.size()) tmp = tanhf(tmp);
-        b[j] = tmp;
+        weighted_in_[l][(size_t)j] = tmp;
+        b[j] = (l + 1 < L) ? tanhf(tmp) : tmp;  // MPPI_NNET_NONLINEARITY; none on the last layer
       }
       off += (size_t)nin * nout + nout;
       a.swap(b);
     }
-    for (int i = 0; i < DYNAMICS_DIM; i++) sd[3 + i] = a[i];
-    for (int i = 0; i < STATE_DIM; i++) state[i] = fmaf(sd[i], dt_, state[i]);
+    for (int i = 0; i < DYNAMICS_DIM; i++) state_der_[3 + i] = a[i];
   }
+  // computeGrad, :233-264: 7 x 9 Jacobian of [kinematics | network] wrt [x | u]; d(yaw rate)/d(s6) is -1
+  // whatever negate_yaw_der says (the reference's quirk, :241)
+  void computeGrad(const float *state, const float *control)
+  {
+    for (int i = 0; i < STATE_DIM; i++)
+      for (int j = 0; j < STATE_DIM + CONTROL_DIM; j++) jac_[i][j] = 0.0f;
+    const float sn = sinf(state[2]), cs = cosf(state[2]);
+    jac_[0][2] = -sn * state[4] - cs * state[5]; jac_[0][4] = cs; jac_[0][5] = -sn;
+    jac_[1][2] = cs * state[4] - sn * state[5];  jac_[1][4] = sn; jac_[1][5] = cs;
+    jac_[2][6] = -1.0f;
+    computeDynamics(state, control);  // "First do the forward pass"
+    const int L = (int)net_structure_.size() - 1;
+    std::vector<size_t> woff((size_t)L);
+    size_t off = 0;
+    for (int l = 0; l < L; l++) { woff[(size_t)l] = off; off += (size_t)(net_structure_[l] + 1) * net_structure_[l + 1]; }
+    // ip_delta_: [neurons of the current layer][4 outputs], starts as the identity at the output
+    std::vector<float> d((size_t)maxWidth() * 4, 0.0f), dn((size_t)maxWidth() * 4, 0.0f);
+    for (int c = 0; c < DYNAMICS_DIM; c++) d[(size_t)c * 4 + c] = 1.0f;
+    for (int l = L - 1; l >= 0; l--) {
+      const int nin = net_structure_[l], nout = net_structure_[l + 1];
+      const float *W = &net_params_[woff[(size_t)l]];
+      for (int i = 0; i < nin; i++)
+        for (int c = 0; c < DYNAMICS_DIM; c++) {
+          float s = 0.0f;
+          for (int k = 0; k < nout; k++) s += W[k * nin + i] * d[(size_t)k * 4 + c];  // W^T ip_delta
+          if (l > 0) {  // .* MPPI_NNET_NONLINEARITY_DERIV(weighted_in_[l-1]) = 1 - tanh^2
+            const float t = tanhf(weighted_in_[(size_t)l - 1][(size_t)i]);
+            s *= (1.0f - t * t);
+          }
+          dn[(size_t)i * 4 + c] = s;
+        }
+      d.swap(dn);
+    }
+    for (int o = 0; o < DYNAMICS_DIM; o++)  // bottomRightCorner(4, 6) += ip_delta_^T
+      for (int i = 0; i < DYNAMICS_DIM + CONTROL_DIM; i++) jac_[3 + o][3 + i] += d[(size_t)i * 4 + o];
+  }
+  // updateState, :280-288: clamp, kinematics, network, Euler step; state_der_ is zero afterwards
+  void updateState(float *state, float *control)
+  {
+    enforceConstraints(state, control);
+    computeKinematics(state);
+    computeDynamics(state, control);
+    for (int i = 0; i < STATE_DIM; i++) {
+      state[i] = fmaf(state_der_[i], dt_, state[i]);
+      state_der_[i] = 0.0f;
+    }
+  }
+  // The policy objects own no device memory and no stream in this build (the controller's handle does), so
+  // these members of the reference's Managed interface (managed.cuh, neural_net_model.cu:108-118,290-294)
+  // have nothing to do; they exist so that code written against the reference compiles and runs unchanged.
+  void bindToStream(void * /*hipStream_t*/) {}
+  void freeCudaMem() {}
 
   // paramsToDevice(), neural_net_model.cu:120-150 -- pushed into a controller's handle
   void paramsToDevice(mppi_handle *h)
@@ -133,7 +201,7 @@ class NeuralNetModel {
     float lo[2] = {control_rngs_[0].x, control_rngs_[1].x}, hi[2] = {control_rngs_[0].y, control_rngs_[1].y};
     check(mppi_set_control_limits(h, lo, hi), h);
   }
-  // bumped whenever host-side parameters change; controllers re-upload when they see a new value
+  // bumped whenever the network weights change; controllers re-upload when they see a new value
   unsigned version_ = 0;
   void touch() { version_++; }
 
@@ -152,6 +220,7 @@ class NeuralNetModel {
   }
   float dt_;
   std::vector<float> net_params_;
+  std::vector<std::vector<float>> weighted_in_;  // per layer, of the last computeDynamics
 };
 
 // ------------------------------------------------------------------------------------------
@@ -194,7 +263,7 @@ class GeneralizedLinear {
     version_++;
   }
   // host updateState (:140-167): clamp, kinematics, basis functions, W phi, Euler step
-  void updateState(float *state, float *control) const
+  void updateState(float *state, float *control)
   {
     for (int i = 0; i < CONTROL_DIM; i++) {
       if (control[i] < control_rngs_[i].x) control[i] = control_rngs_[i].x;
@@ -218,6 +287,8 @@ class GeneralizedLinear {
   }
   // updateModel(description, data): empty in the reference too (generalized_linear.cuh:88)
   void updateModel(const std::vector<int> &, const std::vector<float> &) {}
+  void bindToStream(void * /*hipStream_t*/) {}  // see NeuralNetModel
+  void freeCudaMem() {}
   unsigned version_ = 0;
   void touch() { version_++; }
 
@@ -329,8 +400,7 @@ class MPPICosts {
   {
     params_.r_c1[0] = m[0]; params_.r_c1[1] = m[3]; params_.r_c1[2] = m[6];
     params_.r_c2[0] = m[1]; params_.r_c2[1] = m[4]; params_.r_c2[2] = m[7];
-    for (int i = 0; i < 3; i++) params_.trs[i] = trs[i];
-    map_version_++;
+    for (int i = 0; i < 3; i++) params_.trs[i] = trs[i];  // pushed with the next solve (syncParams compares params_)
   }
 
   float getDesiredSpeed() const { return params_.desired_speed; }
@@ -338,6 +408,28 @@ class MPPICosts {
   // empty bodies in the reference too (costs.cu:297-299)
   void updateCostmap(const std::vector<int> &, const std::vector<float> &) {}
   void updateObstacles(const std::vector<int> &, const std::vector<float> &) {}
+
+  // getDebugDisplay(x, y, heading), costs.cu:272-285 -> debugCostKernel (debug_kernels.cuh:39-88), without the
+  // cv::Mat: the raster [height_m*ppm][width_m*ppm], debugDisplayInit's default window 10 m x 10 m at 50 px/m.
+  // The costs object owns no device state here; the raster runs on the handle of a controller that uses
+  // this object (the last one constructed binds itself), with the current params_ pushed first.
+  std::vector<float> getDebugDisplay(float x, float y, float heading, int width_m = 10, int height_m = 10, int ppm = 50)
+  {
+    if (!bound_) throw std::runtime_error("MPPICosts::getDebugDisplay: no controller uses this costs object");
+    paramsToDevice(bound_, false);
+    NeuralNetModel::check(mppi_set_costmap_transform(bound_, params_.r_c1, params_.r_c2, params_.trs), bound_);
+    std::vector<float> img((size_t)width_m * ppm * height_m * ppm);
+    NeuralNetModel::check(mppi_debug_cost_raster(bound_, x, y, heading, width_m, height_m, ppm, img.data(), img.size()), bound_);
+    return img;
+  }
+  void bindHandle(mppi_handle *h) { bound_ = h; }
+  void unbindHandle(mppi_handle *h) { if (bound_ == h) bound_ = nullptr; }
+  // Managed interface of the reference (managed.cuh): nothing to do here, see NeuralNetModel::bindToStream.
+  // paramsToDevice() without a handle asks every controller to push params_ again at its next solve (they do
+  // so anyway whenever params_ differs from what they pushed last, like mppi_controller.cu:605).
+  void bindToStream(void * /*hipStream_t*/) {}
+  void freeCudaMem() {}
+  void paramsToDevice() { version_++; }
 
   // paramsToDevice + costmapToTexture for one controller's handle
   void paramsToDevice(mppi_handle *h, bool with_map)
@@ -352,6 +444,9 @@ class MPPICosts {
     NeuralNetModel::check(mppi_set_cost_params(h, &p), h);
   }
   unsigned version_ = 0, map_version_ = 0;
+
+ private:
+  mppi_handle *bound_ = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -399,6 +494,7 @@ class MPPIControllerT {
     state_solution_.assign((size_t)numTimesteps_ * STATE_DIM, 0.0f);
     control_solution_.assign((size_t)numTimesteps_ * CONTROL_DIM, 0.0f);
     syncParams(true);
+    costs_->bindHandle(h_);
   }
   ~MPPIControllerT() { deallocateCudaMem(); }
   MPPIControllerT(const MPPIControllerT &) = delete;
@@ -406,18 +502,19 @@ class MPPIControllerT {
 
   void deallocateCudaMem()
   {
-    if (h_) mppi_destroy(h_);
+    if (h_) {
+      costs_->unbindHandle(h_);
+      mppi_destroy(h_);
+    }
     h_ = nullptr;
   }
   mppi_handle *handle() { return h_; }
 
   void resetControls() { ck(mppi_reset_controls(h_)); }
-  void cutThrottle()  // mppi_controller.cu:460-466
+  void cutThrottle()  // mppi_controller.cu:460-466: plain writes to the public members; the next solve pushes them
   {
     costs_->params_.desired_speed = 0.0f;
-    costs_->version_++;
     model_->control_rngs_[1].y = 0.0f;
-    model_->touch();
   }
   // OptimizerResult of ddp/result.h, flattened
   struct FeedbackResult {
@@ -494,8 +591,8 @@ class MPPIControllerT {
   {
     ck(mppi_nominal_traj(h_, state, state_solution_.data(), control_solution_.data()));
   }
-  // costs_->getDebugDisplay(x, y, heading) (costs.cu:272-285) without the cv::Mat: the raster of
-  // debugCostKernel, [height_m*ppm][width_m*ppm]; debugDisplayInit's default window is 10 m x 10 m at 50 px/m
+  // shim kept from round 1: the raster on THIS controller's handle; the reference's call site is
+  // costs_->getDebugDisplay (run_control_loop.cuh:171), which MPPICosts has itself now
   std::vector<float> getDebugDisplay(float x, float y, float heading, int width_m = 10, int height_m = 10, int ppm = 50)
   {
     syncParams(false);
@@ -515,17 +612,36 @@ class MPPIControllerT {
 
  private:
   void ck(int rc) { NeuralNetModel::check(rc, h_); }
+  // costs_->paramsToDevice(); model_->paramsToDevice(); of every computeControl (mppi_controller.cu:605-606).
+  // The reference uploads unconditionally, so plain writes to the public members (costs_->params_,
+  // costs_->l1_cost_, model_->control_rngs_) take effect at the next solve; here the upload happens when the
+  // members differ from the copy pushed last (a 100-byte compare per solve) or a version counter moved
+  // (network weights, costmap texels: changed through loadParams / updateModel / loadTrackData only).
   void syncParams(bool force)
   {
     if (force || model_seen_ != model_->version_) {
-      model_->paramsToDevice(h_);
+      model_->paramsToDevice(h_);  // weights + control ranges
       model_seen_ = model_->version_;
-      first_model_ = false;
+      for (int i = 0; i < CONTROL_DIM; i++) pushed_rngs_[i] = model_->control_rngs_[i];
+    } else if (std::memcmp(pushed_rngs_, model_->control_rngs_.data(), sizeof(pushed_rngs_)) != 0) {
+      const float lo[2] = {model_->control_rngs_[0].x, model_->control_rngs_[1].x};
+      const float hi[2] = {model_->control_rngs_[0].y, model_->control_rngs_[1].y};
+      ck(mppi_set_control_limits(h_, lo, hi));
+      for (int i = 0; i < CONTROL_DIM; i++) pushed_rngs_[i] = model_->control_rngs_[i];
     }
-    if (force || cost_seen_ != costs_->version_ || map_seen_ != costs_->map_version_) {
-      costs_->paramsToDevice(h_, force || map_seen_ != costs_->map_version_);
+    const MPPICosts::CostParams &p = costs_->params_;
+    const bool map_new = force || map_seen_ != costs_->map_version_;
+    const bool changed = force || cost_seen_ != costs_->version_ || pushed_l1_ != costs_->l1_cost_ ||
+                         std::memcmp(&pushed_params_, &p, sizeof(p)) != 0;
+    if (map_new || changed) {
+      if (!map_new && (std::memcmp(pushed_params_.r_c1, p.r_c1, sizeof(p.r_c1)) || std::memcmp(pushed_params_.r_c2, p.r_c2, sizeof(p.r_c2)) ||
+                       std::memcmp(pushed_params_.trs, p.trs, sizeof(p.trs))))
+        ck(mppi_set_costmap_transform(h_, p.r_c1, p.r_c2, p.trs));  // updateTransform, costs.cu:175-188
+      costs_->paramsToDevice(h_, map_new);
       cost_seen_ = costs_->version_;
       map_seen_ = costs_->map_version_;
+      pushed_params_ = p;
+      pushed_l1_ = costs_->l1_cost_;
     }
   }
   mppi_handle *h_ = nullptr;
@@ -534,7 +650,9 @@ class MPPIControllerT {
   std::vector<float> state_solution_, control_solution_;
   FeedbackResult result_;
   unsigned model_seen_ = 0, cost_seen_ = 0, map_seen_ = 0;
-  bool first_model_ = true;
+  MPPICosts::CostParams pushed_params_{};
+  bool pushed_l1_ = false;
+  float2_ pushed_rngs_[CONTROL_DIM] = {{0, 0}, {0, 0}};
 };
 
 // MPPIController<DynamicsModel, MPPICosts, ...> of the two reference builds (path_integral_main.cu:65-78)

@@ -48,6 +48,13 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
   bool have_dcfg = false, debug_image = false;  // stand-ins for the plant's dynamic_reconfigure / debug window
   double dcfg_speed = 0.0;
   std::vector<std::string> overrides;
+  // --pose-script "0.02,0.04,0,0.06": a scripted pose source instead of the debug-mode self-simulation -- the
+  // time between the pose stamps of successive ticks (SimPlant); the live-pose half of runControlLoop runs
+  const char *pose_script = nullptr;
+  // --poke-desired-speed V / --poke-max-throttle V: at tick 5 a PLAIN WRITE to the public members
+  // costs.params_.desired_speed / model.control_rngs_[1].y (no setter, no version bump), as code written against
+  // the reference does (e.g. cutThrottle, mppi_controller.cu:460-466); the next solve must see it
+  double poke_speed = -1.0, poke_throttle = -1.0;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--rollouts") && i + 1 < argc) rollouts = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--layers") && i + 1 < argc) layers = parse_layers(argv[++i]);
@@ -58,6 +65,9 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     else if (!strcmp(argv[i], "--no-sleep")) sleep_to_rate = false;
     else if (!strcmp(argv[i], "--dcfg-desired-speed") && i + 1 < argc) { dcfg_speed = atof(argv[++i]); have_dcfg = true; }
     else if (!strcmp(argv[i], "--debug-image")) debug_image = true;
+    else if (!strcmp(argv[i], "--pose-script") && i + 1 < argc) pose_script = argv[++i];
+    else if (!strcmp(argv[i], "--poke-desired-speed") && i + 1 < argc) poke_speed = atof(argv[++i]);
+    else if (!strcmp(argv[i], "--poke-max-throttle") && i + 1 < argc) poke_throttle = atof(argv[++i]);
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
@@ -74,7 +84,7 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
       else params[k] = ParamValue(v);
     }
     if (max_iter >= 0) params["profiler_max_iter"] = ParamValue(max_iter);
-    params["debug_mode"] = ParamValue(true);  // headless: always the self-simulating mode
+    params["debug_mode"] = ParamValue(pose_script == nullptr);  // headless: self-simulation unless poses are scripted
 
     MPPICosts costs(&params);
     const float2_ control_constraints[2] = {{-.99f, .99f}, {-.99f, (float)(double)params["max_throttle"]}};
@@ -96,6 +106,28 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
       robot.dcfg.desired_speed = dcfg_speed;
     }
     robot.want_debug_image = debug_image;
+    if (poke_speed >= 0.0 || poke_throttle >= 0.0)
+      robot.on_tick = [&costs, &model, poke_speed, poke_throttle](int tick) {
+        if (tick != 5) return;
+        if (poke_speed >= 0.0) costs.params_.desired_speed = (float)poke_speed;
+        if (poke_throttle >= 0.0) model.control_rngs_[1].y = (float)poke_throttle;
+      };
+    if (pose_script) {
+      sleep_to_rate = false;  // the scripted clock only advances when a solution is handed over: nothing to wait for
+      robot.live = true;
+      robot.hz = hz;
+      robot.pose_time = 1000.0;  // any stamp
+      robot.fs.x_pos = (float)(double)params["x_pos"];
+      robot.fs.y_pos = (float)(double)params["y_pos"];
+      robot.fs.yaw = (float)(double)params["heading"];
+      for (const char *c = pose_script; *c;) {
+        char *e = nullptr;
+        robot.pose_script.push_back(strtod(c, &e));
+        c = (*e == ',') ? e + 1 : e;
+        if (e == c && *e) break;
+      }
+      robot.drive = [&model](float *x, float *u) { model.updateState(x, u); };
+    }
     std::atomic<bool> is_alive(true);
     FILE *trace = trace_path ? fopen(trace_path, "w") : nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -108,13 +140,17 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
       for (int i = 0; i < 7; i++) { g0 += robot.last_feedback_gains[i]; g1 += robot.last_feedback_gains[7 + i]; }
     double img_sum = 0.0;
     for (float v : robot.debug_image) img_sum += v;
+    std::string strides;
+    for (int v : st.strides) strides += (strides.empty() ? "" : " ") + std::to_string(v);
     printf("{\"iterations\": %d, \"rollouts\": %d, \"timesteps\": %d, \"avg_tick_ms\": %.4f, \"avg_sleep_ms\": %.4f, "
            "\"wall_s\": %.4f, \"actual_state_used\": %d, \"final_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f], "
            "\"feedback_gain_row_sums_t0\": [%.6f, %.6f], \"desired_speed\": %.4f, \"debug_image_pixels\": %zu, "
-           "\"debug_image_sum\": %.4f}\n",
+           "\"debug_image_sum\": %.4f, \"avg_loop_ms\": %.4f, \"strides\": \"%s\", \"plant_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f]}\n",
            st.iterations, actual.NUM_ROLLOUTS, T, st.avg_tick_ms, st.avg_sleep_ms, wall, robot.n_actual,
            st.final_state[0], st.final_state[1], st.final_state[2], st.final_state[3], st.final_state[4],
-           st.final_state[5], st.final_state[6], g0, g1, costs.params_.desired_speed, robot.debug_image.size(), img_sum);
+           st.final_state[5], st.final_state[6], g0, g1, costs.params_.desired_speed, robot.debug_image.size(), img_sum,
+           st.avg_loop_ms, strides.c_str(), robot.fs.x_pos, robot.fs.y_pos, robot.fs.yaw, robot.fs.roll, robot.fs.u_x,
+           robot.fs.u_y, robot.fs.yaw_mder);
   } catch (const std::exception &e) {
     fprintf(stderr, "path_integral_nn: %s\n", e.what());
     return 1;

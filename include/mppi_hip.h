@@ -125,6 +125,9 @@ int mppi_set_control_limits(mppi_handle *h, const float umin[2], const float uma
  * filter, clamp, normalised coordinates. */
 int mppi_set_costmap(mppi_handle *h, int width, int height, const float *rgba,
                      const float r_c1[3], const float r_c2[3], const float trs[3]);
+/* MPPICosts::updateTransform + paramsToDevice (costs.cu:175-188, 234-238): the coordinate transform alone
+ * (r_c1, r_c2, trs are public members of CostParams; the texture stays). */
+int mppi_set_costmap_transform(mppi_handle *h, const float r_c1[3], const float r_c2[3], const float trs[3]);
 /* costmapToTexture(float*, channel) (costs.cu:101-126). */
 int mppi_set_costmap_channel(mppi_handle *h, int channel, const float *data, size_t n);
 /* updateParams / updateParams_dcfg / paramsToDevice (costs.cu:156-173, 75-87, 234-238). */

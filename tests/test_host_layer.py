@@ -155,13 +155,90 @@ def test_live_update_hooks_and_debug_raster(bins, golden_dir, tmp_path):
     base = [bins["path_integral_nn"], launch_path, "--rollouts", "512", "--max-iter", "30", "--no-sleep",
             "--set", "x_pos=0.0", "--set", "y_pos=-10.0", "--set", "heading=0.0", "--set", "use_feedback_gains=false"]
     outs = {}
-    for tag, extra in (("plain", []), ("slow", ["--dcfg-desired-speed", "2.0", "--debug-image"])):
+    for tag, extra in (("plain", []), ("slow", ["--dcfg-desired-speed", "2.0", "--debug-image"]),
+                       ("poked", ["--poke-desired-speed", "2.0"]), ("cut", ["--poke-max-throttle", "0.0"])):
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr
         outs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
     assert outs["plain"]["desired_speed"] == 8.0 and outs["plain"]["debug_image_pixels"] == 0  # launch value, no window
     assert outs["slow"]["desired_speed"] == 2.0
     assert outs["slow"]["final_state"][4] < outs["plain"]["final_state"][4] - 0.5  # the car really drives slower
+    # plain writes to the public members at tick 5 (no setter, no version bump) reach the next solves, like the
+    # unconditional paramsToDevice of mppi_controller.cu:605-606: a lower desired speed, a throttle range cut to 0
+    assert outs["poked"]["desired_speed"] == 2.0
+    assert outs["poked"]["final_state"][4] < outs["plain"]["final_state"][4] - 0.5
+    assert outs["cut"]["final_state"][4] < outs["poked"]["final_state"][4]  # coasting from tick 5 on
     # the raster handed over at the last tick: 10 m x 10 m at 50 px/m around the predicted state
     assert outs["slow"]["debug_image_pixels"] == 500 * 500
     assert 0.0 < outs["slow"]["debug_image_sum"] < 500 * 500 * 10.0  # the synthetic map rises above 1 off the track
+
+
+@pytest.mark.gpu
+def test_live_pose_loop_against_the_oracle(bins, golden_dir, tmp_path):
+    """The live-pose half of runControlLoop (run_control_loop.cuh:140-144, 175-181, 206-216) in the C++ binary,
+    driven by a scripted pose clock (1, 2, 1, 3, 1 control periods between poses), against a Python statement of
+    the same loop in which the ORACLE is the solver of both controllers (same generator streams: seed 1234,
+    2T draws per solve) and the model of the plant.  Per tick: the stride slid by, the controller chosen,
+    both trajectory costs, the plant state the next tick starts from, the first control handed over."""
+    from oracle import oracle as O
+    model_file, map_file = "autorally_nnet_09_12_2018.npz", "ccrf_costmap_09_29_2017.npz"
+    d = _params_dir(tmp_path, golden_dir, model_file, map_file)
+    launch_path = os.path.join(ROOT, "autorally_amd", "host", "launch", "path_integral_nn.launch")
+    K, T, hz = 1024, 100, 50
+    script = [0.02, 0.04, 0.02, 0.06, 0.02, 0.02]
+    iters = len(script)
+    start = (0.0, -10.0, 0.0)
+    trace = os.path.join(str(tmp_path), "trace.txt")
+    r = subprocess.run([bins["path_integral_nn"], launch_path, "--rollouts", str(K), "--max-iter", str(iters),
+                        "--pose-script", ",".join("%r" % v for v in script), "--set", "use_feedback_gains=false",
+                        "--set", "x_pos=%r" % start[0], "--set", "y_pos=%r" % start[1], "--set", "heading=%r" % start[2],
+                        "--trace", trace], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, AR_MPPI_PARAMS_PATH=d))
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    want_strides = [1] + [int(round(v * hz)) for v in script[:-1]]   # tick 1: status still 1 -> optimization_stride
+    assert out["iterations"] == iters and [int(v) for v in out["strides"].split()] == want_strides
+    rows = [l.split() for l in open(trace).read().splitlines()]
+
+    m, r_c1, r_c2, trs = P.load_costmap_npz(os.path.join(d, "maps", map_file))
+    layers, theta = P.load_model_npz(os.path.join(d, "models", model_file))
+    cfg = dict(K=K, T=T, map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs, cost=dict(P.DEFAULT_COST), seed=1234, layers=layers, theta=theta)
+    cfg.update(P.DEFAULT_CTRL)
+    plant = np.array([start[0], start[1], start[2], 0, 0, 0, 0], np.float32)
+    orc = O.Oracle(dict(cfg, start_state=plant), fma_mode=1, nthreads=8)
+    ctl = {n: dict(U=np.tile(np.array(cfg["init_u"], np.float32), (T, 1)), hist=np.zeros(4, np.float32), off=0,
+                   ss=np.tile(plant, (T, 1)).astype(np.float32) * 0) for n in ("a", "p")}
+    ctl["a"]["ss"][0] = plant
+    ctl["p"]["ss"][0] = plant
+
+    def solve(c, state):
+        eps = O.generate_noise(1234, c["off"], K, T)[None]
+        c["off"] += 2 * T
+        res = orc.compute_control(state, c["U"], c["hist"], eps)
+        c["U"] = res["U"]
+        c["ss"], c["cs"] = orc.nominal_traj(state, res["U"])
+        return res["traj_cost"]
+
+    state = plant.copy()
+    for it in range(iters):
+        stride = want_strides[it]
+        for c in ctl.values():
+            c["U"], c["hist"] = orc.slide_control_seq(c["U"], c["hist"], cfg["init_u"], stride)
+            c["ss"][:T - stride] = c["ss"][stride:].copy()
+        ca = solve(ctl["a"], state)
+        cp = solve(ctl["p"], ctl["p"]["ss"][0].copy())
+        used = "actual" if ca < cp else "predicted"
+        chosen = ctl["a"] if ca < cp else ctl["p"]
+        if ca < cp:  # run_control_loop.cuh:255-258: only the sequences the controller reports move over, not U_
+            ctl["p"]["ss"], ctl["p"]["cs"] = ctl["a"]["ss"].copy(), ctl["a"]["cs"].copy()
+        cs = chosen["cs"]
+        n = int(round(script[it] * hz))
+        for t in range(n):
+            state, _ = orc.update_state(state, cs[t].copy())
+        row = rows[it]
+        assert row[1] == used, (it, row, ca, cp)
+        assert abs(float(row[2]) - ca) <= 2e-3 * abs(ca) and abs(float(row[3]) - cp) <= 2e-3 * abs(cp), (it, row, ca, cp)
+        assert abs(float(row[11]) - cs[0][0]) <= 2e-3 and abs(float(row[12]) - cs[0][1]) <= 2e-3, (it, row, cs[0])
+        assert int(row[14]) == stride
+    np.testing.assert_allclose(out["plant_state"], state, atol=3e-3, rtol=1e-3)
+    assert out["plant_state"][4] > 0.2  # the car drove: 8 control periods from rest
