@@ -86,6 +86,8 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
   float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == 1 + w);
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+  // (s_setprio 3 here -- issue priority over the cost / control wave sharing this wave's SIMD -- changes nothing:
+  //  cfg 4 304.4 us without, 305.5 us with; the co-resident wave's instructions cost their issue cycles either way)
   float b1_next = *p_b1;
   int cd = 0;  // last value seen of the cost wave's consumption counter
   for (int t = 0; t < T; t++) {
