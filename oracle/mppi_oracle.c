@@ -4,9 +4,11 @@
  * TEST INFRASTRUCTURE ONLY: checker for tests/, smoke() and bench.py's
  * cpu_baseline leg.  Never linked into or called from the product library.
  *
- * Parity: "unpinned" for rollout/cost/weighting/reduction (the reference has no
+ * Parity: "unpinned" for rollout bookkeeping and the cost terms (the reference has no
  * fixtures and its CUDA cannot be built here); NN dynamics pinned by
- * tests/golden/nn_dynamics_golden.npz; MRG32k3a pinned by published jump matrices.
+ * tests/golden/nn_dynamics_golden.npz; MRG32k3a pinned by published jump matrices; the
+ * smoothing filter, the softmax weighting and the noise distribution by scipy's statements
+ * of the published algorithms (tests/test_oracle_golden.py).
  *
  * Build: gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp (oracle/Makefile).
  * -ffp-contract=off is REQUIRED: every fused multiply-add below is an explicit

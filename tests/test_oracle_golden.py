@@ -230,3 +230,62 @@ def test_costmap_file_written_by_reference_track_generator(golden_dir):
         b = m[row, min(W - 1, max(0, int((qx - 0.5 - x0) * ppm))), 0]
         got = orc.compute_cost(s, np.zeros(2, np.float32), np.zeros(2, np.float32))[0]
         assert abs(got - (abs(f) + abs(b)) / 2) < 1e-5 * max(1.0, abs(got)), (qx, qy, got, f, b)
+
+
+# ------------------------------------------------------------------ third-party known answers (scipy)
+def test_savgol_is_the_published_quadratic_5_tap_filter():
+    """mppi_controller.cu:468-499 hard-codes [-3, 12, 17, 12, -3] / 35: the Savitzky-Golay smoothing filter of
+    window 5 and polynomial order 2 (or 3).  Pinned against scipy's derivation of the same filter: the
+    coefficients, and the oracle's output away from the padded ends against scipy.signal.savgol_filter."""
+    from scipy.signal import savgol_coeffs, savgol_filter
+    np.testing.assert_allclose(savgol_coeffs(5, 2), np.array([-3, 12, 17, 12, -3]) / 35.0, atol=1e-15)
+    np.testing.assert_allclose(savgol_coeffs(5, 3), np.array([-3, 12, 17, 12, -3]) / 35.0, atol=1e-15)
+    cfg = S.make_config(64, 60, track="ring")
+    orc = O.Oracle(cfg)
+    rng = np.random.RandomState(3)
+    U = np.cumsum(rng.standard_normal((60, 2)) * 0.05, axis=0).astype(np.float32)
+    hist = rng.standard_normal(4).astype(np.float32) * 0.1
+    got = orc.savgol(U, hist)
+    ref = savgol_filter(U.astype(np.float64), 5, 2, axis=0)
+    np.testing.assert_allclose(got[2:-2], ref[2:-2], atol=5e-7)
+    # the ends follow the reference's padding: [hist0, hist1, U..., U_last, U_last] (:476-489)
+    X = np.concatenate([hist.reshape(2, 2), U, U[-1:], U[-1:]]).astype(np.float64)
+    c = np.array([-3, 12, 17, 12, -3]) / 35.0
+    full = np.stack([np.convolve(X[:, j], c[::-1], mode="valid") for j in range(2)], 1)
+    np.testing.assert_allclose(got, full, atol=5e-7)
+
+
+def test_weights_are_a_softmax_and_trajectory_cost_follows():
+    """normExpKernel + the host normaliser (mppi_controller.cu:193-203, 627-652): w / eta is the softmax of
+    -gamma * J (scipy.special.softmax), and trajectory_cost_ is sum w^2 / eta (Q8)."""
+    from scipy.special import softmax
+    cfg = S.make_config(256, 20, track="ring")
+    orc = O.Oracle(cfg)
+    rng = np.random.RandomState(11)
+    J = (40.0 + 30.0 * rng.rand(256)).astype(np.float32)
+    J[7] = 1e12  # a capped rollout weighs nothing
+    w, beta, eta, tc = orc.weights(J)
+    p = softmax(-cfg["gamma"] * J.astype(np.float64))
+    np.testing.assert_allclose(w / eta, p, rtol=2e-6, atol=1e-12)
+    assert beta == J.min() and w[np.argmin(J)] == 1.0 and w[7] == 0.0
+    np.testing.assert_allclose(tc, float((p ** 2).sum() * eta), rtol=1e-5)
+
+
+def test_generated_noise_is_standard_normal_and_uncorrelated():
+    """The noise spec (MRG32k3a + Box-Muller written in IEEE basic operations) against scipy.stats: a
+    Kolmogorov-Smirnov test on 200 000 draws, the two members of a Box-Muller pair uncorrelated, successive
+    timesteps and neighbouring rollouts (subsequences 2^76 apart) uncorrelated."""
+    from scipy import stats
+    K, T = 1000 // 64 * 64 + 64, 100
+    e = O.generate_noise(4321, 0, K, T).astype(np.float64)
+    flat = e.reshape(-1)
+    assert flat.size >= 200000
+    assert stats.kstest(flat, "norm").pvalue > 1e-3
+    assert stats.kstest(e[..., 0].reshape(-1), "norm").pvalue > 1e-3 and stats.kstest(e[..., 1].reshape(-1), "norm").pvalue > 1e-3
+    n = e[..., 0].size
+    bound = 5.0 / np.sqrt(n)
+    assert abs(np.corrcoef(e[..., 0].reshape(-1), e[..., 1].reshape(-1))[0, 1]) < bound
+    assert abs(np.corrcoef(e[:, :-1, 0].reshape(-1), e[:, 1:, 0].reshape(-1))[0, 1]) < bound
+    assert abs(np.corrcoef(e[:-1, :, 0].reshape(-1), e[1:, :, 0].reshape(-1))[0, 1]) < bound
+    # tails exist and are finite: |z| up to ~4.9 expected in 2e5 draws, none absurd
+    assert 3.5 < np.abs(flat).max() < 6.5
