@@ -359,20 +359,25 @@ def main():
             }
             if "quad" in variant and cfg.get("bf_W") is None:
                 # The configuration is latency bound (one 16-rollout group per CU, T sequential steps), so next
-                # to the throughput roofline: the step time of the recurrence against what its two dynamics
-                # wavefronts must at least issue (f32 MFMA = 32 cycles, tanh = 38 cycles per
-                # register with packed multiply-adds, MFMA and VALU do not overlap on a SIMD).
+                # to the throughput roofline: the step time of the recurrence against (a) what its two dynamics
+                # wavefronts must at least ISSUE and (b) the floor of this decomposition with its dependency
+                # latencies and one hand-over per swap (tools/ub/*.hip, tools/quad_stamps.py:
+                # f32 MFMA 32.6 cycles, tanh 28.8 cycles per register with packed multiply-adds, MFMA and VALU do
+                # not overlap inside a wave, ~95 cycles of exposed latency per layer boundary, >= 190 per hand-over).
                 H, nh = cfg["layers"][1], len(cfg["layers"]) - 2
                 mt, ksh = H // 16, H // 4
                 mfma = 2 * mt + (nh - 1) * (mt // 2) * ksh + ksh          # layer 0 on both waves, own tiles, output layer
                 tanh = 4 * mt + (nh - 1) * 4 * (mt // 2)
-                floor = 32 * mfma + 38 * tanh
-                clk_ghz = 2.4
+                issue = 32.6 * mfma + 28.8 * tanh
+                floor = issue + 95.0 * (nh + 1) + 190.0 * (nh - 1)
+                clk_ghz = 2.3  # in-kernel s_memtime cycles per step x T against the rocprofv3 duration
                 cyc = rollout_s / T * clk_ghz * 1e9
                 out["roofline"]["recurrence"] = {
-                    "cycles_per_step": cyc, "issue_floor_cycles_per_step": floor, "frac_of_floor": floor / cyc if cyc > 0 else 0.0,
+                    "cycles_per_step": cyc, "issue_cycles_per_step": issue, "decomposition_floor_cycles_per_step": floor,
+                    "frac_of_floor": floor / cyc if cyc > 0 else 0.0,
                     "mfma_per_step": mfma, "tanh_per_lane_per_step": tanh, "clock_GHz": clk_ghz,
-                    "note": "kernel time / T, launch and prologue included"}
+                    "note": "event-measured kernel time / T (launch, prologue and the events' own overhead included) at the clock "
+                            "the chip holds under this kernel; stamped phases: profiles/r02_b_quad_dynamics_wave_stamps_h32.json"}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
