@@ -174,12 +174,17 @@ def test_live_update_hooks_and_debug_raster(bins, golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
-def test_live_pose_loop_against_the_oracle(bins, golden_dir, tmp_path):
-    """The live-pose half of runControlLoop (run_control_loop.cuh:140-144, 175-181, 206-216) in the C++ binary,
-    driven by a scripted pose clock (1, 2, 1, 3, 1 control periods between poses), against a Python statement of
-    the same loop in which the ORACLE is the solver of both controllers (same generator streams: seed 1234,
-    2T draws per solve) and the model of the plant.  Per tick: the stride slid by, the controller chosen,
-    both trajectory costs, the plant state the next tick starts from, the first control handed over."""
+@pytest.mark.parametrize("mode", ["live", "debug"])
+def test_control_loop_against_the_oracle(bins, golden_dir, tmp_path, mode):
+    """runControlLoop in the C++ binary against a Python statement of the same loop in which the ORACLE is the
+    solver of both controllers (same generator streams: seed 1234, 2T draws per solve) and the model that moves
+    the car -- loop parity, not the solver compared with itself.
+      live:  the live-pose half (run_control_loop.cuh:140-144, 175-181, 206-216) under a scripted pose clock
+             (1, 2, 1, 3, 1 control periods between poses): the plant drives the handed-over solution;
+      debug: the self-simulating half (:296-302), stride = optimization_stride, the state advanced TWICE per
+             executed control (both controllers share one model object).
+    Per tick: the stride slid by, the controller chosen, both trajectory costs, the first control handed over;
+    at the end the state."""
     from oracle import oracle as O
     model_file, map_file = "autorally_nnet_09_12_2018.npz", "ccrf_costmap_09_29_2017.npz"
     d = _params_dir(tmp_path, golden_dir, model_file, map_file)
@@ -189,14 +194,17 @@ def test_live_pose_loop_against_the_oracle(bins, golden_dir, tmp_path):
     iters = len(script)
     start = (0.0, -10.0, 0.0)
     trace = os.path.join(str(tmp_path), "trace.txt")
+    extra = ["--pose-script", ",".join("%r" % v for v in script)] if mode == "live" else ["--no-sleep"]
     r = subprocess.run([bins["path_integral_nn"], launch_path, "--rollouts", str(K), "--max-iter", str(iters),
-                        "--pose-script", ",".join("%r" % v for v in script), "--set", "use_feedback_gains=false",
-                        "--set", "x_pos=%r" % start[0], "--set", "y_pos=%r" % start[1], "--set", "heading=%r" % start[2],
-                        "--trace", trace], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, AR_MPPI_PARAMS_PATH=d))
+                        "--set", "use_feedback_gains=false", "--set", "x_pos=%r" % start[0], "--set", "y_pos=%r" % start[1],
+                        "--set", "heading=%r" % start[2], "--trace", trace] + extra, capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, AR_MPPI_PARAMS_PATH=d))
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    want_strides = [1] + [int(round(v * hz)) for v in script[:-1]]   # tick 1: status still 1 -> optimization_stride
+    if mode == "live":
+        want_strides = [1] + [int(round(v * hz)) for v in script[:-1]]   # tick 1: status still 1 -> optimization_stride
+    else:
+        want_strides = [1] * iters
     assert out["iterations"] == iters and [int(v) for v in out["strides"].split()] == want_strides
     rows = [l.split() for l in open(trace).read().splitlines()]
 
@@ -204,22 +212,21 @@ def test_live_pose_loop_against_the_oracle(bins, golden_dir, tmp_path):
     layers, theta = P.load_model_npz(os.path.join(d, "models", model_file))
     cfg = dict(K=K, T=T, map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs, cost=dict(P.DEFAULT_COST), seed=1234, layers=layers, theta=theta)
     cfg.update(P.DEFAULT_CTRL)
-    plant = np.array([start[0], start[1], start[2], 0, 0, 0, 0], np.float32)
-    orc = O.Oracle(dict(cfg, start_state=plant), fma_mode=1, nthreads=8)
+    state = np.array([start[0], start[1], start[2], 0, 0, 0, 0], np.float32)
+    orc = O.Oracle(dict(cfg, start_state=state), fma_mode=1, nthreads=8)
     ctl = {n: dict(U=np.tile(np.array(cfg["init_u"], np.float32), (T, 1)), hist=np.zeros(4, np.float32), off=0,
-                   ss=np.tile(plant, (T, 1)).astype(np.float32) * 0) for n in ("a", "p")}
-    ctl["a"]["ss"][0] = plant
-    ctl["p"]["ss"][0] = plant
+                   ss=np.zeros((T, 7), np.float32)) for n in ("a", "p")}
+    ctl["a"]["ss"][0] = state
+    ctl["p"]["ss"][0] = state
 
-    def solve(c, state):
+    def solve(c, x):
         eps = O.generate_noise(1234, c["off"], K, T)[None]
         c["off"] += 2 * T
-        res = orc.compute_control(state, c["U"], c["hist"], eps)
+        res = orc.compute_control(x, c["U"], c["hist"], eps)
         c["U"] = res["U"]
-        c["ss"], c["cs"] = orc.nominal_traj(state, res["U"])
+        c["ss"], c["cs"] = orc.nominal_traj(x, res["U"])
         return res["traj_cost"]
 
-    state = plant.copy()
     for it in range(iters):
         stride = want_strides[it]
         for c in ctl.values():
@@ -232,13 +239,17 @@ def test_live_pose_loop_against_the_oracle(bins, golden_dir, tmp_path):
         if ca < cp:  # run_control_loop.cuh:255-258: only the sequences the controller reports move over, not U_
             ctl["p"]["ss"], ctl["p"]["cs"] = ctl["a"]["ss"].copy(), ctl["a"]["cs"].copy()
         cs = chosen["cs"]
-        n = int(round(script[it] * hz))
-        for t in range(n):
-            state, _ = orc.update_state(state, cs[t].copy())
+        if mode == "live":
+            for t in range(int(round(script[it] * hz))):
+                state, _ = orc.update_state(state, cs[t].copy())
+        else:
+            state, _ = orc.update_state(state, cs[0].copy())  # once through each controller's model_ pointer
+            state, _ = orc.update_state(state, cs[0].copy())
         row = rows[it]
         assert row[1] == used, (it, row, ca, cp)
         assert abs(float(row[2]) - ca) <= 2e-3 * abs(ca) and abs(float(row[3]) - cp) <= 2e-3 * abs(cp), (it, row, ca, cp)
         assert abs(float(row[11]) - cs[0][0]) <= 2e-3 and abs(float(row[12]) - cs[0][1]) <= 2e-3, (it, row, cs[0])
         assert int(row[14]) == stride
-    np.testing.assert_allclose(out["plant_state"], state, atol=3e-3, rtol=1e-3)
-    assert out["plant_state"][4] > 0.2  # the car drove: 8 control periods from rest
+    got = out["plant_state"] if mode == "live" else out["final_state"]
+    np.testing.assert_allclose(got, state, atol=3e-3, rtol=1e-3)
+    assert got[4] > 0.2  # the car drove
