@@ -84,6 +84,34 @@ def init_dist(backend):
     return rank, local_rank, world, dist
 
 
+def pin_to_gpu_numa(device):
+    """Keeps this process (its solve thread polls the result block the GPU writes over PCIe) on the CPUs of the
+    NUMA node its GPU hangs off.  Best effort: returns a description, or the reason nothing was done."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return "unchanged (no PCI bus id)"
+        bus = buf.value.decode().lower()
+        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return "unchanged (device %s reports no NUMA node)" % bus
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "unchanged (no allowed CPU on node %d)" % node
+        os.sched_setaffinity(0, cpus)
+        return "NUMA node %d of GPU %s (%d CPUs)" % (node, bus, len(cpus))
+    except (OSError, ValueError, AttributeError) as e:
+        return "unchanged (%s)" % type(e).__name__
+
+
 def rank_workload(args, rank):
     """Instance `rank` of BASELINE configs[4]: its own costmap (rotated/offset oval), start state
     and RNG seed.  Rank 0 alone is configs[2]."""
@@ -208,6 +236,7 @@ def main():
     if cuda:
         import torch
         torch.cuda.set_device(local_rank)
+        affinity = pin_to_gpu_numa(local_rank)
         from autorally_amd import build as B
         if rank == 0:
             B.build()
@@ -324,6 +353,7 @@ def main():
                        "rollout_variant": sol.rollout_variant() if cuda else "none",
                        "step": "computeControl + slideControlSeq(1), result on the host before the next step",
                        "timed_loop": ("native (mppi_control_ticks)" if native else "python (one ctypes call per ABI call)"),
+                       "host_affinity": affinity if cuda else "unchanged",
                        "priming": "%d untimed solves (%.0f ms) before the %d warm-up steps" % (n_prime, args.prime_ms, args.warmup),
                        "parallelism": "replicas x%d (no collective)" % world},
             "state_updates_per_s": value * T,
