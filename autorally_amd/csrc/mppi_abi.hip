@@ -69,7 +69,7 @@ struct Events {
 
 struct mppi_handle {
   mppi_config cfg{};
-  int K = 0, T = 0;
+  int K = 0, T = 0, k99 = 0;
   float dt = 0.0f;
   NetDesc net{};
   bool mfma_ok = false;
@@ -318,7 +318,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.K = h->K;
   a.T = h->T;
   a.opt_delay = h->cfg.optimization_stride;
-  a.k99 = compute_k99(h->K);
+  a.k99 = h->k99;
   for (int i = 0; i < 2; i++) {
     a.nu[i] = h->cfg.exploration_std[i];
     a.u_lo[i] = h->u_lo[i];
@@ -658,6 +658,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   h->cfg = *cfg;
   h->K = cfg->num_rollouts;
   h->T = cfg->num_timesteps;
+  h->k99 = compute_k99(h->K);  // once: the search is O(K) and fill_rollout_args sits between two solves
   h->dt = (float)(1.0 / cfg->hz);  // path_integral_main.cu:100
   h->num_simds = 4 * (n_cus > 0 ? n_cus : 256);
   h->net.n_layers = cfg->n_layers;
