@@ -437,6 +437,12 @@ int upload_controls_if_dirty(mppi_handle *h)
   return MPPI_OK;
 }
 
+#ifdef MPPI_HOSTPROF
+static double hp_acc[8] = {0}, hp_n = 0;
+static std::chrono::steady_clock::time_point hp_seen;
+#define HP(i, t0) hp_acc[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - (t0)).count()
+#endif
+
 // Waits for the pending solve: polls the sequence number the tail kernel publishes (system-scope
 // release) in the host-mapped result block; no stream synchronise on the fast path.
 int wait_pending(mppi_handle *h)
@@ -465,6 +471,9 @@ int wait_pending(mppi_handle *h)
         return fail(h, MPPI_ERR_HIP, "timed out waiting for the solve");
     }
   }
+#ifdef MPPI_HOSTPROF
+  hp_seen = std::chrono::steady_clock::now();
+#endif
   h->pending = false;
   h->baseline = h->h_res[4 * h->T + 0];
   h->eta = h->h_res[4 * h->T + 2];
@@ -497,6 +506,9 @@ int wait_pending(mppi_handle *h)
       h->U[i] = acc;  // device U == host U again
     }
   }
+#ifdef MPPI_HOSTPROF
+  HP(4, hp_seen);
+#endif
   // The minimum-cost rollout has weight 1 and costs are capped (never NaN), so eta >= 1 always.
   // Anything else means a rollout wavefront gave up on a hand-over (its spin budget) and poisoned
   // its costs: report it instead of returning a NaN control sequence.
@@ -521,6 +533,10 @@ int collect(mppi_handle *h) { return wait_pending(h); }
 
 int enqueue_solve(mppi_handle *h, const float *state)
 {
+#ifdef MPPI_HOSTPROF
+  const auto hp_t0 = std::chrono::steady_clock::now();
+  if (hp_n > 0) hp_acc[0] += std::chrono::duration<double, std::micro>(hp_t0 - hp_seen).count();  // seen -> next enqueue entered
+#endif
   int rc = check_ready(h);
   if (rc) return rc;
   if (!state) return fail(h, MPPI_ERR_INVALID, "state is NULL");
@@ -555,8 +571,16 @@ int enqueue_solve(mppi_handle *h, const float *state)
       a.rng_out = h->d_rng[1 - h->rng_cur];
       h->rng_cur = 1 - h->rng_cur;
     }
+#ifdef MPPI_HOSTPROF
+    HP(1, hp_t0);  // entry -> before the rollout launch
+    const auto hp_t1 = std::chrono::steady_clock::now();
+#endif
     rc = launch_rollout(h, a);
     if (rc) return rc;
+#ifdef MPPI_HOSTPROF
+    HP(2, hp_t1);  // the rollout launch call
+    const auto hp_t2 = std::chrono::steady_clock::now();
+#endif
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
     const bool last = (it == iters - 1);
     const int sstride = h->cfg.optimization_stride;
@@ -566,6 +590,13 @@ int enqueue_solve(mppi_handle *h, const float *state)
                                 want_slid ? h->d_in_buf[1 - h->in_cur] : nullptr, sstride,
                                 h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
     if (last) h->slid_valid = want_slid;
+#ifdef MPPI_HOSTPROF
+    HP(3, hp_t2);  // the tail launch call
+    hp_n += 1;
+    if ((long)hp_n % 2000 == 0)
+      fprintf(stderr, "hostprof n=%.0f: seen->enqueue %.2f us, entry->launch %.2f, rollout launch %.2f, tail launch %.2f, poll->smoothed %.2f\n",
+              hp_n, hp_acc[0] / hp_n, hp_acc[1] / hp_n, hp_acc[2] / hp_n, hp_acc[3] / hp_n, hp_acc[4] / hp_n);
+#endif
     if (ev) HIPCHK(h, hipEventRecord(ev->e[3], h->stream));
   }
   h->explicit_iters = 0;
