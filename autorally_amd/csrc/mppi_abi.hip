@@ -80,7 +80,7 @@ struct mppi_handle {
   bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
   int num_simds = 1024;     // 4 per CU
   hipStream_t stream = nullptr;
-  int cur_slot = 0, n_slots = 1;  // noise slots: one per explicit iteration
+  int n_slots = 1;  // explicit-noise slots in d_noise: one per iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
   unsigned seq = 0;             // sequence number of the last enqueued solve (last word of every h_res entry)
   std::vector<float> sg_buf;    // scratch of the host-side Savitzky-Golay pass
@@ -107,6 +107,16 @@ struct mppi_handle {
   int in_cur = 0;                            // stride-slid copy of [U | hist] in the other one
   bool slid_valid = false;
   float *d_noise = nullptr, *d_stage = nullptr;
+  // Generator-kernel forms: eps of a solve is drawn by the stand-alone kernel into one of two buffers, on a
+  // stream of its own (all generator launches, in order: the MRG32k3a states advance in launch order); the
+  // draws of the NEXT solve are requested as soon as this solve's rollout has been enqueued and start when
+  // that rollout ends, i.e. they overlap the weights / tail kernels, which leave the chip idle.
+  float *d_gen[2] = {nullptr, nullptr};
+  int gen_cur = 0;             // buffer of the most recent generator-mode solve (holds its applied controls V)
+  bool prefetch_valid = false; // d_gen[1 - gen_cur] holds the next solve's draws (ev_gen marks their completion)
+  float *v_buf = nullptr;      // where the last solve's applied controls are
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_gen = nullptr, ev_s1 = nullptr;
   float *d_costs = nullptr, *d_w = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
   float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
@@ -413,16 +423,44 @@ int check_ready(mppi_handle *h)
   return MPPI_OK;
 }
 
-// Stand-alone generator launch (mppi_generate_noise, and solves with a rollout variant that has no
-// noise wavefront): fills `slot` with the draws of the next solve iteration.
-int acquire_noise(mppi_handle *h, int *slot_out)
+// Stand-alone generator (mppi_generate_noise, and solves with a rollout variant that has no noise wavefront,
+// or any variant while prefetched draws are waiting): *buf_out holds the draws of the next solve iteration once
+// the handle's stream has passed the wait enqueued here.
+int launch_generator(mppi_handle *h, float *dst)
 {
-  const int slot = 0;
-  const size_t sz = (size_t)h->K * h->T * 2;
   HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
-                         h->noise_C, h->d_noise + (size_t)slot * sz, h->stream));
+                         h->noise_C, dst, h->gstream));
   h->rng_cur = 1 - h->rng_cur;
-  *slot_out = slot;
+  HIPCHK(h, hipEventRecord(h->ev_gen, h->gstream));
+  return MPPI_OK;
+}
+
+int acquire_noise(mppi_handle *h, float **buf_out)
+{
+  if (!h->prefetch_valid) {
+    // generate now: after everything enqueued on the handle's stream so far (the buffer may still be read by an
+    // earlier iteration's tail kernel, the generator states may have been written by an in-kernel generator)
+    HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->gstream, h->ev_s1, 0));
+    int rc = launch_generator(h, h->d_gen[1 - h->gen_cur]);
+    if (rc) return rc;
+  }
+  h->prefetch_valid = false;
+  h->gen_cur = 1 - h->gen_cur;
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gen, 0));
+  *buf_out = h->d_gen[h->gen_cur];
+  return MPPI_OK;
+}
+
+// The next solve's draws, requested right after this solve's rollout went out: they start when that rollout
+// ends (ev_s1) and run beside the weights / tail kernels.  Their target is the buffer of the solve BEFORE this
+// one, which the host has collected.  Only for single-iteration solves of a generator-kernel form.
+int prefetch_noise(mppi_handle *h)
+{
+  HIPCHK(h, hipStreamWaitEvent(h->gstream, h->ev_s1, 0));
+  int rc = launch_generator(h, h->d_gen[1 - h->gen_cur]);
+  if (rc) return rc;
+  h->prefetch_valid = true;
   return MPPI_OK;
 }
 
@@ -554,14 +592,17 @@ int enqueue_solve(mppi_handle *h, const float *state)
   for (int it = 0; it < iters; it++) {
     Events *ev = timed ? &h->ev[it] : nullptr;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[0], h->stream));
-    int slot = explicit_noise ? it : 0;
-    const bool inline_noise = !explicit_noise && has_noise_wave(h);
+    // source of eps: the explicit buffer (mppi_set_noise) > draws already prefetched > the rollout kernel's own
+    // noise wavefront > the generator kernel, now
+    const bool inline_noise = !explicit_noise && !h->prefetch_valid && has_noise_wave(h);
+    float *noise = h->d_noise + (size_t)(explicit_noise ? it : 0) * slot_sz;
     if (!explicit_noise && !inline_noise) {
-      rc = acquire_noise(h, &slot);
+      rc = acquire_noise(h, &noise);
       if (rc) return rc;
+    } else if (inline_noise) {
+      noise = h->d_gen[h->gen_cur];  // receives the applied controls
     }
-    float *noise = h->d_noise + (size_t)slot * slot_sz;
-    h->cur_slot = slot;
+    h->v_buf = noise;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], h->stream));
     RolloutArgs a;
     fill_rollout_args(h, state, noise, a);
@@ -581,6 +622,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
     HP(2, hp_t1);  // the rollout launch call
     const auto hp_t2 = std::chrono::steady_clock::now();
 #endif
+    const bool prefetch = iters == 1 && !explicit_noise && !has_noise_wave(h) && !h->prefetch_valid;
+    if (prefetch) HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));  // the generator starts when this rollout ends
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
     const bool last = (it == iters - 1);
     const int sstride = h->cfg.optimization_stride;
@@ -590,6 +633,10 @@ int enqueue_solve(mppi_handle *h, const float *state)
                                 want_slid ? h->d_in_buf[1 - h->in_cur] : nullptr, sstride,
                                 h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
     if (last) h->slid_valid = want_slid;
+    if (prefetch) {
+      rc = prefetch_noise(h);
+      if (rc) return rc;
+    }
 #ifdef MPPI_HOSTPROF
     HP(3, hp_t2);  // the tail launch call
     hp_n += 1;
@@ -622,6 +669,11 @@ void free_all(mppi_handle *h)
   for (auto &s : h->ev)
     for (auto &e : s.e)
       if (e) (void)hipEventDestroy(e);
+  for (float *p : h->d_gen)
+    if (p) (void)hipFree(p);
+  if (h->ev_gen) (void)hipEventDestroy(h->ev_gen);
+  if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
+  if (h->gstream) (void)hipStreamDestroy(h->gstream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -735,12 +787,18 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     }                                                                   \
   } while (0)
   CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CR(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+  CR(hipEventCreateWithFlags(&h->ev_gen, hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&h->ev_s1, hipEventDisableTiming));
   h->n_slots = std::max(1, cfg->num_iters);
   CR(hipMalloc(&h->d_in_buf[0], sizeof(float) * (2 * (size_t)h->T + 4)));
   CR(hipMalloc(&h->d_in_buf[1], sizeof(float) * (2 * (size_t)h->T + 4)));
   h->d_in = h->d_in_buf[0];
   CR(hipMalloc(&h->d_scal, sizeof(float) * 4));
   CR(hipMalloc(&h->d_noise, sizeof(float) * KT2 * (size_t)h->n_slots));
+  CR(hipMalloc(&h->d_gen[0], sizeof(float) * KT2));
+  CR(hipMalloc(&h->d_gen[1], sizeof(float) * KT2));
+  h->v_buf = h->d_gen[0];
   CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
   CR(hipMemset(h->d_counter, 0, sizeof(unsigned) * (1 + (size_t)h->T)));
   if (h->K > 4096) CR(hipMalloc(&h->d_part, sizeof(float) * (size_t)h->T * (h->K / 64) * 2));
@@ -791,6 +849,7 @@ int mppi_destroy(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
   (void)hipSetDevice(h->cfg.device);
+  if (h->gstream) (void)hipStreamSynchronize(h->gstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_all(h);
   return MPPI_OK;
@@ -1045,6 +1104,8 @@ int mppi_seed(mppi_handle *h, uint64_t seed, uint64_t offset)
   int rc = mppi_synchronize(h);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->gstream));
+  h->prefetch_valid = false;  // draws of the old sequence
   rc = seed_device(h, seed, offset);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1079,11 +1140,11 @@ int mppi_generate_noise(mppi_handle *h, float *eps_out, size_t n)
   HIPCHK(h, hipSetDevice(h->cfg.device));
   int rc = mppi_synchronize(h);
   if (rc) return rc;
-  int slot = 0;
-  rc = acquire_noise(h, &slot);
+  float *buf = nullptr;
+  rc = acquire_noise(h, &buf);
   if (rc) return rc;
-  h->cur_slot = slot;
-  HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)slot * slot_sz, h->d_stage, h->K, h->T, h->stream));
+  h->v_buf = buf;
+  HIPCHK(h, launch_tk_to_kt(buf, h->d_stage, h->K, h->T, h->stream));
   HIPCHK(h, hipMemcpyAsync(eps_out, h->d_stage, slot_sz * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
@@ -1147,7 +1208,7 @@ int mppi_get_applied_controls(mppi_handle *h, float *V, size_t n)
   int rc = mppi_synchronize(h);
   if (rc) return rc;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)h->cur_slot * slot, h->d_stage, h->K, h->T, h->stream));
+  HIPCHK(h, launch_tk_to_kt(h->v_buf, h->d_stage, h->K, h->T, h->stream));
   HIPCHK(h, hipMemcpyAsync(V, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MPPI_OK;
@@ -1163,16 +1224,19 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   if (rc) return rc;
   rc = upload_controls_if_dirty(h);
   if (rc) return rc;
-  int slot = 0;
-  const bool inline_noise = h->explicit_iters == 0 && has_noise_wave(h);
-  if (h->explicit_iters == 0 && !inline_noise) {
-    rc = acquire_noise(h, &slot);
+  const bool explicit_noise = h->explicit_iters > 0;
+  const bool inline_noise = !explicit_noise && !h->prefetch_valid && has_noise_wave(h);
+  float *noise = h->d_noise;  // explicit: its first iteration
+  if (!explicit_noise && !inline_noise) {
+    rc = acquire_noise(h, &noise);
     if (rc) return rc;
+  } else if (inline_noise) {
+    noise = h->d_gen[h->gen_cur];
   }
   h->explicit_iters = 0;
-  h->cur_slot = slot;
+  h->v_buf = noise;
   RolloutArgs a;
-  fill_rollout_args(h, state, h->d_noise + (size_t)slot * h->K * h->T * 2, a);
+  fill_rollout_args(h, state, noise, a);
   if (inline_noise) {
     a.inline_noise = 1;
     a.rng_in = h->d_rng[h->rng_cur];
