@@ -113,6 +113,7 @@ struct mppi_handle {
   // that rollout ends, i.e. they overlap the weights / tail kernels, which leave the chip idle.
   float *d_gen[2] = {nullptr, nullptr};
   int gen_cur = 0;             // buffer of the most recent generator-mode solve (holds its applied controls V)
+  bool gen_async = false;      // K T >= 2^20: generator on its own stream, next solve's draws prefetched
   bool prefetch_valid = false; // d_gen[1 - gen_cur] holds the next solve's draws (ev_gen marks their completion)
   float *v_buf = nullptr;      // where the last solve's applied controls are
   hipStream_t gstream = nullptr;
@@ -437,6 +438,18 @@ int launch_generator(mppi_handle *h, float *dst)
 
 int acquire_noise(mppi_handle *h, float **buf_out)
 {
+  if (!h->gen_async) {
+    // small problems: the generator on the handle's own stream, in front of the rollout.  The two event waits of
+    // the asynchronous path cost ~10 us per solve, more than a generator of K T < 2^20 pairs takes
+    // (basis-function build, K=2560: 86 -> 92 us per solve with it; config 4, 2.4 M pairs: 355 -> 337 us)
+    h->gen_cur = 1 - h->gen_cur;
+    float *dst = h->d_gen[h->gen_cur];
+    HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
+                           h->noise_C, dst, h->stream));
+    h->rng_cur = 1 - h->rng_cur;
+    *buf_out = dst;
+    return MPPI_OK;
+  }
   if (!h->prefetch_valid) {
     // generate now: after everything enqueued on the handle's stream so far (the buffer may still be read by an
     // earlier iteration's tail kernel, the generator states may have been written by an in-kernel generator)
@@ -622,7 +635,7 @@ int enqueue_solve(mppi_handle *h, const float *state)
     HP(2, hp_t1);  // the rollout launch call
     const auto hp_t2 = std::chrono::steady_clock::now();
 #endif
-    const bool prefetch = iters == 1 && !explicit_noise && !has_noise_wave(h) && !h->prefetch_valid;
+    const bool prefetch = h->gen_async && iters == 1 && !explicit_noise && !has_noise_wave(h) && !h->prefetch_valid;
     if (prefetch) HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));  // the generator starts when this rollout ends
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
     const bool last = (it == iters - 1);
@@ -799,6 +812,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_gen[0], sizeof(float) * KT2));
   CR(hipMalloc(&h->d_gen[1], sizeof(float) * KT2));
   h->v_buf = h->d_gen[0];
+  h->gen_async = (size_t)h->K * (size_t)h->T >= ((size_t)1 << 20);
   CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
   CR(hipMemset(h->d_counter, 0, sizeof(unsigned) * (1 + (size_t)h->T)));
   if (h->K > 4096) CR(hipMalloc(&h->d_part, sizeof(float) * (size_t)h->T * (h->K / 64) * 2));
