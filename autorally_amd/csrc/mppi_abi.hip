@@ -62,10 +62,16 @@ Mat3 base_A1() { return Mat3{{0, 1, 0, 0, 0, 1, (uint32_t)(M1 - 810728ULL), 1403
 Mat3 base_A2() { return Mat3{{0, 1, 0, 0, 0, 1, (uint32_t)(M2 - 1370589ULL), 0, 527612u}}; }
 
 struct Events {
+  // e[0..3]: markers on the handle's stream before noise / before rollout / after rollout / after tail;
+  // e[4], e[5]: begin and end of the rollout kernel's own dispatch (hipExtLaunchKernelGGL, MPPI_LAUNCH_ROLLOUT)
   hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
+
+namespace mppi {
+thread_local hipEvent_t tl_kernel_start = nullptr, tl_kernel_stop = nullptr;
+}
 
 struct mppi_handle {
   mppi_config cfg{};
@@ -570,6 +576,11 @@ int wait_pending(mppi_handle *h)
       HIPCHK(h, hipEventSynchronize(h->ev[it].e[3]));
       float ms[3] = {0, 0, 0};
       for (int i = 0; i < 3; i++) (void)hipEventElapsedTime(&ms[i], h->ev[it].e[i], h->ev[it].e[i + 1]);
+      // the rollout stage: the kernel's own dispatch stamps where the runtime delivered them
+      float kms = 0.0f;
+      if (hipEventElapsedTime(&kms, h->ev[it].e[4], h->ev[it].e[5]) == hipSuccess && kms > 0.0f) {
+        ms[1] = kms;
+      }
       h->acc.noise_ms += ms[0];
       h->acc.rollout_ms += ms[1];
       h->acc.reduction_ms += ms[2];
@@ -629,7 +640,9 @@ int enqueue_solve(mppi_handle *h, const float *state)
     HP(1, hp_t0);  // entry -> before the rollout launch
     const auto hp_t1 = std::chrono::steady_clock::now();
 #endif
+    if (ev) { tl_kernel_start = ev->e[4]; tl_kernel_stop = ev->e[5]; }
     rc = launch_rollout(h, a);
+    tl_kernel_start = tl_kernel_stop = nullptr;
     if (rc) return rc;
 #ifdef MPPI_HOSTPROF
     HP(2, hp_t1);  // the rollout launch call

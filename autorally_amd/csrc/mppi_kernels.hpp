@@ -2,7 +2,24 @@
 #pragma once
 #include "mppi_device.hpp"
 
+#include <hip/hip_ext.h>
+
 namespace mppi {
+
+// Rollout kernels are launched through this macro.  When the caller has set the two thread-local events
+// (mppi_enable_stage_timing: the stage-timing pass of bench.py), the launch goes through
+// hipExtLaunchKernelGGL, which stamps them with the begin / end of THIS kernel's dispatch -- the figure
+// rocprofv3 --kernel-trace reports -- instead of the time between two marker packets around it (which on this
+// runtime is 3-4 us longer).  Otherwise a plain launch.
+extern thread_local hipEvent_t tl_kernel_start, tl_kernel_stop;
+#define MPPI_LAUNCH_ROLLOUT(kern, grid, block, lds, stream, ...)                                                   \
+  do {                                                                                                             \
+    if (::mppi::tl_kernel_start != nullptr)                                                                        \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ::mppi::tl_kernel_start, ::mppi::tl_kernel_stop, 0,    \
+                            __VA_ARGS__);                                                                          \
+    else                                                                                                           \
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                             \
+  } while (0)
 
 // rollout_mfma.hip
 bool mfma_variant_supported(int hidden, int n_hidden);

@@ -298,8 +298,8 @@ __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, c
 
 hipError_t launch_rollout_bf(const RolloutArgs &a, bool two_waves, hipStream_t stream)
 {
-  if (two_waves) hipLaunchKernelGGL(rollout_bf2_kernel, dim3(a.K / kBfLanes), dim3(2 * kBfLanes), 0, stream, a);
-  else hipLaunchKernelGGL(rollout_bf_kernel, dim3(a.K / kBfLanes), dim3(kBfLanes), 0, stream, a);
+  if (two_waves) MPPI_LAUNCH_ROLLOUT(rollout_bf2_kernel, dim3(a.K / kBfLanes), dim3(2 * kBfLanes), 0, stream, a);
+  else MPPI_LAUNCH_ROLLOUT(rollout_bf_kernel, dim3(a.K / kBfLanes), dim3(kBfLanes), 0, stream, a);
   return hipGetLastError();
 }
 

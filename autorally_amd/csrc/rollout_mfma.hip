@@ -17,6 +17,7 @@
 //     contiguous 128-B line per step; the weighted reduction later streams it row by row.
 #include "mfma_net.hpp"
 #include "noise_device.hpp"
+#include "mppi_kernels.hpp"
 
 namespace mppi {
 
@@ -632,19 +633,19 @@ static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipS
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   if (block_threads == 512) {  // quad form: two dynamics waves + cost wave + control wave per 16 rollouts
     const dim3 grid(a.K / kRolloutsPerWave), block(256);
-    if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
-    else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
-    else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rollout_quad_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
+    if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_quad_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
+    else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_quad_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
+    else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_quad_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
+    else MPPI_LAUNCH_ROLLOUT((rollout_quad_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
   const int waves = a.K / kRolloutsPerWave;
   const int wpb = block_threads / 64;
   const dim3 grid((waves + wpb - 1) / wpb), block(block_threads);
-  if (affine && !ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
-  else if (affine && ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
-  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((rollout_mfma_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
+  if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_mfma_kernel<H, NHID, true, false>), grid, block, 0, stream, a);
+  else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_mfma_kernel<H, NHID, true, true>), grid, block, 0, stream, a);
+  else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_mfma_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
+  else MPPI_LAUNCH_ROLLOUT((rollout_mfma_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 

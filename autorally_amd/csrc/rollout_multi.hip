@@ -21,6 +21,7 @@
 // one workgroup per CU every SIMD runs exactly one dynamics wave (K = 16384: 256 workgroups).
 #include "mfma_net.hpp"
 #include "noise_device.hpp"
+#include "mppi_kernels.hpp"
 
 namespace mppi {
 
@@ -299,9 +300,9 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
 template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (nd == 4) hipLaunchKernelGGL((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
-  else if (nd == 2) hipLaunchKernelGGL((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
-  else if (nd == 1) hipLaunchKernelGGL((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
+  if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
+  else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
+  else if (nd == 1) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

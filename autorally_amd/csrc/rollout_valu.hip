@@ -282,7 +282,7 @@ hipError_t launch_rollout_valu_reg(int hidden, int n_hidden, const RolloutArgs &
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_valu_reg_kernel<HH, NN>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
     if (e != hipSuccess) return e;                                                                  \
-    hipLaunchKernelGGL((rollout_valu_reg_kernel<HH, NN>), grid, block, lds, stream, a);             \
+    MPPI_LAUNCH_ROLLOUT((rollout_valu_reg_kernel<HH, NN>), grid, block, lds, stream, a);             \
     return hipGetLastError();                                                                       \
   }
   MPPI_VR(32, 2)
@@ -315,7 +315,7 @@ hipError_t launch_rollout_valu(const NetDesc &net, const RolloutArgs &a, hipStre
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_valu_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(rollout_valu_kernel, dim3(a.K / kValuLanes), dim3(kValuLanes), lds, stream, a,
+  MPPI_LAUNCH_ROLLOUT(rollout_valu_kernel, dim3(a.K / kValuLanes), dim3(kValuLanes), lds, stream, a,
                      to_dev(net));
   return hipGetLastError();
 }

@@ -375,7 +375,9 @@ def main():
             inline_noise = ("quad" in variant) or ("multi" in variant and not variant.endswith("_gen"))
             bpu = ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
-            out["stage_ms"]["note"] = "HIP events on the handle's stream around every stage of %d solves, separate pass after the timed region" % n
+            out["stage_ms"]["note"] = ("HIP events on the handle's stream, %d solves, separate pass after the timed region: markers around the "
+                                       "noise and tail stages; the rollout stage is the begin / end of the rollout kernel's own dispatch "
+                                       "(hipExtLaunchKernelGGL start / stop events: the quantity rocprofv3 --kernel-trace reports)" % n)
             traffic, traffic_file = measured_traffic(cfg, variant)
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
