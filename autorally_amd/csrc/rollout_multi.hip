@@ -98,6 +98,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
     while (cd < t - kMRing + 1 && --budget > 0) cd = __builtin_amdgcn_readfirstlane(*p_cd);
     lds_put1(a_rec + (uint32_t)(t & (kMRing - 1)) * kRecSlot, b0);
     lds_publish(a_mypub, t + 1);  // also: this wave is done with the control record of step t
+    if (t == T - 1) break;  // the last update feeds no cost (mppi_controller.cu:160-177): no network evaluation
     // requested now, used after the network: the control wave's count, then this lane's layer-0 operand
     // of step t+1 (valid if the count read before it is >= t+2), and the cost wave's progress
     const int tn = (t + 1) & (kMRing - 1);
