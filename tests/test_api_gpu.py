@@ -325,3 +325,56 @@ def test_slide_by_zero_is_a_no_op_and_hist_waits_for_a_pending_solve():
     ref = O.Oracle(cfg, fma_mode=1).compute_control(cfg["start_state"], U0, hist, eps)
     assert np.max(np.abs(got["U"] - ref["U"])) <= 1e-4
     sol.close()
+
+
+def test_prefetched_generator_draws_are_the_right_ones():
+    """Handles with K T >= 2^20 draw eps with the stand-alone generator on a stream of its own and request the
+    NEXT solve's draws while the current solve's tail runs.  The sequence of draws must be what it always was:
+    solve i of a handle consumes draws [2T i, 2T (i+1)) of every rollout's subsequence -- also across
+    mppi_generate_noise (hands out the prefetched draws), mppi_seed (discards them), an explicit-noise solve in
+    between (consumes none) and a switch to a kernel form with its own noise wavefront."""
+    K, T = 16384, 64
+    assert K * T >= 1 << 20
+    cfg = S.make_config(K, T, track="oval")
+    gen = capi.Solver(dict(cfg, seed=77))
+    ref = capi.Solver(dict(cfg, seed=77))
+    assert "multi4_gen" in gen.rollout_variant()
+    x = cfg["start_state"]
+
+    def both(offset, label):
+        gen.compute_control(x)
+        ref.set_noise(O.generate_noise(77, offset, K, T)[None])
+        ref.compute_control(x)
+        a, b = gen.get_control_seq(), ref.get_control_seq()
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=label)
+        gen.slide_control_seq(1)
+        ref.slide_control_seq(1)
+
+    both(0, "first solve (generated now)")
+    both(2 * T, "second solve (prefetched)")
+    both(4 * T, "third solve (prefetched)")
+    # the API's own view of the stream: the next draws are the prefetched ones
+    e = gen.generate_noise()
+    np.testing.assert_array_equal(e.view(np.uint32), O.generate_noise(77, 6 * T, K, T).view(np.uint32))
+    both(8 * T, "after mppi_generate_noise")
+    # an explicit-noise solve consumes no draws
+    eps = O.generate_noise(5, 0, K, T)[None]
+    for s in (gen, ref):
+        s.set_noise(eps)
+        s.compute_control(x)
+        s.slide_control_seq(1)
+    np.testing.assert_array_equal(gen.get_control_seq().view(np.uint32), ref.get_control_seq().view(np.uint32))
+    both(10 * T, "after an explicit-noise solve")
+    # a form with its own noise wavefront takes over the prefetched draws, then continues the stream itself
+    gen.set_rollout_variant("quad")
+    both(12 * T, "quad form, prefetched draws")
+    both(14 * T, "quad form, in-kernel generator")
+    gen.set_rollout_variant("auto")
+    both(16 * T, "back to the generator kernel")
+    # re-seeding discards what was prefetched
+    gen.seed(123, 10)
+    gen.compute_control(x)
+    ref.set_noise(O.generate_noise(123, 10, K, T)[None])
+    ref.compute_control(x)
+    np.testing.assert_array_equal(gen.get_control_seq().view(np.uint32), ref.get_control_seq().view(np.uint32))
+    gen.close(); ref.close()
