@@ -1,6 +1,7 @@
 // rollout_multi.hip -- rolloutKernel (PI/mppi_controller.cu:72-184) for gfx950, the form for K beyond
 // the latency regime: ND "dynamics" wavefronts (16 rollouts each, the whole network on the matrix
-// instruction, mfma_net.hpp) + ONE cost wavefront + ONE control wavefront per workgroup of 16 ND rollouts.
+// instruction, mfma_net.hpp) + ONE cost wavefront (two at ND = 4: pose | cost) + ONE control wavefront per
+// workgroup of 16 ND rollouts.
 //
 // Why: in the single-wave form (rollout_mfma_kernel) every lane of a 16-rollout wave carries the scalar
 // work of its rollout -- controls, sin/cos, two costmap fetches, MPPICosts::computeCost, the f64 running
@@ -30,6 +31,7 @@ constexpr int kMCtlChunk = 4;  // steps of U / explicit eps the control wave req
 
 template <int ND>
 struct MultiShared {
+  static constexpr bool SPLIT = (ND == 4);  // cost work on two wavefronts (pose | cost), see the kernel
   static constexpr int NR = 16 * ND;       // rollouts per workgroup
   float rec[kMRing][NR][4];                // s3..s6 before the update of step t (dynamics waves)
   float ctl_rec[kMRing][NR][4];            // clamped u0, u1, du0, du1 (control wave -> cost wave)
@@ -37,6 +39,8 @@ struct MultiShared {
   int dyn_pub[4][64];                      // steps published by dynamics wave w (written per lane, word 0 read)
   int cost_done[64];                       // steps consumed by the cost wave
   int ctl_pub[64];                         // steps published by the control wave
+  float tex[SPLIT ? kMRing : 1][SPLIT ? NR : 1][2];  // costmap texels (front, back) of step t (pose wave -> cost wave)
+  int pose_pub[64];                        // steps whose texels the pose wave has published
   int fail[4];                             // word 0: raised by a wave whose waits ran out of budget
   int fin[8];                              // word r: wave r is through its T steps
 };
@@ -132,13 +136,21 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
 }
 
 template <int H, int NHID, int ND>
-__global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const RolloutArgs a)
+__global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_multi_kernel(const RolloutArgs a)
 {
   using SH = MultiShared<ND>;
   constexpr int NR = SH::NR;
+  constexpr bool SPLIT = SH::SPLIT;
+  // Roles: 0..ND-1 dynamics; then [pose,] cost, control.  With ND = 4 every SIMD of the CU carries a dynamics wave
+  // and whatever rides along with it delays it: the one cost wave of the other forms costs the dynamics wave on
+  // its SIMD ~500 cycles per step (6-32-32-4, K=16384: 104.7 us, 82.7 us with the cost arithmetic removed).  So
+  // its work is cut in two wavefronts that land on different SIMDs: the POSE wave (x, y, yaw kinematics, sin/cos,
+  // the two costmap fetches) hands the texels to the COST wave (computeCost, running mean, crash flags) through
+  // one more ring.
+  constexpr int kPose = SPLIT ? ND : -1, kCost = ND + (SPLIT ? 1 : 0), kCtl = kCost + 1;
   __shared__ __attribute__((aligned(16))) SH sh;
   const int lane = threadIdx.x & 63;
-  // 0..ND-1 dynamics, ND cost, ND+1 control; made uniform for the compiler (budgets and waits stay scalar)
+  // made uniform for the compiler (budgets and waits stay scalar)
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int K = a.K, T = a.T;
   // sequence words and the constant rows of the layer-0 operand start at 0; the only barrier
@@ -146,17 +158,18 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
     for (int w = 0; w < 4; w++) sh.dyn_pub[w][lane] = 0;
     sh.cost_done[lane] = 0;
     sh.ctl_pub[lane] = 0;
+    sh.pose_pub[lane] = 0;
     sh.fail[lane & 3] = 0;
     sh.fin[lane & 7] = 0;
   }
-  if (role == ND + 1)
+  if (role == kCtl)
     for (int q = 0; q < kMRing; q++)
       for (int w = 0; w < ND; w++) sh.ctl_b1[q][w][lane] = 0.0f;
   __syncthreads();
 
   if (role < ND) {
     multi_dynamics<H, NHID, ND>(a, sh, role);
-  } else if (role == ND + 1) {
+  } else if (role == kCtl) {
     // -------------------------------- control wave: one lane per rollout --------------------------------
     const bool inl = a.inline_noise != 0;
     const bool active = lane < NR;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
     const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
     const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
     const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
-    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == ND + 2);
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kCtl + 1);
     int seen_d = 0, seen_c = 0;  // steps published by all dynamics waves / consumed by the cost wave
     for (int t0 = 0; t0 < T; t0 += kMCtlChunk) {
       float2 Uq[kMCtlChunk], eq[kMCtlChunk];
@@ -220,7 +233,98 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
       a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
       a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
     }
-    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[ND + 1]));
+    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[kCtl]));
+  } else if (SPLIT && role == kPose) {
+    // -------------------------------- pose wave (ND = 4): one lane per rollout --------------------------------
+    // Software-pipelined by one step: the texels of step t are requested in iteration t and handed to the cost
+    // wave in iteration t+1.
+    const bool active = lane < NR;
+    const int r = active ? lane : NR - 1;
+    const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
+    const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+    const uint32_t a_mypub = lds_addr(&sh.pose_pub[lane]);
+    const bool affine = a.cost.affine != 0;
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kPose + 1), seen = 0, cdone = 0;
+    float tf_p = 0.0f, tb_p = 0.0f;
+    for (int t = 0; t <= T; t++) {
+      float tf = 0.0f, tb = 0.0f;
+      if (t < T) {
+        while (seen < t + 1 && --budget > 0) {  // rec(t) is written before a dynamics wave publishes step t
+          seen = dyn_pub_min<ND>(a_dynw);
+          if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);  // s3 s4 s5 s6
+        float spsi, cpsi;
+        sincos_fast(yaw, spsi, cpsi);
+        const float st[3] = {x, y, yaw};
+        if (affine) track_fetch<true>(a.cost, st, cpsi, spsi, tf, tb);
+        else track_fetch<false>(a.cost, st, cpsi, spsi, tf, tb);
+        // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
+        const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
+        const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
+        const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
+        x = fmaf(sd0, a.dt, x);
+        y = fmaf(sd1, a.dt, y);
+        yaw = fmaf(sd2, a.dt, yaw);
+      }
+      if (t > 0) {
+        // the texels of step t-1; their ring slot held step t-1-kMRing, which the cost wave must have consumed
+        while (cdone < t - kMRing && --budget > 0) cdone = lds_peek(a_cd);
+        *reinterpret_cast<float2 *>(&sh.tex[(t - 1) & (kMRing - 1)][r][0]) = make_float2(tf_p, tb_p);
+        lds_publish(a_mypub, t);  // steps < t are out
+      }
+      tf_p = tf; tb_p = tb;
+    }
+    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[kPose]));
+  } else if (SPLIT) {
+    // -------------------------------- cost wave (ND = 4): one lane per rollout --------------------------------
+    const bool active = lane < NR;
+    const int r = active ? lane : NR - 1;
+    const int k = blockIdx.x * NR + r;
+    const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
+    const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
+    const bool ctrl = a.cost.need_control_cost != 0;
+    int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kCost + 1), seen = 0;
+    float J = 0.0f;
+    for (int t = 0; t < T; t++) {
+      const double rt = a.inv_t[t];
+      // the pose wave publishes the texels of step t after it has read rec(t): the records of step t are there
+      while (seen < t + 1 && --budget > 0) {
+        seen = lds_peek(a_pose);
+        if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+      }
+      const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);      // s3 s4 s5 s6
+      const float4 r1 = *reinterpret_cast<const float4 *>(&sh.ctl_rec[t & (kMRing - 1)][r][0]);  // u0 u1 du0 du1
+      const float2 tx = *reinterpret_cast<const float2 *>(&sh.tex[t & (kMRing - 1)][r][0]);      // front, back texel
+      lds_publish(a_mydone, t + 1);  // executes after the three reads (the LDS runs a wave's instructions in order)
+      const int rc = (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
+      CostTerms ct;
+      if (ctrl) cost_terms_a<true>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+      else cost_terms_a<false>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+      // running mean over 1..T-1 (Q5); the t = 0 evaluation is discarded
+      crash |= rc;
+      int crash_new = crash;
+      const float c = cost_terms_b(a.cost, ct, tx.x, tx.y, crash_new);
+      const float Jn = running_mean(J, c, t, rt);
+      J = (t > 0) ? Jn : J;
+      crash = (t > 0) ? crash_new : crash;
+    }
+    // a hand-over that never arrived, in ANY wave of the group: poison, do not hang (mppi_device.hpp)
+    {
+      // lanes 0..ND-1: the dynamics waves' finished words, lane ND: the pose wave's, the rest: the control wave's
+      const uint32_t a_fin = lds_addr(&sh.fin[(lane <= ND) ? lane : kCtl]);
+      for (;;) {
+        const int v = lds_peek_lanes(a_fin);
+        int all = __builtin_amdgcn_readlane(v, ND) & __builtin_amdgcn_readlane(v, ND + 1);
+#pragma unroll
+        for (int w = 0; w < ND; w++) all &= __builtin_amdgcn_readlane(v, w);
+        if (all != 0 || --budget <= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
+    }
+    if (active) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
   } else {
     // -------------------------------- cost wave: one lane per rollout --------------------------------
     // Software-pipelined by one step: the costmap texels of step t are requested in iteration t and
@@ -232,7 +336,7 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
     const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
     const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
     float x = a.state[0], y = a.state[1], yaw = a.state[2];
-    int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == ND + 1), seen = 0;
+    int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kCost + 1), seen = 0;
     float J = 0.0f;
     float tf_p = 0.0f, tb_p = 0.0f;
     CostTerms ct_p{0.0f, 0.0f, 0.0f};
@@ -283,7 +387,7 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
     }
     // a hand-over that never arrived, in ANY wave of the group: poison, do not hang (mppi_device.hpp)
     {
-      const uint32_t a_fin = lds_addr(&sh.fin[(lane < ND) ? lane : ND + 1]);  // lanes 0..ND-1: dynamics, the rest: control
+      const uint32_t a_fin = lds_addr(&sh.fin[(lane < ND) ? lane : kCtl]);  // lanes 0..ND-1: dynamics, the rest: control
       for (;;) {
         const int v = lds_peek_lanes(a_fin);
         int all = __builtin_amdgcn_readlane(v, ND);
@@ -301,7 +405,7 @@ __global__ __launch_bounds__((ND + 2) * 64) void rollout_multi_kernel(const Roll
 template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
+  if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(7 * 64), 0, stream, a);
   else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
   else if (nd == 1) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
   else return hipErrorInvalidValue;

@@ -231,7 +231,8 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
  * dynamics waves, 3 = cost wave, 4 = control wave; of the two-wavefront basis-function kernel: 1 = dynamics,
  * 2 = cost.  The solve must then end in MPPI_ERR_HIP ("hand-over failed"), never in finite costs.
  * wave = 0 and spin_budget = 0 restore normal operation.
- * Roles of the multi form: 1 .. ND = dynamics waves, ND+1 = cost wave, ND+2 = control wave. */
+ * Roles of the multi form: 1 .. ND = dynamics waves, then the cost wave and the control wave (ND = 4: the pose
+ * wave, the cost wave, the control wave). */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
 
 #ifdef __cplusplus

@@ -268,7 +268,8 @@ def test_control_ticks_equals_the_call_by_call_loop():
 
 
 @pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2),
-                                         ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi2", 2), ("multi2", 3)])
+                                         ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7),
+                                         ("multi2", 2), ("multi2", 3), ("multi2", 4)])
 def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, family, wave):
     """The multi-wavefront rollout kernels hand data over through LDS sequence words; a wave whose wait runs
     out of its poll budget carries on with whatever the LDS holds.  Whichever role that is -- a dynamics
@@ -284,7 +285,7 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
         extra = dict(layers=l, theta=th)
     cfg = S.make_config(256, 40, track="oval", **extra)
     sol = capi.Solver(cfg)
-    if family != "bf":  # multi form: roles 1..ND = dynamics waves, ND+1 = cost wave, ND+2 = control wave
+    if family != "bf":  # multi form: roles 1..ND = dynamics waves, then [pose wave (ND = 4),] cost wave, control wave
         sol.set_rollout_variant(family if family.startswith("multi") else "quad")
     sol.compute_control(cfg["start_state"])          # healthy
     good = sol.get_results()
