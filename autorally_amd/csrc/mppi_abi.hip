@@ -476,7 +476,11 @@ int acquire_noise(mppi_handle *h, float **buf_out)
 // one, which the host has collected.  Only for single-iteration solves of a generator-kernel form.
 int prefetch_noise(mppi_handle *h)
 {
-  HIPCHK(h, hipStreamWaitEvent(h->gstream, h->ev_s1, 0));
+  // While every SIMD runs at most one dynamics wave (K <= 16 x #SIMDs) the generator starts at once, beside the
+  // rollout: its instructions fit the dependency bubbles of the dynamics waves (config 4 0.317 -> 0.309 ms per
+  // solve, K=16384 6-32-32-4 0.122 -> 0.117).  With several workgroups per CU there are no bubbles left
+  // (K=65536: 0.380 -> 0.470 ms), so there it starts when the rollout ends, beside the weights / tail kernels.
+  if (h->K / kRolloutsPerWave > h->num_simds) HIPCHK(h, hipStreamWaitEvent(h->gstream, h->ev_s1, 0));
   int rc = launch_generator(h, h->d_gen[1 - h->gen_cur]);
   if (rc) return rc;
   h->prefetch_valid = true;
