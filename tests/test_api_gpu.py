@@ -379,3 +379,25 @@ def test_prefetched_generator_draws_are_the_right_ones():
     ref.compute_control(x)
     np.testing.assert_array_equal(gen.get_control_seq().view(np.uint32), ref.get_control_seq().view(np.uint32))
     gen.close(); ref.close()
+
+
+def test_large_handle_two_iterations_generator_mode():
+    """K T >= 2^20 with num_iters = 2: the second iteration's draws cannot be prefetched (they are generated on
+    the generator stream between the two iterations, ordered by events against the first iteration's tail kernel
+    reading the other buffer).  Generator mode must equal explicit noise fed with the same draws, twice in a row."""
+    K, T = 16384, 64
+    cfg = S.make_config(K, T, track="oval", num_iters=2)
+    gen = capi.Solver(dict(cfg, seed=31))
+    ref = capi.Solver(dict(cfg, seed=31))
+    x = cfg["start_state"]
+    for solve in range(2):
+        gen.compute_control(x)
+        eps = np.stack([O.generate_noise(31, 2 * T * (2 * solve + it), K, T) for it in range(2)])
+        ref.set_noise(eps)
+        ref.compute_control(x)
+        np.testing.assert_array_equal(gen.get_control_seq().view(np.uint32), ref.get_control_seq().view(np.uint32))
+        a, b = gen.get_applied_controls(), ref.get_applied_controls()
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        gen.slide_control_seq(1)
+        ref.slide_control_seq(1)
+    gen.close(); ref.close()
