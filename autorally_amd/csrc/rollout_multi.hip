@@ -142,11 +142,13 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
   constexpr int NR = SH::NR;
   constexpr bool SPLIT = SH::SPLIT;
   // Roles: 0..ND-1 dynamics; then [pose,] cost, control.  With ND = 4 every SIMD of the CU carries a dynamics wave
-  // and whatever rides along with it delays it: the one cost wave of the other forms costs the dynamics wave on
-  // its SIMD ~500 cycles per step (6-32-32-4, K=16384: 104.7 us, 82.7 us with the cost arithmetic removed).  So
-  // its work is cut in two wavefronts that land on different SIMDs: the POSE wave (x, y, yaw kinematics, sin/cos,
-  // the two costmap fetches) hands the texels to the COST wave (computeCost, running mean, crash flags) through
-  // one more ring.
+  // and the other waves ride along on the issue slots its MFMA chain leaves.  That costs the dynamics wave nothing
+  // (tools/ub/rider_ub.hip), but a rider whose step is one long dependent chain is stretched -- the one cost wave
+  // of the other forms to ~2400 cycles per step -- and through the rings' back-pressure the whole workgroup runs
+  // at its pace (6-32-32-4, K=16384: 104.7 us, 82.7 us with the cost arithmetic removed).  So the cost work is a
+  // two-stage pipeline on two wavefronts that land on different SIMDs: the POSE wave (x, y, yaw kinematics,
+  // sin/cos, the two costmap fetches) hands the texels to the COST wave (computeCost, running mean, crash flags)
+  // through one more ring; each stage keeps up.
   constexpr int kPose = SPLIT ? ND : -1, kCost = ND + (SPLIT ? 1 : 0), kCtl = kCost + 1;
   __shared__ __attribute__((aligned(16))) SH sh;
   const int lane = threadIdx.x & 63;
