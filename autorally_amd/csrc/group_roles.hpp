@@ -1,0 +1,271 @@
+// group_roles.hpp -- the wavefronts that ride along with the dynamics wavefronts of a rollout GROUP (16 rollouts
+// whose network is split over NW dynamics wavefronts of one workgroup, rollout_oct.hip), written over the
+// group's LDS block: pose wave -> cost wave, noise wave -> control wave.  Each is one pipeline stage: a rider
+// only gets the issue slots its SIMD's dynamics wave leaves free (the waits of the swaps), and one stage per SIMD
+// keeps every stage inside that budget.
+//
+// SH (the __shared__ struct of the kernel) provides
+//   static constexpr int NW, NSW;           dynamics waves of the group; swaps they publish per step
+//   int   xseq[NW][64];                     swaps published by dynamics wave w (word 0 is read)
+//   float rec[kGRing][16][4];               s3..s6 before the update of step t (written by dynamics wave 0
+//                                           BEFORE it publishes the first swap of step t)
+//   int   cost_done[64];                    steps consumed by the cost wave
+//   float ctl_b1[kGRing][64];               layer-0 B operand of k-step 1, [u0c, u1c, 0, 0][g] per rollout
+//   float ctl_rec[kGRing][16][4];           clamped u0, u1 and du0, du1 for the cost wave
+//   int   ctl_pub[64];                      steps published by the control wave
+//   float tex[kGRing][16][2]; int pose_pub[64];   front / back texel of step t; steps published by the pose wave
+//   float eps[kGRing][16][2]; int rng_pub[64];    the generator's pair of step t; steps published by the noise wave
+//   int   fail[4]; int fin[8];              mppi_device.hpp: spin_finish
+// Roles (= wave index in the workgroup): 0..NW-1 dynamics, then pose, cost, control, noise.  a.fault_wave ==
+// role + 1 starts that role with an exhausted poll budget (mppi_debug_inject_handover_fault).
+//
+// Reference: the per-step bookkeeping of rolloutKernel, mppi_controller.cu:127-177 (control perturbation
+// :136-153, store before the clamp :155-158 (Q3), running-mean cost :160-166 (Q5)); costs.cu:396-409.
+#pragma once
+
+#include "mppi_device.hpp"
+#include "noise_device.hpp"
+
+namespace mppi {
+
+constexpr int kGRing = 16;     // steps in flight between the waves of a group (power of two)
+constexpr int kGCtlChunk = 4;  // steps of U / explicit eps the control wave requests at once
+
+template <class SH>
+struct GroupRoles {
+  static constexpr int kPose = SH::NW, kCost = SH::NW + 1, kCtl = SH::NW + 2, kRng = SH::NW + 3;
+  static constexpr int kWaves = SH::NW + 4;
+  static_assert(kWaves <= 8, "fin[8]");
+};
+
+template <class SH>
+__device__ __forceinline__ int group_seq_min(SH &sh)
+{
+  int m = lds_peek(lds_addr(&sh.xseq[0][0]));
+#pragma unroll
+  for (int w = 1; w < SH::NW; w++) m = min(m, lds_peek(lds_addr(&sh.xseq[w][0])));
+  return m;
+}
+
+// ---------------------------------- noise wave ----------------------------------
+// The handle's MRG32k3a streams, one lane per rollout, one pair per step, into a ring for the control wave.
+template <class SH>
+__device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
+{
+  using R = GroupRoles<SH>;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * kRolloutsPerWave + (lane & 15);
+  const int K = a.K, T = a.T;
+  const bool active = lane < kRolloutsPerWave;
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kRng + 1);
+  if (a.inline_noise != 0) {
+    Mrg gsta{0, 0, 0, 0, 0, 0};
+    if (active) {
+      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
+      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
+    }
+    const uint32_t a_ctl = lds_addr(&sh.ctl_pub[0]);
+    const uint32_t a_mypub = lds_addr(&sh.rng_pub[lane]);
+    int seen = 0;
+    for (int t = 0; t < T; t++) {
+      const float2 e = active ? noise_pair(gsta) : make_float2(0.0f, 0.0f);
+      // slot t % kGRing held step t - kGRing, consumed once the control wave has published that step
+      const int need = t - kGRing + 1;
+      while (seen < need && --budget > 0) {
+        seen = lds_peek(a_ctl);
+        if (seen < need) __builtin_amdgcn_s_sleep(2);
+      }
+      if (active) *reinterpret_cast<float2 *>(&sh.eps[t & (kGRing - 1)][lane][0]) = e;
+      lds_publish(a_mypub, t + 1);
+    }
+    if (active) {
+      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
+      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+    }
+  }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kRng]));
+}
+
+// ---------------------------------- control wave ----------------------------------
+template <class SH>
+__device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
+{
+  using R = GroupRoles<SH>;
+  constexpr int NSW = SH::NSW;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * kRolloutsPerWave + (lane & 15);
+  const int K = a.K, T = a.T;
+  const bool inl = a.inline_noise != 0;
+  const bool active = lane < kRolloutsPerWave;
+  float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+  const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+  const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
+  const bool pure_noise_k = (k >= a.k99);  // :141
+  const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+  const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
+  const uint32_t a_rng = lds_addr(&sh.rng_pub[0]);
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kCtl + 1);
+  int seen_x = 0, seen_c = 0, seen_r = 0;  // swaps published by all dynamics waves / steps consumed by the cost wave / pairs drawn
+  for (int t0 = 0; t0 < T; t0 += kGCtlChunk) {
+    // the chunk's nominal controls and (explicit noise) eps are requested together
+    float2 Uq[kGCtlChunk], eq[kGCtlChunk];
+#pragma unroll
+    for (int q = 0; q < kGCtlChunk; q++) {
+      const int tq = min(t0 + q, T - 1);
+      Uq[q] = Useq[tq];
+      eq[q] = (active && !inl) ? noise[(size_t)tq * K + k] : make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int q = 0; q < kGCtlChunk; q++) {
+      const int t = t0 + q;
+      if (t < T) {
+        // slot t % kGRing held step t - kGRing: the dynamics waves read it during step t - kGRing - 1 (done
+        // once all of them published the first swap of step t - kGRing), the cost wave in step t - kGRing
+        const int need_x = (t >= kGRing) ? (t - kGRing) * NSW + 1 : 0;
+        const int need_c = t - kGRing + 1;
+        while ((seen_x < need_x || seen_c < need_c) && --budget > 0) {
+          seen_x = group_seq_min(sh);
+          seen_c = lds_peek(a_cd);
+          if (seen_x < need_x || seen_c < need_c) __builtin_amdgcn_s_sleep(2);
+        }
+        float2 e = eq[q];
+        if (inl) {  // generator mode: the pair of step t from the noise wave's ring
+          while (seen_r < t + 1 && --budget > 0) {
+            seen_r = lds_peek(a_rng);
+            if (seen_r < t + 1) __builtin_amdgcn_s_sleep(1);
+          }
+          e = *reinterpret_cast<const float2 *>(&sh.eps[t & (kGRing - 1)][lane & 15][0]);
+        }
+        if (active) {
+          // control perturbation, mppi_controller.cu:136-153
+          const bool nf = noise_free_k | (t < a.opt_delay);
+          const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+          const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+          float u0 = nf ? Uq[q].x : (pure_noise_k ? n0 : Uq[q].x + n0);
+          float u1 = nf ? Uq[q].y : (pure_noise_k ? n1 : Uq[q].y + n1);
+          noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+          u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+          u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+          const int slot = t & (kGRing - 1);
+          sh.ctl_b1[slot][lane] = u0;
+          sh.ctl_b1[slot][kRolloutsPerWave + lane] = u1;
+          *reinterpret_cast<float4 *>(&sh.ctl_rec[slot][lane][0]) = make_float4(u0, u1, du0, du1);
+        }
+        lds_publish(a_mypub, t + 1);  // after the read of eps(t): releases that slot to the noise wave
+      }
+    }
+  }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kCtl]));
+}
+
+// ---------------------------------- pose wave ----------------------------------
+// x, y, yaw of the group's rollouts and the two costmap texels per step.  Software-pipelined by one step: the
+// texels of step t are requested in iteration t and handed to the cost wave in iteration t+1.
+template <class SH, bool AFFINE>
+__device__ __forceinline__ void group_pose_wave(const RolloutArgs &a, SH &sh)
+{
+  using R = GroupRoles<SH>;
+  constexpr int NSW = SH::NSW;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15;
+  const int T = a.T;
+  const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]);
+  const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+  const uint32_t a_mypub = lds_addr(&sh.pose_pub[lane]);
+  float x = a.state[0], y = a.state[1], yaw = a.state[2];
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kPose + 1), seen = 0, cdone = 0;
+  float tf_p = 0.0f, tb_p = 0.0f;
+  for (int t = 0; t <= T; t++) {
+    float tf = 0.0f, tb = 0.0f;
+    if (t < T) {
+      const int need = t * NSW + 1;  // rec(t) is written before wave 0 publishes the first swap of step t
+      while (seen < need && --budget > 0) {
+        seen = lds_peek(a_seq0);
+        if (seen < need) __builtin_amdgcn_s_sleep(1);
+      }
+      const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kGRing - 1)][j][0]);  // s3 s4 s5 s6
+      float spsi, cpsi;
+      sincos_fast(yaw, spsi, cpsi);
+      const float st[3] = {x, y, yaw};
+      track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
+      // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
+      const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
+      const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
+      const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
+      x = fmaf(sd0, a.dt, x);
+      y = fmaf(sd1, a.dt, y);
+      yaw = fmaf(sd2, a.dt, yaw);
+    }
+    if (t > 0) {
+      // the texels of step t-1; their ring slot held step t-1-kGRing, which the cost wave must have consumed
+      while (cdone < t - kGRing && --budget > 0) cdone = lds_peek(a_cd);
+      if (lane < kRolloutsPerWave) *reinterpret_cast<float2 *>(&sh.tex[(t - 1) & (kGRing - 1)][lane][0]) = make_float2(tf_p, tb_p);
+      lds_publish(a_mypub, t);  // steps < t are out
+    }
+    tf_p = tf; tb_p = tb;
+  }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kPose]));
+}
+
+// the end of the cost wave: wait for every other wave's finished word, poison on a raised fail word
+template <class SH>
+__device__ __forceinline__ float group_settle(SH &sh, int budget, float J)
+{
+  using R = GroupRoles<SH>;
+  const int lane = threadIdx.x & 63;
+  // a hand-over that never arrived, in ANY wave of the group: poison, do not hang (mppi_device.hpp).  The
+  // other waves raise the fail word before their finished word; the kernel cannot end before they do.
+  // lane r < kWaves looks at finished word r (the cost wave's own counts as set)
+  const uint32_t a_fin = lds_addr(&sh.fin[(lane < R::kWaves) ? lane : 0]);
+  for (;;) {
+    const int v = (lane == R::kCost) ? 1 : lds_peek_lanes(a_fin);
+    const bool all = __builtin_amdgcn_ballot_w64(v != 0) == ~0ull;
+    if (all || --budget <= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
+  return J;
+}
+
+// ---------------------------------- cost wave ----------------------------------
+// computeCost over the records of the dynamics, control and pose waves; running mean; writes costs[k].
+template <class SH, bool CTRL>
+__device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
+{
+  using R = GroupRoles<SH>;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15;
+  const int k = blockIdx.x * kRolloutsPerWave + j;
+  const int T = a.T;
+  const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
+  const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
+  int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kCost + 1), seen = 0;
+  float J = 0.0f;
+  for (int t = 0; t < T; t++) {
+    const double rt = a.inv_t[t];
+    // the pose wave publishes the texels of step t after it has read rec(t): the records of step t are there
+    // (ctl(t) was published before the dynamics waves could start step t)
+    while (seen < t + 1 && --budget > 0) {
+      seen = lds_peek(a_pose);
+      if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+    }
+    const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kGRing - 1)][j][0]);      // s3 s4 s5 s6
+    const float4 r1 = *reinterpret_cast<const float4 *>(&sh.ctl_rec[t & (kGRing - 1)][j][0]);  // u0 u1 du0 du1
+    const float2 tx = *reinterpret_cast<const float2 *>(&sh.tex[t & (kGRing - 1)][j][0]);      // front, back texel
+    lds_publish(a_mydone, t + 1);  // executes after the three reads (the LDS runs a wave's instructions in order)
+    const int rc = (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
+    CostTerms ct;
+    cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+    // running mean over 1..T-1 (Q5); the t = 0 evaluation is discarded
+    crash |= rc;
+    int crash_new = crash;
+    const float c = cost_terms_b(a.cost, ct, tx.x, tx.y, crash_new);
+    const float Jn = running_mean(J, c, t, rt);
+    J = (t > 0) ? Jn : J;
+    crash = (t > 0) ? crash_new : crash;
+  }
+  J = group_settle(sh, budget, J);
+  a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
+}
+
+}  // namespace mppi

@@ -81,7 +81,8 @@ struct mppi_handle {
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 0;    // 0: auto; 512: quad (2 dynamics + cost + control waves per 16 rollouts); 64, 256: single-wave form;
+  int block_threads = 0;    // 0: auto; 512: quad (2 dynamics + cost + control waves per 16 rollouts); 800: oct (4 dynamics waves, one M tile of a
+                            // 64-wide net each, + pose, cost, control, noise wave); 64, 256: single-wave form;
                             // 1000 + ND: multi form (ND dynamics waves of 16 rollouts + cost wave + control wave), ND = 1, 2, 4
   bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
   int num_simds = 1024;     // 4 per CU
@@ -245,15 +246,17 @@ bool use_valu_reg(const mppi_handle *h) { return !h->basis && !use_mfma(h) && h-
 // 4 SIMDs).  Measured rollout-kernel times (this file's forms are bit-identical, so only time decides):
 //   * up to one group per CU (K <= 4096): the QUAD form -- the network itself split over two SIMDs, plus a
 //     cost and a control wave; the T-step recurrence is latency bound and this is the shortest chain
-//     (6-32-32-4, T=100, K=4096: quad 71 us, multi1 / multi2 83 us, single-wave 122 us);
+//     (6-32-32-4, T=100, K=4096: quad 71 us, multi1 / multi2 83 us, single-wave 122 us).  64-wide nets: the
+//     OCT form -- one M tile per dynamics wave, four of them, and four riders (rollout_oct.hip; T=100,
+//     K=4096: 6-64-64-4 oct 108 us, quad 134 us; 6-64x4-4 oct 185 us, quad 279 us);
 //   * up to two groups per CU (K <= 8192): MULTI2 -- two dynamics waves (whole network each), one cost wave,
 //     one control wave with the in-kernel generator, every wave on a SIMD of its own (K=8192: 83 us; quad
 //     112 us, single-wave 123 us; 6-64-64-4, T=150: 277 us vs 359 / 339 us);
 //   * beyond: MULTI4 with eps from the stand-alone generator kernel -- four dynamics waves per workgroup, one
 //     per SIMD, the cost and control waves riding along (K=16384: 106 us vs 124 us single-wave;
 //     6-64-64-4, T=150: 306 us vs 341 us; the in-kernel generator would load one SIMD too much: 341 us).
-// Shapes the multi form does not have (6-64x4-4: its weights do not fit a wave of a six-wave workgroup) keep
-// the quad form while its four waves per group fit the SIMDs and the single-wave form after that -- in
+// Shapes the multi form does not have (6-64x4-4: its weights do not fit a wave of a six-wave workgroup) run
+// the single-wave form beyond one group per CU -- in
 // workgroups of FOUR waves: the dispatcher spreads the waves of one workgroup over the four SIMDs of a CU,
 // whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD on paper (K = 16384) --
 // sometimes two on one SIMD and none on its neighbour, which doubles the kernel time
@@ -263,6 +266,7 @@ int effective_block(const mppi_handle *h)
   if (h->block_threads != 0) return h->block_threads;
   const int groups = h->K / kRolloutsPerWave;
   const int cus = h->num_simds / 4;
+  if (groups <= cus && oct_variant_supported(h->hidden, h->n_hidden)) return 800;
   if (multi_variant_supported(h->hidden, h->n_hidden)) {
     if (groups <= cus) return 512;
     if (groups <= 2 * cus) return 1002;
@@ -291,7 +295,7 @@ bool has_noise_wave(const mppi_handle *h)
 {
   if (!use_mfma(h)) return false;
   const int b = effective_block(h);
-  return b == 512 || (b > 1000 && !multi_gen(h));
+  return b == 512 || ((b == 800 || b > 1000) && !multi_gen(h));
 }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
@@ -357,6 +361,7 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
   hipError_t e = h->basis ? launch_rollout_bf(a, bf_two_waves(h), h->stream)
                  : (use_mfma(h) && effective_block(h) > 1000)
                      ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
+                 : (use_mfma(h) && effective_block(h) == 800) ? launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream)
                  : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
                                    : launch_rollout_valu(h->net, a, h->stream);
@@ -1477,7 +1482,7 @@ const char *mppi_rollout_variant(const mppi_handle *h)
              multi_gen(h) ? "_gen" : "");
   else
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
-             b == 512 ? "quad4w" : (b == 256 ? "fused_b256" : "fused_b64"));
+             b == 512 ? "quad4w" : b == 800 ? (multi_gen(h) ? "oct8w_gen" : "oct8w") : (b == 256 ? "fused_b256" : "fused_b64"));
   return buf;
 }
 
@@ -1494,6 +1499,12 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
   else if (strcmp(name, "valu_lds") == 0) h->variant_pref = 3;
   else if (strcmp(name, "quad") == 0) h->block_threads = 512;
+  else if (strcmp(name, "oct") == 0 || strcmp(name, "oct_gen") == 0) {
+    if (!h->mfma_ok || !oct_variant_supported(h->hidden, h->n_hidden))
+      return fail(h, MPPI_ERR_UNSUPPORTED, "oct form exists for 6-64x2-4 and 6-64x4-4");
+    h->block_threads = 800;
+    h->multi_standalone_noise = name[3] != 0;
+  }
   else if (strncmp(name, "multi", 5) == 0) {
     const int nd = name[5] - '0';
     const bool gen = strcmp(name + 6, "_gen") == 0;

@@ -266,6 +266,13 @@ __device__ __forceinline__ int lds_peek(uint32_t addr)
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
   return __builtin_amdgcn_readfirstlane(v);
 }
+// one word per lane, not made uniform
+__device__ __forceinline__ int lds_peek_lanes(uint32_t addr)
+{
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
 
 // Budget of one wavefront's waits (all of them together): `while (<not yet there> && --budget > 0) poll;`.
 // fault_wave (tests) starts one role with an exhausted budget: it then never waits for anybody, which is

@@ -34,6 +34,11 @@ hipError_t launch_dynamics_mfma(int hidden, int n_hidden, const float *wpack, co
 bool multi_variant_supported(int hidden, int n_hidden);
 hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, int nd, hipStream_t stream);
 
+// rollout_oct.hip: four dynamics waves (one M tile of a 64-wide net each) + pose, cost, control and noise wave per
+// 16 rollouts
+bool oct_variant_supported(int hidden, int n_hidden);
+hipError_t launch_rollout_oct(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
+
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {
   int n_layers;

@@ -49,13 +49,6 @@ __device__ __forceinline__ void lds_put1(uint32_t addr, float v)
 {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-// one word per lane, not made uniform
-__device__ __forceinline__ int lds_peek_lanes(uint32_t addr)
-{
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-  return v;
-}
 // smallest of the ND dynamics waves' publication counts (lane l reads the word of wave l % ND)
 template <int ND>
 __device__ __forceinline__ int dyn_pub_min(uint32_t a_lane_word)

@@ -57,6 +57,8 @@ def _draw(golden_dir, seed):
     else:
         cfg = S.make_config(K, T, layers=layers, track=track, **over)
         variants = ["auto", "quad", "fused", "multi4", "multi2", "multi1", "multi4_gen", "valu", "valu_lds"]
+        if layers is not None and len(layers) > 1 and layers[1] == 64:
+            variants += ["oct", "oct_gen"]
     st = cfg["start_state"].copy()
     st[4], st[5], st[6], st[3] = rng.uniform(0.05, 12.0), rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.2, 0.2)
     if rng.rand() < 0.2:

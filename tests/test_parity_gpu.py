@@ -207,6 +207,51 @@ def test_quad_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
         np.testing.assert_array_equal(a["U"].view(np.uint32), m["U"].view(np.uint32))
 
 
+@pytest.mark.parametrize("K,T,layers", [(256, 30, [6, 64, 64, 4]), (64, 2, [6, 64, 64, 4]), (128, 3, [6, 64, 64, 4]),
+                                        (192, 37, [6, 64, 64, 64, 64, 4]), (64, 17, [6, 64, 64, 64, 64, 4])])
+def test_oct_kernel_agrees_bitwise_with_the_single_wave_form(K, T, layers):
+    """The eight-wave form for 64-wide nets (four dynamics waves, one M tile of every layer each, all-to-all
+    swap per layer; riders: pose -> cost and noise -> control) keeps every dot product's k-ascending order:
+    costs, applied controls and the new control sequence equal the single-wave form's bit for bit -- also for
+    horizons shorter than the rings, T not a multiple of the control wave's chunk, and in generator mode."""
+    l, th = P.synthetic_model(layers, seed=4)
+    cfg = S.make_config(K, T, track="oval", layers=l, theta=th)
+    U0 = warm_U(cfg)
+    _, a = _solve_both(cfg, U0=U0, variant="fused")
+    for v in ("oct", "auto"):
+        _, m = _solve_both(cfg, U0=U0, variant=v)
+        assert "oct8w" in m["variant"]
+        np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))
+        np.testing.assert_array_equal(a["V"].view(np.uint32), m["V"].view(np.uint32))
+        np.testing.assert_array_equal(a["U"].view(np.uint32), m["U"].view(np.uint32))
+    # generator mode: the noise wave draws in the kernel, like the quad form's control wave; "_gen": eps from the
+    # stand-alone generator kernel.  Same streams, same sequence of solves.
+    names = ("quad", "oct", "oct_gen", "fused")
+    sols = [capi.Solver(cfg) for _ in names]
+    for sol, v in zip(sols, names):
+        sol.set_rollout_variant(v)
+    for it in range(3):
+        for sol in sols:
+            sol.compute_control(cfg["start_state"])
+        r0 = sols[0].get_results()
+        for sol, v in zip(sols[1:], names[1:]):
+            r1 = sol.get_results()
+            assert v.replace("oct", "oct8w") in sol.rollout_variant()
+            np.testing.assert_array_equal(r0["costs"].view(np.uint32), r1["costs"].view(np.uint32))
+            np.testing.assert_array_equal(r0["U"].view(np.uint32), r1["U"].view(np.uint32))
+    for sol in sols:
+        sol.close()
+
+
+def test_oct_form_is_refused_for_narrow_nets():
+    cfg = S.make_config(64, 10, track="oval")
+    sol = capi.Solver(cfg)
+    with pytest.raises(capi.MppiError) as e:
+        sol.set_rollout_variant("oct")
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    sol.close()
+
+
 def test_cold_start_zero_controls():
     cfg = S.make_config(1024, 100, track="oval")
     ref, got = _solve_both(cfg)
@@ -403,6 +448,11 @@ def test_solve_with_the_other_shipped_models(golden_dir, name, negate):
     _, f = _solve_both(cfg, U0=U0, variant="fused")
     assert "quad" in q["variant"] and "fused" in f["variant"]
     np.testing.assert_array_equal(q["costs"].view(np.uint32), f["costs"].view(np.uint32))
+    if layers[1] == 64:  # the eight-wave form of the 64-wide nets (the automatic choice at this size)
+        _, x = _solve_both(cfg, U0=U0)
+        assert "oct8w" in x["variant"]
+        np.testing.assert_array_equal(x["costs"].view(np.uint32), f["costs"].view(np.uint32))
+        np.testing.assert_array_equal(x["U"].view(np.uint32), f["U"].view(np.uint32))
     np.testing.assert_array_equal(q["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
     err = rel_err(q["costs"], ref["costs"])
     assert int(np.sum(err > 1e-4)) <= 3 and float(np.percentile(err, 95)) < 1e-5
