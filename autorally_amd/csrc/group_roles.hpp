@@ -2,7 +2,7 @@
 // whose network is split over NW dynamics wavefronts of one workgroup, rollout_oct.hip), written over the
 // group's LDS block: pose wave -> cost wave, noise wave -> control wave.  Each is one pipeline stage: a rider
 // only gets the issue slots its SIMD's dynamics wave leaves free (the waits of the swaps), and one stage per SIMD
-// keeps every stage inside that budget (DESIGN.md 4.7).
+// keeps every stage inside that budget (DESIGN.md 4.2b).
 //
 // SH (the __shared__ struct of the kernel) provides
 //   static constexpr int NW, NSW;           dynamics waves of the group; swaps they publish per step
@@ -14,7 +14,7 @@
 //   float ctl_rec[kGRing][16][4];           clamped u0, u1 and du0, du1 for the cost wave
 //   int   ctl_pub[64];                      steps published by the control wave
 //   float tex[kGRing][16][2]; int pose_pub[64];   front / back texel of step t; steps published by the pose wave
-//   float eps[kGRing][16][2]; int rng_pub[64];    the generator's pair of step t; steps published by the noise wave
+//   float eps[kGRing][16][2]; int rng_pub[64];    the generator's two uniforms of step t; steps published by the noise wave
 //   int   fail[4]; int fin[8];              mppi_device.hpp: spin_finish
 // Roles (= wave index in the workgroup): 0..NW-1 dynamics, then pose, cost, control, noise.  a.fault_wave ==
 // role + 1 starts that role with an exhausted poll budget (mppi_debug_inject_handover_fault).
@@ -48,7 +48,9 @@ __device__ __forceinline__ int group_seq_min(SH &sh)
 }
 
 // ---------------------------------- noise wave ----------------------------------
-// The handle's MRG32k3a streams, one lane per rollout, one pair per step, into a ring for the control wave.
+// The handle's MRG32k3a streams, one lane per rollout: the two uniform draws of every step into a ring for the
+// control wave, which does Box-Muller (the generator's 64-bit multiply chains on quarter-rate v_mul_hi_u32 are
+// work enough for one rider).
 template <class SH>
 __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
 {
@@ -68,7 +70,7 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
     const uint32_t a_mypub = lds_addr(&sh.rng_pub[lane]);
     int seen = 0;
     for (int t = 0; t < T; t++) {
-      const float2 e = active ? noise_pair(gsta) : make_float2(0.0f, 0.0f);
+      const float2 e = active ? uniform_pair(gsta) : make_float2(0.5f, 0.5f);
       // slot t % kGRing held step t - kGRing, consumed once the control wave has published that step
       const int need = t - kGRing + 1;
       while (seen < need && --budget > 0) {
@@ -134,7 +136,7 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
             seen_r = lds_peek(a_rng);
             if (seen_r < t + 1) __builtin_amdgcn_s_sleep(1);
           }
-          e = *reinterpret_cast<const float2 *>(&sh.eps[t & (kGRing - 1)][lane & 15][0]);
+          e = box_muller(*reinterpret_cast<const float2 *>(&sh.eps[t & (kGRing - 1)][lane & 15][0]));
         }
         if (active) {
           // control perturbation, mppi_controller.cu:136-153

@@ -112,15 +112,27 @@ __device__ __forceinline__ void spec_sincos2pi(float v, float &sn, float &cs)
   cs = -c2;
 }
 
-// One timestep's pair of N(0,1) draws: two generator steps + Box-Muller.
-__device__ __forceinline__ float2 noise_pair(Mrg &g)
+// One timestep's pair of uniforms: two generator steps.
+__device__ __forceinline__ float2 uniform_pair(Mrg &g)
 {
   const float u1 = (float)mrg_next_z(g) * 0x1p-32f;
   const float u2 = (float)mrg_next_z(g) * 0x1p-32f;
-  const float r = sqrtf(-2.0f * spec_logf(u1));
+  return make_float2(u1, u2);
+}
+
+// Box-Muller on one pair of uniforms.
+__device__ __forceinline__ float2 box_muller(float2 u)
+{
+  const float r = sqrtf(-2.0f * spec_logf(u.x));
   float sn, cs;
-  spec_sincos2pi(u2, sn, cs);
+  spec_sincos2pi(u.y, sn, cs);
   return make_float2(r * sn, r * cs);
+}
+
+// One timestep's pair of N(0,1) draws: two generator steps + Box-Muller.
+__device__ __forceinline__ float2 noise_pair(Mrg &g)
+{
+  return box_muller(uniform_pair(g));
 }
 
 }  // namespace mppi

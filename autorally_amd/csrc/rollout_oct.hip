@@ -15,7 +15,7 @@
 // The four dynamics waves take the four SIMDs of the CU, so everything else rides along in the issue slots they
 // leave free (the waits of the swaps).  With two riders (cost wave, control wave with the generator) the
 // control wave could not keep up with a 6-64-64-4 step: rollout 125 us; with the work cut into four stages, one
-// per SIMD, 108 us (102 us when eps comes from the generator kernel; the dynamics chain alone).
+// per SIMD, 107 us (101 us when eps comes from the generator kernel: the dynamics chain alone).
 //
 // Hand-overs: LDS sequence words, no barrier in the T loop (rollout_mfma.hip, quad form).  Two parities of the
 // swap buffer suffice: a wave publishes swap n+1 only after it has loaded every partner's swap n, so when a

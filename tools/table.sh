@@ -26,5 +26,6 @@ row k16384 --K 16384 --no-cpu-baseline
 row k65536 --K 65536 --no-cpu-baseline --steps 100
 row k32768_h64 --K 32768 --T 150 --layers 6-64-64-4 --no-cpu-baseline --steps 50
 row k4096_h64 --K 4096 --T 100 --layers 6-64-64-4 --no-cpu-baseline
+row k1920_wd --K 1920 --T 100 --layers 6-64-64-64-64-4 --no-cpu-baseline
 row k4096_l4 --K 4096 --T 100 --layers 6-32-32-32-32-4 --no-cpu-baseline
 row bf2560 --dynamics basis --K 2560
