@@ -248,7 +248,9 @@ bool use_valu_reg(const mppi_handle *h) { return !h->basis && !use_mfma(h) && h-
 //     cost and a control wave; the T-step recurrence is latency bound and this is the shortest chain
 //     (6-32-32-4, T=100, K=4096: quad 71 us, multi1 / multi2 83 us, single-wave 122 us).  64-wide nets: the
 //     OCT form -- one M tile per dynamics wave, four of them, and four riders (rollout_oct.hip; T=100,
-//     K=4096: 6-64-64-4 oct 108 us, quad 134 us; 6-64x4-4 oct 185 us, quad 279 us);
+//     K=4096: 6-64-64-4 oct 108 us, quad 134 us; 6-64x4-4 oct 185 us, quad 279 us), also at two groups per
+//     CU (K=8192: 6-64-64-4 oct 172 us, multi2 187 us; 6-64x4-4 oct 365 us, single-wave 503 us; at four
+//     groups per CU it loses: 724 vs 508 us);
 //   * up to two groups per CU (K <= 8192): MULTI2 -- two dynamics waves (whole network each), one cost wave,
 //     one control wave with the in-kernel generator, every wave on a SIMD of its own (K=8192: 83 us; quad
 //     112 us, single-wave 123 us; 6-64-64-4, T=150: 277 us vs 359 / 339 us);
@@ -266,7 +268,7 @@ int effective_block(const mppi_handle *h)
   if (h->block_threads != 0) return h->block_threads;
   const int groups = h->K / kRolloutsPerWave;
   const int cus = h->num_simds / 4;
-  if (groups <= cus && oct_variant_supported(h->hidden, h->n_hidden)) return 800;
+  if (groups <= 2 * cus && oct_variant_supported(h->hidden, h->n_hidden)) return 800;
   if (multi_variant_supported(h->hidden, h->n_hidden)) {
     if (groups <= cus) return 512;
     if (groups <= 2 * cus) return 1002;
