@@ -284,17 +284,21 @@ bool multi_gen(const mppi_handle *h)
   return effective_block(h) == 1004;
 }
 
-// basis-function model: dynamics wave + cost wave per 64 rollouts ("fused" / "block64" force the one-wave form)
-bool bf_two_waves(const mppi_handle *h)
+// basis-function model, wavefronts per 64 rollouts: dynamics + cost + control wave (in-kernel generator) while
+// each gets a SIMD of its own; dynamics + cost wave ("quad") up to twice that; one wave ("fused" / "block64")
+int bf_waves(const mppi_handle *h)
 {
-  if (h->block_threads == 64 || h->block_threads == 256) return false;
-  if (h->block_threads == 512) return true;
-  return 2 * (h->K / 64) <= 2 * h->num_simds;
+  if (h->block_threads == 64 || h->block_threads == 256) return 1;
+  if (h->block_threads == 512) return 2;
+  if (h->block_threads == 768) return 3;
+  if (3 * (h->K / 64) <= h->num_simds) return 3;
+  return (2 * (h->K / 64) <= 2 * h->num_simds) ? 2 : 1;
 }
 
 // the quad and multi MFMA kernels carry their own control/noise wavefront
 bool has_noise_wave(const mppi_handle *h)
 {
+  if (h->basis) return bf_waves(h) == 3;
   if (!use_mfma(h)) return false;
   const int b = effective_block(h);
   return b == 512 || ((b == 800 || b > 1000) && !multi_gen(h));
@@ -360,7 +364,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
 int launch_rollout(mppi_handle *h, const RolloutArgs &a)
 {
   // basis-function model: the two-wave form while both waves of a group get a SIMD of their own
-  hipError_t e = h->basis ? launch_rollout_bf(a, bf_two_waves(h), h->stream)
+  hipError_t e = h->basis ? launch_rollout_bf(a, bf_waves(h), h->stream)
                  : (use_mfma(h) && effective_block(h) > 1000)
                      ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
                  : (use_mfma(h) && effective_block(h) == 800) ? launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream)
@@ -1475,7 +1479,7 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out)
 const char *mppi_rollout_variant(const mppi_handle *h)
 {
   if (!h) return "";
-  if (h->basis) return bf_two_waves(h) ? "basis_funcs25_valu_2w" : "basis_funcs25_valu";
+  if (h->basis) return bf_waves(h) == 3 ? "basis_funcs25_valu_3w" : bf_waves(h) == 2 ? "basis_funcs25_valu_2w" : "basis_funcs25_valu";
   if (!use_mfma(h)) return use_valu_reg(h) ? "valu_reg_lds" : "valu_lds";
   static thread_local char buf[64];
   const int b = effective_block(h);
@@ -1501,6 +1505,10 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   } else if (strcmp(name, "valu") == 0) h->variant_pref = 2;
   else if (strcmp(name, "valu_lds") == 0) h->variant_pref = 3;
   else if (strcmp(name, "quad") == 0) h->block_threads = 512;
+  else if (strcmp(name, "bf3") == 0) {
+    if (!h->basis) return fail(h, MPPI_ERR_UNSUPPORTED, "bf3 is a form of the basis-function model");
+    h->block_threads = 768;
+  }
   else if (strcmp(name, "oct") == 0 || strcmp(name, "oct_gen") == 0) {
     if (!h->mfma_ok || !oct_variant_supported(h->hidden, h->n_hidden))
       return fail(h, MPPI_ERR_UNSUPPORTED, "oct form exists for 6-64x2-4 and 6-64x4-4");

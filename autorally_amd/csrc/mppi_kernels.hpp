@@ -56,7 +56,7 @@ hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const fl
                                 hipStream_t stream);
 
 // rollout_bf.hip (GeneralizedLinear basis-function dynamics, W[4][25] in a.wpack)
-hipError_t launch_rollout_bf(const RolloutArgs &a, bool two_waves, hipStream_t stream);
+hipError_t launch_rollout_bf(const RolloutArgs &a, int waves, hipStream_t stream);  // waves per 64 rollouts: 1, 2, 3
 hipError_t launch_dynamics_bf(const float *W, const float *states, const float *controls, float *ders, int n,
                               hipStream_t stream);
 

@@ -7,6 +7,7 @@
 // instruction could help with -- followed by the same cost evaluation as the network kernels.  W
 // (400 B) is staged into LDS and read as broadcasts.  Noise comes from the stand-alone generator.
 #include "basis_funcs.hpp"
+#include "noise_device.hpp"
 #include "mppi_kernels.hpp"
 
 namespace mppi {
@@ -273,6 +274,175 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// rollout_bf3_kernel: the two-wave form with the control work in a THIRD wavefront, like the control wave of
+// the network kernels (rollout_mfma.hip): noise (the handle's MRG32k3a streams in the kernel, or the explicit
+// eps buffer), the perturbed control, its write-back before the clamp (Q3), the clamp.  Nothing of
+// mppi_controller.cu:136-153 depends on the state, so this wave runs up to kBfRing steps ahead, the dynamics
+// wave touches no global memory in the T loop, and the stand-alone generator kernel in front of the rollout
+// (7.9 us at K = 2560, T = 100) is gone.  Of the last step only the state record goes out (its update feeds
+// nothing, mppi_controller.cu:160-177).  Same arithmetic, same order: bit-identical to the other two forms.
+//   roles: 0 dynamics, 1 cost, 2 control (a.fault_wave == role + 1: mppi_debug_inject_handover_fault)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const RolloutArgs a)
+{
+  __shared__ __attribute__((aligned(16))) float W_s[4 * kNumBfs];  // transposed: [25][4]
+  __shared__ float rec[kBfRing][8][kBfLanes];  // [slot][field][lane]: s3 s4 s5 s6 (dynamics) | u0 u1 du0 du1 (control)
+  __shared__ int pub[kBfLanes], cpub[kBfLanes], done[kBfLanes], fail[4], fin[4];
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int i = threadIdx.x; i < 4 * kNumBfs; i += 3 * kBfLanes) W_s[(i % kNumBfs) * 4 + i / kNumBfs] = a.wpack[i];
+  if (role == 0) { pub[lane] = 0; cpub[lane] = 0; done[lane] = 0; fail[lane & 3] = 0; fin[lane & 3] = 0; }
+  __syncthreads();  // the only barrier
+  const int k = blockIdx.x * kBfLanes + lane;
+  const int K = a.K, T = a.T;
+  const uint32_t a_pub = lds_addr(&pub[0]), a_cpub = lds_addr(&cpub[0]), a_done = lds_addr(&done[0]);
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == role + 1);  // mppi_device.hpp
+
+  if (role == 0) {
+    // ------------------------------ dynamics wave ------------------------------
+    const uint32_t a_mypub = lds_addr(&pub[lane]);
+    BfWeights Wr;
+    Wr.load(W_s);
+    float s[kStateDim];
+#pragma unroll
+    for (int i = 0; i < kStateDim; i++) s[i] = a.state[i];
+    int seen = 0;  // steps the control wave has published
+    for (int t = 0; t < T; t++) {
+      // controls of step t: the control wave wrote them only after the cost wave had consumed step t - kBfRing,
+      // so the slot's state fields are free as well
+      while (seen < t + 1 && --budget > 0) seen = lds_peek(a_cpub);
+      const int slot = t & (kBfRing - 1);
+      const float u0 = rec[slot][4][lane], u1 = rec[slot][5][lane];
+      rec[slot][0][lane] = s[3]; rec[slot][1][lane] = s[4]; rec[slot][2][lane] = s[5]; rec[slot][3][lane] = s[6];
+      lds_publish(a_mypub, t + 1);
+      if (t == T - 1) break;  // the last update feeds nothing
+      float phi[kNumBfs], d[4];
+      BasisShared c;
+      basis_shared_fast(s, u0, c);
+      basis_funcs_from(s, u1, c, phi);
+      basis_dynamics_dev(Wr, phi, d);
+#pragma unroll
+      for (int i = 0; i < 4; i++) s[3 + i] = fmaf(d[i], a.dt, s[3 + i]);
+    }
+    spin_finish(budget, lds_addr(&fail[0]), lds_addr(&fin[0]));
+  } else if (role == 2) {
+    // ------------------------------ control wave ------------------------------
+    const uint32_t a_mypub = lds_addr(&cpub[lane]);
+    const bool inl = a.inline_noise != 0;
+    Mrg gsta{0, 0, 0, 0, 0, 0};
+    if (inl) {
+      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
+      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
+    }
+    float2 *const noise = reinterpret_cast<float2 *>(a.noise);
+    const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
+    const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
+    const bool pure_noise_k = (k >= a.k99);  // :141
+    constexpr int kChunk = 4;  // steps of U / explicit eps requested at once
+    int seen_d = 0, seen_c = 0;  // steps published by the dynamics wave / consumed by the cost wave
+    for (int t0 = 0; t0 < T; t0 += kChunk) {
+      float2 Uq[kChunk], eq[kChunk];
+#pragma unroll
+      for (int q = 0; q < kChunk; q++) {
+        const int tq = min(t0 + q, T - 1);
+        Uq[q] = Useq[tq];
+        eq[q] = inl ? make_float2(0.0f, 0.0f) : noise[(size_t)tq * K + k];
+      }
+#pragma unroll
+      for (int q = 0; q < kChunk; q++) {
+        const int t = t0 + q;
+        if (t < T) {
+          const float2 e = inl ? noise_pair(gsta) : eq[q];
+          float du0, du1, u0, u1;
+          if (noise_free_k || t < a.opt_delay) {
+            du0 = 0.0f; du1 = 0.0f; u0 = Uq[q].x; u1 = Uq[q].y;
+          } else {
+            du0 = e.x * a.nu[0];
+            du1 = e.y * a.nu[1];
+            u0 = pure_noise_k ? du0 : Uq[q].x + du0;
+            u1 = pure_noise_k ? du1 : Uq[q].y + du1;
+          }
+          noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+          u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+          u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+          // slot t % kBfRing held step t - kBfRing: the dynamics wave read its controls before it published
+          // that step, the cost wave is done with it once it has consumed it
+          const int need = t - kBfRing + 1;
+          while ((seen_d < need || seen_c < need) && --budget > 0) {
+            seen_d = lds_peek(a_pub);
+            seen_c = lds_peek(a_done);
+            if (seen_d < need || seen_c < need) __builtin_amdgcn_s_sleep(2);
+          }
+          const int slot = t & (kBfRing - 1);
+          rec[slot][4][lane] = u0; rec[slot][5][lane] = u1; rec[slot][6][lane] = du0; rec[slot][7][lane] = du1;
+          lds_publish(a_mypub, t + 1);
+        }
+      }
+    }
+    if (inl) {
+      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
+      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+    }
+    spin_finish(budget, lds_addr(&fail[0]), lds_addr(&fin[2]));
+  } else {
+    // -------------------------------- cost wave --------------------------------
+    const uint32_t a_mydone = lds_addr(&done[lane]);
+    float x = a.state[0], y = a.state[1], yaw = a.state[2];
+    int crash = 0, seen = 0;
+    float J = 0.0f;
+    float tf_p = 0.0f, tb_p = 0.0f;
+    CostTerms ct_p{0.0f, 0.0f, 0.0f};
+    int rc_p = 0;
+    double rt_p = 0.0;
+    for (int t = 0; t <= T; t++) {
+      float tf = 0.0f, tb = 0.0f;
+      CostTerms ct{0.0f, 0.0f, 0.0f};
+      int rc = 0;
+      double rt = 0.0;
+      if (t < T) {
+        rt = a.inv_t[t];
+        while (seen < t + 1 && --budget > 0) {  // the dynamics wave publishes step t after it has read ctl(t)
+          seen = lds_peek(a_pub);
+          if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        const int slot = t & (kBfRing - 1);
+        const float r3 = rec[slot][0][lane], r4 = rec[slot][1][lane], r5 = rec[slot][2][lane], r6 = rec[slot][3][lane];
+        const float u0 = rec[slot][4][lane], u1 = rec[slot][5][lane], du0 = rec[slot][6][lane], du1 = rec[slot][7][lane];
+        lds_publish(a_mydone, t + 1);  // executes after the reads (the LDS runs a wave's instructions in order)
+        rc = (int)((t > 0) & (fabsf(r3) >= kRollCrash));  // getCrash of update t-1
+        float spsi, cpsi;
+        sincos_fast(yaw, spsi, cpsi);
+        const float st[3] = {x, y, yaw};
+        if (t > 0) {
+          if (a.cost.affine) track_fetch<true>(a.cost, st, cpsi, spsi, tf, tb);
+          else track_fetch<false>(a.cost, st, cpsi, spsi, tf, tb);
+        }
+        if (a.cost.need_control_cost) cost_terms_a<true>(a.cost, a.nu, r4, r5, u0, u1, du0, du1, ct);
+        else cost_terms_a<false>(a.cost, a.nu, r4, r5, u0, u1, du0, du1, ct);
+        // computeKinematics (generalized_linear.cu:212-217, yaw rate always negated) + incrementState
+        const float sd0 = fmaf(cpsi, r4, -(spsi * r5));
+        const float sd1 = fmaf(spsi, r4, cpsi * r5);
+        x = fmaf(sd0, a.dt, x);
+        y = fmaf(sd1, a.dt, y);
+        yaw = fmaf(-r6, a.dt, yaw);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 1) {  // finish step t-1: running mean over 1..T-1 (Q5); step 0 is never costed
+        const int tp = t - 1;
+        crash |= rc_p;
+        const float c = cost_terms_b(a.cost, ct_p, tf_p, tb_p, crash);
+        J = running_mean(J, c, tp, rt_p);
+      }
+      tf_p = tf; tb_p = tb; ct_p = ct; rc_p = rc; rt_p = rt;
+    }
+    // a hand-over that never arrived, in any wave: poison, do not hang (mppi_device.hpp)
+    while ((lds_peek(lds_addr(&fin[0])) & lds_peek(lds_addr(&fin[2]))) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    if (budget <= 0 || lds_peek(lds_addr(&fail[0])) != 0) J = __builtin_nanf("");
+    a.costs[k] = J + 0.0f;
+  }
+}
+
 // test entry (mppi_debug_dynamics): state derivative of n independent (state, control) pairs
 __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, const float *states,
                                                                const float *controls, float *ders, int n)
@@ -296,9 +466,10 @@ __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, c
   for (int i = 0; i < kStateDim; i++) ders[idx * kStateDim + i] = sd[i];
 }
 
-hipError_t launch_rollout_bf(const RolloutArgs &a, bool two_waves, hipStream_t stream)
+hipError_t launch_rollout_bf(const RolloutArgs &a, int waves, hipStream_t stream)
 {
-  if (two_waves) MPPI_LAUNCH_ROLLOUT(rollout_bf2_kernel, dim3(a.K / kBfLanes), dim3(2 * kBfLanes), 0, stream, a);
+  if (waves == 3) MPPI_LAUNCH_ROLLOUT(rollout_bf3_kernel, dim3(a.K / kBfLanes), dim3(3 * kBfLanes), 0, stream, a);
+  else if (waves == 2) MPPI_LAUNCH_ROLLOUT(rollout_bf2_kernel, dim3(a.K / kBfLanes), dim3(2 * kBfLanes), 0, stream, a);
   else MPPI_LAUNCH_ROLLOUT(rollout_bf_kernel, dim3(a.K / kBfLanes), dim3(kBfLanes), 0, stream, a);
   return hipGetLastError();
 }

@@ -267,7 +267,7 @@ def test_control_ticks_equals_the_call_by_call_loop():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2),
+@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
                                          ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7),
                                          ("multi2", 2), ("multi2", 3), ("multi2", 4),
                                          ("oct", 1), ("oct", 2), ("oct", 3), ("oct", 4), ("oct", 5), ("oct", 6), ("oct", 7),
@@ -280,14 +280,16 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
     The hook starts one role with an exhausted poll budget: it never waits for its partners."""
     import os
     extra = {}
-    if family == "bf":
+    if family.startswith("bf"):
         extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
     elif family == "nn64" or family.startswith("oct"):
         l, th = P.synthetic_model([6, 64, 64, 4], seed=4)
         extra = dict(layers=l, theta=th)
     cfg = S.make_config(256, 40, track="oval", **extra)
     sol = capi.Solver(cfg)
-    if family != "bf":  # multi form: roles 1..ND = dynamics waves, then [pose wave (ND = 4),] cost wave, control wave;
+    if family == "bf2":
+        sol.set_rollout_variant("quad")  # dynamics + cost wave; "bf": + control wave (the automatic choice)
+    elif family != "bf":  # multi form: roles 1..ND = dynamics waves, then [pose wave (ND = 4),] cost wave, control wave;
         # oct form: 1..4 dynamics, 5 pose, 6 cost, 7 control, 8 noise wave
         sol.set_rollout_variant(family if family.startswith(("multi", "oct")) else "quad")
     sol.compute_control(cfg["start_state"])          # healthy

@@ -86,7 +86,7 @@ def test_gpu_basis_dynamics_match_oracle(golden_dir):
     cfg = _bf_cfg(golden_dir)
     orc = O.Oracle(cfg)
     sol = capi.Solver(cfg)
-    assert sol.rollout_variant() == "basis_funcs25_valu_2w"
+    assert sol.rollout_variant() == "basis_funcs25_valu_3w"
     s, u = _samples(512, seed=3)
     got = sol.debug_dynamics(s, u)
     ref = np.stack([orc.state_deriv(s[i], u[i]) for i in range(s.shape[0])])
@@ -130,23 +130,31 @@ def test_gpu_basis_solve_matches_oracle(golden_dir, K, T, track):
     r = orc.ddp_feedback_gains(x0, rs, rc)
     scale = np.abs(r["feedback"]).max()
     assert scale > 1e-3 and np.max(np.abs(g["feedback"] - r["feedback"])) <= 2e-2 * scale
-    # the one-wave form of the kernel does the same arithmetic in the same order
-    sol.set_rollout_variant("fused")
-    assert sol.rollout_variant() == "basis_funcs25_valu"
-    sol.set_control_seq(U0)
-    sol.set_noise(eps)
-    sol.compute_control(cfg["start_state"])
-    one = sol.get_results()
-    np.testing.assert_array_equal(one["costs"].view(np.uint32), got["costs"].view(np.uint32))
-    np.testing.assert_array_equal(one["U"].view(np.uint32), got["U"].view(np.uint32))
-    sol.set_rollout_variant("auto")
-    # generator mode runs too and is deterministic
-    sol.seed(5, 0)
-    sol.set_control_seq(U0)
-    sol.compute_control(x0)
-    a = sol.get_results()["U"].copy()
-    sol.seed(5, 0)
-    sol.set_control_seq(U0)
-    sol.compute_control(x0)
-    np.testing.assert_array_equal(a.view(np.uint32), sol.get_results()["U"].view(np.uint32))
+    # the one- and two-wave forms of the kernel do the same arithmetic in the same order as the three-wave form
+    assert sol.rollout_variant() == "basis_funcs25_valu_3w"
+    for v, name in (("fused", "basis_funcs25_valu"), ("quad", "basis_funcs25_valu_2w")):
+        sol.set_rollout_variant(v)
+        assert sol.rollout_variant() == name
+        sol.set_control_seq(U0)
+        sol.set_noise(eps)
+        sol.compute_control(cfg["start_state"])
+        one = sol.get_results()
+        np.testing.assert_array_equal(one["costs"].view(np.uint32), got["costs"].view(np.uint32))
+        np.testing.assert_array_equal(one["U"].view(np.uint32), got["U"].view(np.uint32))
+    # generator mode: the control wave's in-kernel draws (three-wave form) equal the stand-alone generator
+    # kernel's (the other forms), solve after solve; and a re-seeded handle repeats itself
+    seq = {}
+    for v in ("auto", "quad", "fused"):
+        sol.set_rollout_variant(v)
+        sol.seed(5, 0)
+        sol.reset_controls()
+        sol.set_control_seq(U0)
+        outs = []
+        for it in range(3):
+            sol.compute_control(x0)
+            outs.append(sol.get_results()["U"].copy())
+        seq[v] = outs
+    for v in ("quad", "fused"):
+        for a, b in zip(seq["auto"], seq[v]):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
     sol.close()
