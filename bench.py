@@ -277,6 +277,8 @@ def main():
             for _ in range(n):
                 step()
 
+    local_s = []  # this rank's own time for the steps of each block, before the closing barrier (per-GPU spread)
+
     def timed_block():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
         if dist is not None:
@@ -285,6 +287,7 @@ def main():
         t0 = time.perf_counter()
         run_steps(args.steps)
         sync()
+        local_s.append(time.perf_counter() - t0)
         if dist is not None:
             dist.barrier()
         return max_over_ranks(dist, time.perf_counter() - t0, cuda)
@@ -329,7 +332,9 @@ def main():
     # what every rank ran (proves the instances are distinct), gathered off the timed region
     mine = {"rank": rank, "start_state": [round(float(x), 4) for x in cfg["start_state"]],
             "map_checksum": float(np.asarray(cfg["map_rgba"], dtype=np.float64).sum()),
-            "U0": [round(float(x), 5) for x in sol.get_control_seq()[0]]}
+            "U0": [round(float(x), 5) for x in sol.get_control_seq()[0]],
+            "own_ms_per_step": 1e3 * local_s[0] / args.steps,  # the timed block, this GPU alone (no closing barrier)
+            "own_median_ms_per_step": 1e3 * float(np.median(local_s)) / args.steps}
     instances = [mine]
     if dist is not None:
         instances = [None] * world
@@ -372,7 +377,8 @@ def main():
             fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            inline_noise = ("quad" in variant) or ("multi" in variant and not variant.endswith("_gen"))
+            inline_noise = (("quad" in variant or "oct8w" in variant or "multi" in variant) and not variant.endswith("_gen")) \
+                or variant.endswith("_3w")  # the kernel's own noise / control wavefront draws eps
             bpu = ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
             out["stage_ms"]["note"] = ("HIP events on the handle's stream, %d solves, separate pass after the timed region: markers around the "
