@@ -209,14 +209,17 @@ int mppi_enable_stage_timing(mppi_handle *h, int on);
 int mppi_reset_stage_times(mppi_handle *h);
 int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
 /* Name of the rollout kernel variant in use: "mfma16x16x4_h32_l2_quad4w" (four wavefronts per 16
- * rollouts), "..._fused_b64" (one wavefront per 16 rollouts), "valu_reg_lds", "valu_lds",
- * "basis_funcs25_valu". */
+ * rollouts), "..._oct8w[_gen]" (eight, 64-wide nets), "..._multi{1,2,4}[_gen]", "..._fused_b256" / "_b64" (one
+ * wavefront per 16 rollouts), "valu_reg_lds", "valu_lds", "basis_funcs25_valu[_2w|_3w]". */
 const char *mppi_rollout_variant(const mppi_handle *h);
 /* Force a variant (A/B of SURVEY cfg 4 and of the kernel forms): "auto"; "mfma" | "valu" | "valu_lds"
  * (arithmetic unit); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
  * wavefront per 16 rollouts) | "multi4" | "multi2" | "multi1" (ND dynamics wavefronts of 16 rollouts + one
- * cost + one control wavefront; "_gen" appended: eps from the stand-alone generator kernel) | "fused" =
- * "block256" | "block64" (one wavefront per 16 rollouts does everything; workgroups of 4 or 1 waves). */
+ * cost + one control wavefront; "_gen" appended: eps from the stand-alone generator kernel) | "oct" | "oct_gen"
+ * (64-wide nets: four dynamics wavefronts, one M tile each, + pose, cost, control, noise wavefront per 16
+ * rollouts) | "fused" = "block256" | "block64" (one wavefront per 16 rollouts does everything; workgroups of 4
+ * or 1 waves).  Basis-function model: "bf3" (dynamics + cost + control wavefront per 64 rollouts) | "quad"
+ * (dynamics + cost) | "fused" (one).  MPPI_ERR_UNSUPPORTED if the handle's model has no such form. */
 int mppi_set_rollout_variant(mppi_handle *h, const char *name);
 
 /* Test hook (not part of the drop-in surface): d/dt of n independent (state[7], control[2])
