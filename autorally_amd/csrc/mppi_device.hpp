@@ -266,6 +266,15 @@ __device__ __forceinline__ int lds_peek(uint32_t addr)
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
   return __builtin_amdgcn_readfirstlane(v);
 }
+// The layer-0 B operand of k-step 0, [s3, s4, s5, s6][g] (g = lane >> 4), as a select tree of depth 2 (three
+// v_cndmask on lane-constant conditions; the ternary CHAIN on g is one level deeper on the T-step chain).
+__device__ __forceinline__ float row_sel(int g, float s3, float s4, float s5, float s6)
+{
+  const float lo = (g == 0) ? s3 : s4;
+  const float hi = (g == 2) ? s5 : s6;
+  return (g < 2) ? lo : hi;
+}
+
 // one word per lane, not made uniform
 __device__ __forceinline__ int lds_peek_lanes(uint32_t addr)
 {

@@ -60,6 +60,21 @@ __device__ __forceinline__ int dyn_pub_min(uint32_t a_lane_word)
   return m;
 }
 
+// Diagnostic build only (-DMPPI_STAMPS): s_memtime stamps of dynamics wave 0 of workgroup 0 (rollout_mfma.hip).
+#ifdef MPPI_STAMPS
+__device__ unsigned long long g_multi_stamps[8];
+#define MSTAMP(var)                                                              \
+  do {                                                                           \
+    unsigned long long t__;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");   \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    var = t__;                                                                   \
+  } while (0)
+#else
+#define MSTAMP(var) do { } while (0)
+#endif
+
 template <int H, int NHID, int ND>
 __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared<ND> &sh, const int w)
 {
@@ -87,25 +102,48 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
   // (s_setprio 3 here -- issue priority over the cost / control wave sharing this wave's SIMD -- changes nothing:
   //  cfg 4 304.4 us without, 305.5 us with; the co-resident wave's instructions cost their issue cycles either way)
   float b1_next = *p_b1;
-  int cd = 0;  // last value seen of the cost wave's consumption counter
-  for (int t = 0; t < T; t++) {
-    const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
-    const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
-    // record for the cost wave: the state BEFORE this step's update; its ring slot held step t - kMRing
-    while (cd < t - kMRing + 1 && --budget > 0) cd = __builtin_amdgcn_readfirstlane(*p_cd);
+  // Pinned: the value is "produced" here, so the wait for this LDS read sits here.  Otherwise the compiler's
+  // waitcnt pass, which cannot tell the first iteration from the others, puts an s_waitcnt lgkmcnt at the first
+  // use of b1 INSIDE the loop, where it waits every step for the record store and the publication issued just
+  // before it (LDS operations complete in order; ~20 cycles per step in tools/ub/dyn_step_ub.hip).
+  asm volatile("" : "+v"(b1_next));
+#ifdef MPPI_STAMPS
+  unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0, mprev = 0, ma[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  // the state record of step t (the state BEFORE its update) for the cost wave, then its publication -- which
+  // also says: this wave is done with the control record of step t
+  auto record = [&](int t, float b0) __attribute__((always_inline)) {
     lds_put1(a_rec + (uint32_t)(t & (kMRing - 1)) * kRecSlot, b0);
-    lds_publish(a_mypub, t + 1);  // also: this wave is done with the control record of step t
-    if (t == T - 1) break;  // the last update feeds no cost (mppi_controller.cu:160-177): no network evaluation
+    lds_publish(a_mypub, t + 1);
+  };
+  // Steps 0 .. T-2 in full; of step T-1 only the record goes out (the last update feeds no cost,
+  // mppi_controller.cu:160-177).  ONE scalar branch per step: the ring check of the NEXT step's record joins the
+  // test of the control wave's count at the end of the step, and the exit test of the last step is peeled off --
+  // a second test and an exit test at the top of the step cost ~210 cycles per step of this chain
+  // (tools/ub/dyn_step_ub.hip: 1 935 -> 1 727 cycles at 6-32-32-4, 4 394 -> 4 162 at 6-64-64-4).
+  for (int t = 0; t < T - 1; t++) {
+    MSTAMP(m0);
+    const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
+    // k-step 0 of layer 0 needs the state only: its MFMAs go first, and the step's LDS traffic below is issued
+    // in their shadow instead of in front of the chain
+    const float b0 = row_sel(g, s3, s4, s5, s6);
+    f32x4 acc[N::MT];
+#pragma unroll
+    for (int m = 0; m < N::MT; m++)
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m * 2 + 0], b0, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    record(t, b0);
     // requested now, used after the network: the control wave's count, then this lane's layer-0 operand
     // of step t+1 (valid if the count read before it is >= t+2), and the cost wave's progress
     const int tn = (t + 1) & (kMRing - 1);
     int cp = *p_pub;
     float b1n = p_b1[tn * (kB1Slot / 4)];
-    int cdn = *p_cd;
+    int cd = *p_cd;
     __builtin_amdgcn_sched_barrier(0);  // keep the requests up here: the scheduler would sink them to their use
+    MSTAMP(m1);
 
-    f32x4 acc[N::MT];
-    nn_layer0_ops<H, NHID>(A, b0, b1, acc);
+#pragma unroll
+    for (int m = 0; m < N::MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m * 2 + 1], b1, acc[m], 0, 0, 0);
     nn_hidden<H, NHID>(A, Bi, acc);
     float d[4];
     nn_last<H, NHID>(A, Bi, acc, d);
@@ -114,17 +152,30 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
     s5 = fmaf(d[2], a.dt, s5);
     s6 = fmaf(d[3], a.dt, s6);
 
+    MSTAMP(m2);
     __builtin_amdgcn_sched_barrier(0);  // ... and their first use down here, behind the network
-    const int want = min(t + 2, T);
+    // step t+1 may start when the control wave has published it (never late in steady state: it runs ahead) and
+    // the ring slot of its record is free: that slot held step t+1 - kMRing, consumed once cost_done >= t+2 - kMRing
+    const int want = t + 2, want_cd = t + 2 - kMRing;
     cp = __builtin_amdgcn_readfirstlane(cp);
-    while (cp < want && --budget > 0) {  // never in steady state: the control wave runs ahead
+    cd = __builtin_amdgcn_readfirstlane(cd);
+    while (((cp < want) | (cd < want_cd)) && --budget > 0) {
       cp = __builtin_amdgcn_readfirstlane(*p_pub);
       b1n = p_b1[tn * (kB1Slot / 4)];
-      cdn = *p_cd;
+      cd = __builtin_amdgcn_readfirstlane(*p_cd);
     }
     b1_next = b1n;
-    cd = __builtin_amdgcn_readfirstlane(cdn);
+#ifdef MPPI_STAMPS
+    MSTAMP(m3);
+    if (t >= 16) { ma[0] += m1 - m0; ma[1] += m2 - m1; ma[2] += m3 - m2; ma[3] += m0 - mprev; ma[4] += 1; }
+    mprev = m3;
+#endif
   }
+  record(T - 1, row_sel(g, s3, s4, s5, s6));
+#ifdef MPPI_STAMPS
+  if (blockIdx.x == 0 && w == 0 && lane == 0)
+    for (int i = 0; i < 6; i++) g_multi_stamps[i] = ma[i];
+#endif
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
@@ -424,3 +475,10 @@ hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, 
 }
 
 }  // namespace mppi
+
+#ifdef MPPI_STAMPS
+extern "C" int mppi_debug_read_multi_stamps(unsigned long long *out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mppi::g_multi_stamps), sizeof(unsigned long long) * 8);
+}
+#endif
