@@ -276,9 +276,6 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == W + 1);
   while (lds_peek(a_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   float b1_next = sh.ctl_b1[0][lane];
-  // pinned: the wait for this LDS read sits here, not at the first use of b1 inside the loop, where it would also
-  // wait, every step, for the state record stored just before it (rollout_multi.hip, multi_dynamics)
-  asm volatile("" : "+v"(b1_next));
   int cd = 0;  // last value seen of the cost wave's consumption counter
   // Two forms of the per-step look at the control wave's and the cost wave's progress.  Classic: read with
   // every poll of the swap (one batch of five LDS reads per poll).  Slim: the swap polls only the partner's

@@ -114,7 +114,6 @@ __device__ __forceinline__ void oct_dynamics(const RolloutArgs &a, OctShared<H, 
   // pinned: the wait for this LDS read sits here, not at the first use of b1 inside the loop, where it would also
   // wait, every step, for the state record stored just before it (rollout_multi.hip, multi_dynamics)
   asm volatile("" : "+v"(b1_next));
-  int cd = 0;  // last value seen of the cost wave's consumption counter
   int cp_v = 0, cd_v = 0;
   float b1n_v = 0.0f;
 
@@ -148,16 +147,16 @@ __device__ __forceinline__ void oct_dynamics(const RolloutArgs &a, OctShared<H, 
   // the running mean over the states BEFORE the updates of steps 1..T-1, mppi_controller.cu:160-177)
   for (int t = 0; t < T - 1; t++) {
     const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
-    const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
-    if (W == 0) {  // record for the cost wave: the state BEFORE this step's update
-      while (cd < t - kGRing + 1 && --budget > 0) cd = lds_peek(a_cd);
-      sh.rec[t & (kGRing - 1)][j][g] = b0;
-    }
+    const float b0 = row_sel(g, s3, s4, s5, s6);
     float act[MT * 4];
     int n = t * NSW;  // swaps published before this step
     {
+      // k-step 0 needs the state only: its MFMA goes first, wave 0's record store is issued in its shadow
       f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
       z = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[0], b0, z, 0, 0, 0);
+      // record for the cost wave: the state BEFORE this step's update (its ring slot was checked at the end of
+      // the previous step)
+      if (W == 0) sh.rec[t & (kGRing - 1)][j][g] = b0;
       z = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[1], b1, z, 0, 0, 0);
       f32x4 own;
 #pragma unroll
@@ -190,20 +189,22 @@ __device__ __forceinline__ void oct_dynamics(const RolloutArgs &a, OctShared<H, 
     s5 = fmaf(o[2] + BL[2], a.dt, s5);
     s6 = fmaf(o[3] + BL[3], a.dt, s6);
     __builtin_amdgcn_sched_barrier(0);
-    const int want = min(t + 2, T);
-    int cp = __builtin_amdgcn_readfirstlane(cp_v);
-    while (cp < want && --budget > 0) {  // never in steady state: the control wave runs ahead
+    // ONE scalar test per step (a second one at the top of wave 0's step costs the whole group ~100 cycles per
+    // step, tools/ub/dyn_step_ub.hip): step t+1 may start when the control wave has published it (never late in
+    // steady state: it runs ahead) and -- wave 0 -- the ring slot of its state record is free: that slot held
+    // step t+1 - kGRing, consumed once cost_done >= t+2 - kGRing
+    const int want = t + 2, want_cd = (W == 0) ? t + 2 - kGRing : -(1 << 30);
+    int cp = __builtin_amdgcn_readfirstlane(cp_v), cd = __builtin_amdgcn_readfirstlane(cd_v);
+    while (((cp < want) | (cd < want_cd)) && --budget > 0) {
       cp = __builtin_amdgcn_readfirstlane(*p_pub);
       b1n_v = p_b1[((t + 1) & (kGRing - 1)) * 64];
-      cd_v = *p_cd;
+      cd = __builtin_amdgcn_readfirstlane(*p_cd);
     }
     b1_next = b1n_v;
-    cd = __builtin_amdgcn_readfirstlane(cd_v);
   }
   if (W == 0) {  // the record of step T-1, released to the cost wave by the sequence word it waits for
     const int t = T - 1;
-    const float b0 = (g == 0) ? s3 : (g == 1) ? s4 : (g == 2) ? s5 : s6;
-    while (cd < t - kGRing + 1 && --budget > 0) cd = lds_peek(a_cd);
+    const float b0 = row_sel(g, s3, s4, s5, s6);
     sh.rec[t & (kGRing - 1)][j][g] = b0;
     lds_publish(a_myseq, t * NSW + 1);
   }
