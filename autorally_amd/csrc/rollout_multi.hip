@@ -302,10 +302,14 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
         }
         const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);  // s3 s4 s5 s6
         float spsi, cpsi;
+#ifdef MPPI_DIAG_NOPOSE  // diagnostic build: the hand-overs without the arithmetic (which rider paces the group?)
+        spsi = 0.0f; cpsi = 1.0f; tf = r0.x; tb = r0.y;
+#else
         sincos_fast(yaw, spsi, cpsi);
         const float st[3] = {x, y, yaw};
         if (affine) track_fetch<true>(a.cost, st, cpsi, spsi, tf, tb);
         else track_fetch<false>(a.cost, st, cpsi, spsi, tf, tb);
+#endif
         // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
         const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
         const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
@@ -345,6 +349,11 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
       const float2 tx = *reinterpret_cast<const float2 *>(&sh.tex[t & (kMRing - 1)][r][0]);      // front, back texel
       lds_publish(a_mydone, t + 1);  // executes after the three reads (the LDS runs a wave's instructions in order)
       const int rc = (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
+#ifdef MPPI_DIAG_NOCOST  // diagnostic build, as above
+      crash |= rc;
+      int crash_new = crash;
+      const float Jn = J + r0.y + r1.x + tx.x + (float)rt;
+#else
       CostTerms ct;
       if (ctrl) cost_terms_a<true>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
       else cost_terms_a<false>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
@@ -353,6 +362,7 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
       int crash_new = crash;
       const float c = cost_terms_b(a.cost, ct, tx.x, tx.y, crash_new);
       const float Jn = running_mean(J, c, t, rt);
+#endif
       J = (t > 0) ? Jn : J;
       crash = (t > 0) ? crash_new : crash;
     }
