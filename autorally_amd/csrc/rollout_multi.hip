@@ -84,6 +84,11 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
   const int T = a.T;
   float A[N::nA], Bi[N::nBias];
   load_weights<H, NHID>(a.wpack, lane, A, Bi);
+  // pinned: the waits for these loads sit here, not (one s_waitcnt vmcnt per first use) inside the T loop
+#pragma unroll
+  for (int i = 0; i < N::nA; i++) asm volatile("" : "+v"(A[i]));
+#pragma unroll
+  for (int i = 0; i < N::nBias; i++) asm volatile("" : "+v"(Bi[i]));
 
   const uint32_t a_mypub = lds_addr(&sh.dyn_pub[w][lane]);
   const uint32_t a_rec = lds_addr(&sh.rec[0][16 * w + j][g]);
