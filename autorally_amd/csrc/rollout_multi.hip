@@ -39,8 +39,10 @@ struct MultiShared {
   int dyn_pub[4][64];                      // steps published by dynamics wave w (written per lane, word 0 read)
   int cost_done[64];                       // steps consumed by the cost wave
   int ctl_pub[64];                         // steps published by the control wave
-  float tex[SPLIT ? kMRing : 1][SPLIT ? NR : 1][2];  // costmap texels (front, back) of step t (pose wave -> cost wave)
-  int pose_pub[64];                        // steps whose texels the pose wave has published
+  float pts[SPLIT ? kMRing : 1][SPLIT ? NR : 1][4];  // x, y, cos psi, sin psi of step t (pose wave -> fetch wave)
+  int pose_pub[64];                        // steps the pose wave has published
+  float tex[SPLIT ? kMRing : 1][SPLIT ? NR : 1][2];  // costmap texels (front, back) of step t (fetch wave -> cost wave)
+  int fetch_pub[64];                       // steps whose texels the fetch wave has published
   int fail[4];                             // word 0: raised by a wave whose waits ran out of budget
   int fin[8];                              // word r: wave r is through its T steps
 };
@@ -185,7 +187,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
 }
 
 template <int H, int NHID, int ND>
-__global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_multi_kernel(const RolloutArgs a)
+__global__ __launch_bounds__((ND + 2 + (ND == 4 ? 2 : 0)) * 64) void rollout_multi_kernel(const RolloutArgs a)
 {
   using SH = MultiShared<ND>;
   constexpr int NR = SH::NR;
@@ -198,7 +200,11 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
   // two-stage pipeline on two wavefronts that land on different SIMDs: the POSE wave (x, y, yaw kinematics,
   // sin/cos, the two costmap fetches) hands the texels to the COST wave (computeCost, running mean, crash flags)
   // through one more ring; each stage keeps up.
-  constexpr int kPose = SPLIT ? ND : -1, kCost = ND + (SPLIT ? 1 : 0), kCtl = kCost + 1;
+  // The pose work is cut once more, pose (sin/cos, kinematics) -> FETCH (look-ahead points, texel fetches), the
+  // fetch wave being the eighth wave, on the SIMD that had no rider: the f32 MFMA and the vector ALU share one
+  // pipeline, so a SIMD's step is max(chain, MFMA + VALU of everything on it), and with ~100 vector instructions
+  // per step (f64 range reduction included) the one pose wave pushed its SIMD past the chain of a 32-wide net.
+  constexpr int kPose = SPLIT ? ND : -1, kCost = ND + (SPLIT ? 1 : 0), kCtl = kCost + 1, kFetch = SPLIT ? kCtl + 1 : -1;
   __shared__ __attribute__((aligned(16))) SH sh;
   const int lane = threadIdx.x & 63;
   // made uniform for the compiler (budgets and waits stay scalar)
@@ -210,6 +216,7 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
     sh.cost_done[lane] = 0;
     sh.ctl_pub[lane] = 0;
     sh.pose_pub[lane] = 0;
+    sh.fetch_pub[lane] = 0;
     sh.fail[lane & 3] = 0;
     sh.fin[lane & 7] = 0;
   }
@@ -287,66 +294,95 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
     spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[kCtl]));
   } else if (SPLIT && role == kPose) {
     // -------------------------------- pose wave (ND = 4): one lane per rollout --------------------------------
-    // Software-pipelined by one step: the texels of step t are requested in iteration t and handed to the cost
-    // wave in iteration t+1.
+    // x, y, yaw of the rollouts: sin/cos and the kinematic update; hands (x, y, cos, sin) of every step on.
     const bool active = lane < NR;
     const int r = active ? lane : NR - 1;
     const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
-    const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+    const uint32_t a_fp = lds_addr(&sh.fetch_pub[0]);
     const uint32_t a_mypub = lds_addr(&sh.pose_pub[lane]);
-    const bool affine = a.cost.affine != 0;
     float x = a.state[0], y = a.state[1], yaw = a.state[2];
-    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kPose + 1), seen = 0, cdone = 0;
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kPose + 1), seen = 0, fdone = 0;
+    for (int t = 0; t < T; t++) {
+      while (seen < t + 1 && --budget > 0) {  // rec(t) is written before a dynamics wave publishes step t
+        seen = dyn_pub_min<ND>(a_dynw);
+        if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
+      }
+      const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);  // s3 s4 s5 s6
+      float spsi, cpsi;
+#ifdef MPPI_DIAG_NOPOSE  // diagnostic build: the hand-overs without the arithmetic (which rider paces the group?)
+      spsi = 0.0f; cpsi = 1.0f;
+#else
+      sincos_fast(yaw, spsi, cpsi);
+#endif
+      // the ring slot held step t - kMRing.  The fetch wave sets fetch_pub = t' in iteration t', after it has
+      // read the record of step t' (none in iteration 0): fetch_pub >= max(t - kMRing, 1) says that record was read
+      const int need = (t >= kMRing) ? max(t - kMRing, 1) : 0;
+      while (fdone < need && --budget > 0) fdone = lds_peek(a_fp);
+      *reinterpret_cast<float4 *>(&sh.pts[t & (kMRing - 1)][r][0]) = make_float4(x, y, cpsi, spsi);
+      lds_publish(a_mypub, t + 1);
+      // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
+      const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
+      const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
+      const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
+      x = fmaf(sd0, a.dt, x);
+      y = fmaf(sd1, a.dt, y);
+      yaw = fmaf(sd2, a.dt, yaw);
+    }
+    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[kPose]));
+  } else if (SPLIT && role == kFetch) {
+    // -------------------------------- fetch wave (ND = 4): one lane per rollout --------------------------------
+    // The two costmap texels of every step.  Software-pipelined by one step: the texels of step t are requested
+    // in iteration t and handed to the cost wave in iteration t+1.  (Giving this wave the stabilizing term of
+    // computeCost as well -- the cost wave is the heaviest rider left -- was measured: K=16384 87.0 -> 94.5 us.)
+    const bool active = lane < NR;
+    const int r = active ? lane : NR - 1;
+    const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
+    const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+    const uint32_t a_mypub = lds_addr(&sh.fetch_pub[lane]);
+    const bool affine = a.cost.affine != 0;
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kFetch + 1), seen = 0, cdone = 0;
     float tf_p = 0.0f, tb_p = 0.0f;
     for (int t = 0; t <= T; t++) {
       float tf = 0.0f, tb = 0.0f;
       if (t < T) {
-        while (seen < t + 1 && --budget > 0) {  // rec(t) is written before a dynamics wave publishes step t
-          seen = dyn_pub_min<ND>(a_dynw);
+        while (seen < t + 1 && --budget > 0) {
+          seen = lds_peek(a_pose);
           if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
         }
-        const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);  // s3 s4 s5 s6
-        float spsi, cpsi;
-#ifdef MPPI_DIAG_NOPOSE  // diagnostic build: the hand-overs without the arithmetic (which rider paces the group?)
-        spsi = 0.0f; cpsi = 1.0f; tf = r0.x; tb = r0.y;
+        const float4 p = *reinterpret_cast<const float4 *>(&sh.pts[t & (kMRing - 1)][r][0]);  // x, y, cos psi, sin psi
+#ifdef MPPI_DIAG_NOPOSE
+        tf = p.x; tb = p.y;
 #else
-        sincos_fast(yaw, spsi, cpsi);
-        const float st[3] = {x, y, yaw};
-        if (affine) track_fetch<true>(a.cost, st, cpsi, spsi, tf, tb);
-        else track_fetch<false>(a.cost, st, cpsi, spsi, tf, tb);
+        const float st[3] = {p.x, p.y, 0.0f};
+        if (affine) track_fetch<true>(a.cost, st, p.z, p.w, tf, tb);
+        else track_fetch<false>(a.cost, st, p.z, p.w, tf, tb);
 #endif
-        // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
-        const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
-        const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
-        const float sd2 = a.negate_yaw_der ? -r0.w : r0.w;
-        x = fmaf(sd0, a.dt, x);
-        y = fmaf(sd1, a.dt, y);
-        yaw = fmaf(sd2, a.dt, yaw);
       }
       if (t > 0) {
         // the texels of step t-1; their ring slot held step t-1-kMRing, which the cost wave must have consumed
         while (cdone < t - kMRing && --budget > 0) cdone = lds_peek(a_cd);
         *reinterpret_cast<float2 *>(&sh.tex[(t - 1) & (kMRing - 1)][r][0]) = make_float2(tf_p, tb_p);
-        lds_publish(a_mypub, t);  // steps < t are out
+        lds_publish(a_mypub, t);  // steps < t are out (and the record of step t has been read)
       }
       tf_p = tf; tb_p = tb;
     }
-    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[kPose]));
+    spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[kFetch]));
   } else if (SPLIT) {
     // -------------------------------- cost wave (ND = 4): one lane per rollout --------------------------------
     const bool active = lane < NR;
     const int r = active ? lane : NR - 1;
     const int k = blockIdx.x * NR + r;
-    const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
+    const uint32_t a_fetch = lds_addr(&sh.fetch_pub[0]);
     const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
     const bool ctrl = a.cost.need_control_cost != 0;
     int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kCost + 1), seen = 0;
     float J = 0.0f;
     for (int t = 0; t < T; t++) {
       const double rt = a.inv_t[t];
-      // the pose wave publishes the texels of step t after it has read rec(t): the records of step t are there
+      // the fetch wave publishes the texels of step t after the pose wave has read rec(t): the records of step t
+      // are there
       while (seen < t + 1 && --budget > 0) {
-        seen = lds_peek(a_pose);
+        seen = lds_peek(a_fetch);
         if (seen < t + 1) __builtin_amdgcn_s_sleep(1);
       }
       const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kMRing - 1)][r][0]);      // s3 s4 s5 s6
@@ -373,14 +409,12 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
     }
     // a hand-over that never arrived, in ANY wave of the group: poison, do not hang (mppi_device.hpp)
     {
-      // lanes 0..ND-1: the dynamics waves' finished words, lane ND: the pose wave's, the rest: the control wave's
-      const uint32_t a_fin = lds_addr(&sh.fin[(lane <= ND) ? lane : kCtl]);
+      // lane r < 8 looks at the finished word of wave r (the cost wave's own counts as set)
+      const uint32_t a_fin = lds_addr(&sh.fin[lane & 7]);
       for (;;) {
-        const int v = lds_peek_lanes(a_fin);
-        int all = __builtin_amdgcn_readlane(v, ND) & __builtin_amdgcn_readlane(v, ND + 1);
-#pragma unroll
-        for (int w = 0; w < ND; w++) all &= __builtin_amdgcn_readlane(v, w);
-        if (all != 0 || --budget <= 0) break;
+        const int v = ((lane & 7) == kCost) ? 1 : lds_peek_lanes(a_fin);
+        const bool all = __builtin_amdgcn_ballot_w64(v != 0) == ~0ull;
+        if (all || --budget <= 0) break;
         __builtin_amdgcn_s_sleep(1);
       }
       if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
@@ -466,7 +500,7 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 1 : 0)) * 64) void rollout_mul
 template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(7 * 64), 0, stream, a);
+  if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
   else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
   else if (nd == 1) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
   else return hipErrorInvalidValue;

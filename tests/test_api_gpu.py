@@ -268,7 +268,7 @@ def test_control_ticks_equals_the_call_by_call_loop():
 
 
 @pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
-                                         ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7),
+                                         ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7), ("multi4", 8),
                                          ("multi2", 2), ("multi2", 3), ("multi2", 4),
                                          ("oct", 1), ("oct", 2), ("oct", 3), ("oct", 4), ("oct", 5), ("oct", 6), ("oct", 7),
                                          ("oct", 8)])
@@ -289,7 +289,7 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
     sol = capi.Solver(cfg)
     if family == "bf2":
         sol.set_rollout_variant("quad")  # dynamics + cost wave; "bf": + control wave (the automatic choice)
-    elif family != "bf":  # multi form: roles 1..ND = dynamics waves, then [pose wave (ND = 4),] cost wave, control wave;
+    elif family != "bf":  # multi form: roles 1..ND = dynamics waves, then [pose wave (ND = 4),] cost wave, control wave[, fetch wave (ND = 4)];
         # oct form: 1..4 dynamics, 5 pose, 6 cost, 7 control, 8 noise wave
         sol.set_rollout_variant(family if family.startswith(("multi", "oct")) else "quad")
     sol.compute_control(cfg["start_state"])          # healthy
