@@ -55,14 +55,18 @@ SYMBOLS = [
     "mppi_destroy", "mppi_set_nn_params", "mppi_update_model", "mppi_set_control_limits",
     "mppi_set_costmap", "mppi_set_costmap_transform", "mppi_set_costmap_channel", "mppi_set_cost_params", "mppi_reset_controls",
     "mppi_set_control_seq", "mppi_get_control_seq", "mppi_set_control_hist", "mppi_get_control_hist",
-    "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
-    "mppi_compute_control", "mppi_control_ticks", "mppi_compute_control_async", "mppi_synchronize", "mppi_get_results",
+    "mppi_savitsky_golay", "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
+    "mppi_compute_control", "mppi_control_ticks", "mppi_compute_control_async", "mppi_synchronize",
+    "mppi_compute_control_batch_async", "mppi_compute_control_batch", "mppi_control_ticks_batch", "mppi_get_results",
     "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
     "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_debug_cost_raster", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
     "mppi_debug_inject_handover_fault",
 ]
+
+ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
+                "mppi_compute_control_batch", "mppi_compute_control_batch_async", "mppi_control_ticks_batch")
 
 _lib = None
 
@@ -127,11 +131,17 @@ def lib():
         L.mppi_rollout_variant.argtypes = [hp]
         L.mppi_set_rollout_variant.argtypes = [hp, C.c_char_p]
         L.mppi_debug_dynamics.argtypes = [hp, C.c_int, fp, fp, fp]
-        if hasattr(L, "mppi_debug_inject_handover_fault") or not os.environ.get("MPPI_LIB_PATH"):
-            # (an older library given through MPPI_LIB_PATH for a kernel A/B may lack this test hook)
+        # symbols added with ABI version 2 (include/mppi_hip.h): an older library (kernel A/B through
+        # MPPI_LIB_PATH) reports version 1 and lacks them
+        v2 = L.mppi_abi_version() >= 2
+        if v2:
             L.mppi_debug_inject_handover_fault.argtypes = [hp, C.c_int, C.c_int]
-        for s in SYMBOLS:  # every declared symbol must be there (except in an older A/B library)
-            if s != "mppi_debug_inject_handover_fault" or not os.environ.get("MPPI_LIB_PATH"):
+            L.mppi_savitsky_golay.argtypes = [hp]
+            L.mppi_compute_control_batch_async.argtypes = [C.POINTER(hp), fp, C.c_int]
+            L.mppi_compute_control_batch.argtypes = [C.POINTER(hp), fp, C.c_int]
+            L.mppi_control_ticks_batch.argtypes = [C.POINTER(hp), fp, C.c_int, C.c_int, C.c_int]
+        for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
+            if v2 or s not in ABI2_SYMBOLS:
                 getattr(L, s)
         _lib = L
     return _lib
@@ -250,6 +260,9 @@ class Solver:
         h = np.zeros(4, dtype=np.float32)
         self._ck(self.L.mppi_get_control_hist(self.h, _fp(h)))
         return h
+
+    def savitsky_golay(self):
+        self._ck(self.L.mppi_savitsky_golay(self.h))
 
     def slide_control_seq(self, stride):
         self._ck(self.L.mppi_slide_control_seq(self.h, int(stride)))
@@ -379,3 +392,28 @@ class Solver:
 
     def set_rollout_variant(self, name):
         self._ck(self.L.mppi_set_rollout_variant(self.h, name.encode()))
+
+
+def compute_control_batch(solvers, states, blocking=True):
+    """mppi_compute_control_batch[_async]: the solves of several Solver objects enqueued together (one launch of
+    the quad kernel + one of the tail kernel where the library can batch them)."""
+    n = len(solvers)
+    hs = (C.c_void_p * n)(*[s.h for s in solvers])
+    st = np.ascontiguousarray(np.stack([_f32(x, (7,)) for x in states]), dtype=np.float32)
+    L = solvers[0].L
+    fn = L.mppi_compute_control_batch if blocking else L.mppi_compute_control_batch_async
+    rc = fn(hs, _fp(st), n)
+    if rc != OK:
+        msgs = [s.L.mppi_last_error(s.h).decode() for s in solvers]
+        raise MppiError(rc, "; ".join(m for m in msgs if m))
+
+
+def control_ticks_batch(solvers, states, n_ticks, stride=1):
+    """mppi_control_ticks_batch: n_ticks x (batched solve + slide of every controller) inside one library call."""
+    n = len(solvers)
+    hs = (C.c_void_p * n)(*[s.h for s in solvers])
+    st = np.ascontiguousarray(np.stack([_f32(x, (7,)) for x in states]), dtype=np.float32)
+    rc = solvers[0].L.mppi_control_ticks_batch(hs, _fp(st), n, int(n_ticks), int(stride))
+    if rc != OK:
+        raise MppiError(rc, "; ".join(s.L.mppi_last_error(s.h).decode() for s in solvers))
+

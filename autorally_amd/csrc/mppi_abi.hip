@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -87,6 +88,9 @@ struct mppi_handle {
   bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
   int num_simds = 1024;     // 4 per CU
   hipStream_t stream = nullptr;
+  // The stream the handle's most recent device work went to: its own, or the device's batch stream after a
+  // batched solve (mppi_compute_control_batch).  nullptr: nothing outstanding anywhere but on `stream`.
+  hipStream_t order_stream = nullptr;
   int n_slots = 1;  // explicit-noise slots in d_noise: one per iteration
   bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
   unsigned seq = 0;             // sequence number of the last enqueued solve (last word of every h_res entry)
@@ -168,6 +172,37 @@ int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess)
     hipError_t e__ = (call);                                             \
     if (e__ != hipSuccess) return fail((h), MPPI_ERR_HIP, #call, e__);   \
   } while (0)
+
+// Batched solves of several handles go to ONE stream per device, shared by all handles and never destroyed, so
+// that the instances' kernels are one launch and a handle never holds another handle's stream.
+std::mutex g_batch_mu;
+hipStream_t g_batch_stream[64] = {};
+hipStream_t batch_stream(int device)
+{
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_batch_mu);
+  if (!g_batch_stream[device] &&
+      hipStreamCreateWithFlags(&g_batch_stream[device], hipStreamNonBlocking) != hipSuccess)
+    g_batch_stream[device] = nullptr;
+  return g_batch_stream[device];
+}
+
+// Called by every entry point that enqueues on the handle's OWN stream or relies on a synchronise of that stream
+// having seen all of the handle's device work: if the handle's last work went to the batch stream, wait for it
+// (only on a batch -> single transition: setup calls, result vectors, a stand-alone solve after a batched one).
+int own_stream(mppi_handle *h)
+{
+  if (h->order_stream && h->order_stream != h->stream) HIPCHK(h, hipStreamSynchronize(h->order_stream));
+  h->order_stream = h->stream;
+  return MPPI_OK;
+}
+#define OWN(h)                      \
+  do {                              \
+    int rc__ = own_stream(h);       \
+    if (rc__) return rc__;          \
+  } while (0)
+// where small follow-up work (upload of U, the slide kernel) goes: behind the handle's latest work, wherever it is
+hipStream_t work_stream(const mppi_handle *h) { return h->order_stream ? h->order_stream : h->stream; }
 
 int compute_k99(int K)
 {
@@ -498,13 +533,13 @@ int prefetch_noise(mppi_handle *h)
   return MPPI_OK;
 }
 
-int upload_controls_if_dirty(mppi_handle *h)
+int upload_controls_if_dirty(mppi_handle *h, hipStream_t stream)
 {
   if (!h->u_dirty) return MPPI_OK;
   memcpy(h->h_in, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
   memcpy(h->h_in + 2 * h->T, h->hist.data(), sizeof(float) * 4);
   HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_in, sizeof(float) * (2 * (size_t)h->T + 4), hipMemcpyHostToDevice,
-                           h->stream));
+                           stream));
   h->u_dirty = false;
   return MPPI_OK;
 }
@@ -514,6 +549,37 @@ static double hp_acc[8] = {0}, hp_n = 0;
 static std::chrono::steady_clock::time_point hp_seen;
 #define HP(i, t0) hp_acc[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - (t0)).count()
 #endif
+
+// savitskyGolay (mppi_controller.cu:468-499) on the host, the same operations in the same order as the tail
+// kernel applies to the device copy (this file is compiled with -ffp-contract=off):
+// X = [hist0, hist1, U_0 .. U_{T-1}, U_{T-1}, U_{T-1}], U_i = sum_m f_m X_{i+m}.  Row t of the unsmoothed
+// sequence is (src[stride t], src[stride t + off1]); the result goes to h->U.
+void savgol_host(mppi_handle *h, const float *src, int stride, int off1)
+{
+  const int T = h->T;
+  std::vector<float> &X = h->sg_buf;
+  X.resize((size_t)(T + 4) * 2);
+  for (int j = 0; j < 4; j++) X[j] = h->hist[j];
+  for (int t = 0; t < T; t++) {
+    X[(t + 2) * 2 + 0] = src[stride * t + 0];
+    X[(t + 2) * 2 + 1] = src[stride * t + off1];
+  }
+  for (int r = T + 2; r < T + 4; r++)
+    for (int j = 0; j < 2; j++) X[r * 2 + j] = X[(T + 1) * 2 + j];
+  const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
+  for (int i = 0; i < 2 * T; i++) {
+    float acc = f0 * X[i];
+    float p = f1 * X[i + 2];
+    acc = acc + p;
+    p = f2 * X[i + 4];
+    acc = acc + p;
+    p = f1 * X[i + 6];
+    acc = acc + p;
+    p = f0 * X[i + 8];
+    acc = acc + p;
+    h->U[i] = acc;
+  }
+}
 
 // Waits for the pending solve: polls the sequence number the tail kernel publishes (system-scope
 // release) in the host-mapped result block; no stream synchronise on the fast path.
@@ -536,7 +602,7 @@ int wait_pending(mppi_handle *h)
     if (next == n_entries) break;
     __builtin_ia32_pause();
     if ((++spins & 0xFFFFF) == 0) {
-      if (hipStreamQuery(h->stream) == hipSuccess && (__atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) != h->seq ||
+      if (hipStreamQuery(work_stream(h)) == hipSuccess && (__atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) != h->seq ||
                                                       __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq))
         return fail(h, MPPI_ERR_HIP, "solve finished without publishing its result block");
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
@@ -550,34 +616,7 @@ int wait_pending(mppi_handle *h)
   h->baseline = h->h_res[4 * h->T + 0];
   h->eta = h->h_res[4 * h->T + 2];
   h->traj_cost = h->h_res[4 * (h->T + 1) + 0];
-  {
-    // savitskyGolay (mppi_controller.cu:468-499) on the host, the same operations in the same order as
-    // the tail kernel applies to the device copy (this file is compiled with -ffp-contract=off):
-    // X = [hist0, hist1, U_0 .. U_{T-1}, U_{T-1}, U_{T-1}], U_i = sum_m f_m X_{i+m}
-    const int T = h->T;
-    std::vector<float> &X = h->sg_buf;
-    X.resize((size_t)(T + 4) * 2);
-    for (int j = 0; j < 4; j++) X[j] = h->hist[j];
-    for (int t = 0; t < T; t++) {
-      X[(t + 2) * 2 + 0] = h->h_res[4 * t + 0];
-      X[(t + 2) * 2 + 1] = h->h_res[4 * t + 2];
-    }
-    for (int r = T + 2; r < T + 4; r++)
-      for (int j = 0; j < 2; j++) X[r * 2 + j] = X[(T + 1) * 2 + j];
-    const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
-    for (int i = 0; i < 2 * T; i++) {
-      float acc = f0 * X[i];
-      float p = f1 * X[i + 2];
-      acc = acc + p;
-      p = f2 * X[i + 4];
-      acc = acc + p;
-      p = f1 * X[i + 6];
-      acc = acc + p;
-      p = f0 * X[i + 8];
-      acc = acc + p;
-      h->U[i] = acc;  // device U == host U again
-    }
-  }
+  savgol_host(h, h->h_res, 4, 2);  // rows [u0, seq, u1, seq] of the result block
 #ifdef MPPI_HOSTPROF
   HP(4, hp_seen);
 #endif
@@ -608,6 +647,24 @@ int wait_pending(mppi_handle *h)
 
 int collect(mppi_handle *h) { return wait_pending(h); }
 
+// the tail kernel of the last iteration leaves [U | hist] slid by the optimization stride in the other buffer
+bool wants_slid_copy(const mppi_handle *h)
+{
+  return h->cfg.optimization_stride >= 1 && h->cfg.optimization_stride < h->T;
+}
+
+TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last)
+{
+  TailLaunch l;
+  l.costs = h->d_costs; l.V = V; l.U = h->d_in; l.hist = h->d_in + 2 * h->T; l.w = h->d_w; l.scal = h->d_scal;
+  l.res = h->d_res_map; l.counter = h->d_counter; l.part = h->d_part;
+  l.K = h->K; l.T = h->T; l.gamma = h->cfg.gamma; l.last_iter = last ? 1 : 0; l.seq = h->seq;
+  l.slid = (last && wants_slid_copy(h)) ? h->d_in_buf[1 - h->in_cur] : nullptr;
+  l.slide_stride = h->cfg.optimization_stride;
+  l.init0 = h->cfg.init_control[0]; l.init1 = h->cfg.init_control[1];
+  return l;
+}
+
 int enqueue_solve(mppi_handle *h, const float *state)
 {
 #ifdef MPPI_HOSTPROF
@@ -622,7 +679,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
   const int K = h->K, T = h->T, iters = h->cfg.num_iters;
   if (h->explicit_iters > 0 && h->explicit_iters != iters)
     return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
-  rc = upload_controls_if_dirty(h);
+  OWN(h);
+  rc = upload_controls_if_dirty(h, h->stream);
   if (rc) return rc;
   const bool timed = h->timing && (h->timing_count++ % (unsigned)h->timing_every) == 0;
   const bool explicit_noise = h->explicit_iters > 0;
@@ -667,12 +725,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
     if (prefetch) HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));  // the generator starts when this rollout ends
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
     const bool last = (it == iters - 1);
-    const int sstride = h->cfg.optimization_stride;
-    const bool want_slid = last && sstride >= 1 && sstride < T;
-    HIPCHK(h, launch_solve_tail(h->d_costs, noise, h->d_in, h->d_in + 2 * T, h->d_w, h->d_scal, h->d_res_map,
-                                h->d_counter, h->d_part, K, T, h->cfg.gamma, last ? 1 : 0, h->seq,
-                                want_slid ? h->d_in_buf[1 - h->in_cur] : nullptr, sstride,
-                                h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
+    const bool want_slid = last && wants_slid_copy(h);
+    HIPCHK(h, launch_solve_tail(tail_launch(h, noise, last), h->stream));
     if (last) h->slid_valid = want_slid;
     if (prefetch) {
       rc = prefetch_noise(h);
@@ -891,6 +945,7 @@ int mppi_destroy(mppi_handle *h)
 {
   if (!h) return MPPI_ERR_INVALID;
   (void)hipSetDevice(h->cfg.device);
+  if (h->order_stream && h->order_stream != h->stream) (void)hipStreamSynchronize(h->order_stream);
   if (h->gstream) (void)hipStreamSynchronize(h->gstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_all(h);
@@ -903,6 +958,7 @@ int mppi_set_bf_params(mppi_handle *h, const float *W, size_t n)
   if (!h->basis) return fail(h, MPPI_ERR_STATE, "handle was created with a network (n_layers != 0)");
   if (n != (size_t)(4 * kNumBfs)) return fail(h, MPPI_ERR_INVALID, "W size != 4 * 25");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->theta.assign(W, W + n);
   HIPCHK(h, hipMemcpy(h->d_theta, W, n * sizeof(float), hipMemcpyHostToDevice));
@@ -916,6 +972,7 @@ int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
   if (h->basis) return fail(h, MPPI_ERR_STATE, "handle was created for basis-function dynamics: use mppi_set_bf_params");
   if (n != (size_t)h->net.num_params) return fail(h, MPPI_ERR_INVALID, "theta size != NUM_PARAMS");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->theta.assign(theta, theta + n);
   HIPCHK(h, hipMemcpy(h->d_theta, theta, n * sizeof(float), hipMemcpyHostToDevice));
@@ -979,6 +1036,7 @@ int mppi_set_costmap(mppi_handle *h, int width, int height, const float *rgba, c
   if (width <= 0 || height <= 0 || (size_t)width * (size_t)height > ((size_t)1 << 30))
     return fail(h, MPPI_ERR_INVALID, "bad costmap size");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const size_t n = (size_t)width * height;
   h->map_rgba.assign(rgba, rgba + 4 * n);
@@ -1022,6 +1080,7 @@ int mppi_set_costmap_channel(mppi_handle *h, int channel, const float *data, siz
   for (size_t i = 0; i < n; i++) h->map_rgba[4 * i + channel] = data[i];
   if (channel == 0) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    OWN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->d_map, data, n * sizeof(float), hipMemcpyHostToDevice));
   }
@@ -1089,6 +1148,20 @@ int mppi_set_control_hist(mppi_handle *h, const float hist[4])
   return MPPI_OK;
 }
 
+int mppi_savitsky_golay(mppi_handle *h)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  if (h->pending) {
+    int rc = mppi_synchronize(h);
+    if (rc) return rc;
+  }
+  const std::vector<float> raw(h->U);
+  savgol_host(h, raw.data(), 2, 1);
+  h->u_dirty = true;  // the device copy follows with the next solve
+  h->slid_valid = false;
+  return MPPI_OK;
+}
+
 int mppi_get_control_hist(mppi_handle *h, float hist[4])
 {
   if (!h || !hist) return MPPI_ERR_INVALID;
@@ -1132,7 +1205,7 @@ int mppi_slide_control_seq(mppi_handle *h, int stride)
       h->d_in = h->d_in_buf[h->in_cur];
     } else {
       HIPCHK(h, hipSetDevice(h->cfg.device));
-      HIPCHK(h, launch_slide(h->d_in, T, stride, h->cfg.init_control[0], h->cfg.init_control[1], h->stream));
+      HIPCHK(h, launch_slide(h->d_in, T, stride, h->cfg.init_control[0], h->cfg.init_control[1], work_stream(h)));
     }
   }
   h->slid_valid = false;
@@ -1145,6 +1218,7 @@ int mppi_seed(mppi_handle *h, uint64_t seed, uint64_t offset)
   HIPCHK(h, hipSetDevice(h->cfg.device));
   int rc = mppi_synchronize(h);
   if (rc) return rc;
+  OWN(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipStreamSynchronize(h->gstream));
   h->prefetch_valid = false;  // draws of the old sequence
@@ -1164,6 +1238,7 @@ int mppi_set_noise(mppi_handle *h, const float *eps, size_t n)
     int rc = mppi_synchronize(h);
     if (rc) return rc;
   }
+  OWN(h);
   for (int it = 0; it < h->cfg.num_iters; it++) {
     HIPCHK(h, hipMemcpyAsync(h->d_stage, eps + (size_t)it * slot, slot * sizeof(float),
                              hipMemcpyHostToDevice, h->stream));
@@ -1182,6 +1257,7 @@ int mppi_generate_noise(mppi_handle *h, float *eps_out, size_t n)
   HIPCHK(h, hipSetDevice(h->cfg.device));
   int rc = mppi_synchronize(h);
   if (rc) return rc;
+  OWN(h);
   float *buf = nullptr;
   rc = acquire_noise(h, &buf);
   if (rc) return rc;
@@ -1212,6 +1288,115 @@ int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM])
   return mppi_synchronize(h);
 }
 
+int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states, int n)
+{
+  if (!hs || !states || n < 1) return MPPI_ERR_INVALID;
+  for (int i = 0; i < n; i++) {
+    if (!hs[i]) return MPPI_ERR_INVALID;
+    for (int q = 0; q < i; q++)
+      if (hs[q] == hs[i]) return fail(hs[i], MPPI_ERR_INVALID, "the same handle twice in one batch");
+  }
+  // One launch for all instances where the quad form serves them together (every wave of every group still gets a
+  // SIMD of its own: the sum of the groups fits the CUs); otherwise every solve on its own handle's stream, as
+  // n calls of mppi_compute_control_async would do.
+  mppi_handle *h0 = hs[0];
+  bool together = n >= 2 && n <= kMaxBatch;
+  int groups = 0;
+  for (int i = 0; i < n && together; i++) {
+    const mppi_handle *h = hs[i];
+    together = h->cfg.device == h0->cfg.device && !h->basis && use_mfma(h) && effective_block(h) == 512 &&
+               h->hidden == h0->hidden && h->n_hidden == h0->n_hidden && h->cfg.num_iters == h0->cfg.num_iters &&
+               h->K <= 4096 && !h->timing && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
+    groups += h->K / kRolloutsPerWave;
+  }
+  together = together && groups <= h0->num_simds / 4;
+  if (!together) {
+    for (int i = 0; i < n; i++) {
+      const int rc = mppi_compute_control_async(hs[i], states + (size_t)MPPI_STATE_DIM * i);
+      if (rc) return rc;
+    }
+    return MPPI_OK;
+  }
+  HIPCHK(h0, hipSetDevice(h0->cfg.device));
+  const hipStream_t S = batch_stream(h0->cfg.device);
+  if (!S) return fail(h0, MPPI_ERR_HIP, "no batch stream");
+  const int iters = h0->cfg.num_iters;
+  for (int i = 0; i < n; i++) {
+    mppi_handle *h = hs[i];
+    int rc = wait_pending(h);  // finish a previous asynchronous solve first
+    if (rc) return rc;
+    if (h->explicit_iters > 0 && h->explicit_iters != iters)
+      return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
+    if (h->order_stream != S) {  // first batched solve after work on the handle's own streams: let that finish
+      HIPCHK(h, hipStreamSynchronize(h->order_stream ? h->order_stream : h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->gstream));
+      h->order_stream = S;
+    }
+    rc = upload_controls_if_dirty(h, S);
+    if (rc) return rc;
+    h->seq++;
+  }
+  for (int it = 0; it < iters; it++) {
+    QuadBatchArgs qb;
+    TailLaunch tl[kMaxBatch];
+    qb.n = n;
+    qb.first[0] = 0;
+    const bool last = (it == iters - 1);
+    for (int i = 0; i < n; i++) {
+      mppi_handle *h = hs[i];
+      const bool explicit_noise = h->explicit_iters > 0;
+      // eps: the explicit buffer, else the control wavefront's own generator; the buffer receives the applied controls
+      float *noise = explicit_noise ? h->d_noise + (size_t)it * ((size_t)h->K * h->T * 2) : h->d_gen[h->gen_cur];
+      h->v_buf = noise;
+      RolloutArgs &a = qb.inst[i];
+      fill_rollout_args(h, states + (size_t)MPPI_STATE_DIM * i, noise, a);
+      if (!explicit_noise) {
+        a.inline_noise = 1;
+        a.rng_in = h->d_rng[h->rng_cur];
+        a.rng_out = h->d_rng[1 - h->rng_cur];
+        h->rng_cur = 1 - h->rng_cur;
+      }
+      qb.first[i + 1] = qb.first[i] + h->K / kRolloutsPerWave;
+      tl[i] = tail_launch(h, noise, last);
+      if (last) h->slid_valid = wants_slid_copy(h);
+    }
+    for (int i = n; i < kMaxBatch; i++) {
+      qb.inst[i] = qb.inst[0];
+      qb.first[i + 1] = qb.first[n];
+    }
+    hipError_t e = launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
+    if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
+    if (e != hipSuccess) return fail(h0, MPPI_ERR_HIP, "batched launch", e);
+  }
+  for (int i = 0; i < n; i++) {
+    hs[i]->explicit_iters = 0;
+    hs[i]->pending = true;
+    hs[i]->pending_timed = false;
+  }
+  return MPPI_OK;
+}
+
+int mppi_compute_control_batch(mppi_handle *const *hs, const float *states, int n)
+{
+  int rc = mppi_compute_control_batch_async(hs, states, n);
+  for (int i = 0; i < n && rc == MPPI_OK; i++) rc = mppi_synchronize(hs[i]);
+  return rc;
+}
+
+int mppi_control_ticks_batch(mppi_handle *const *hs, const float *states, int n, int n_ticks, int stride)
+{
+  if (!hs || !states || n < 1 || n_ticks < 0 || stride < 0) return MPPI_ERR_INVALID;
+  for (int t = 0; t < n_ticks; t++) {
+    int rc = mppi_compute_control_batch(hs, states, n);
+    if (rc) return rc;
+    for (int i = 0; i < n && stride > 0; i++) {
+      rc = mppi_slide_control_seq(hs[i], stride);
+      if (rc) return rc;
+    }
+  }
+  return MPPI_OK;
+}
+
 int mppi_control_ticks(mppi_handle *h, const float state[MPPI_STATE_DIM], int n_ticks, int stride)
 {
   if (!h || n_ticks < 0 || stride < 0) return MPPI_ERR_INVALID;
@@ -1235,6 +1420,7 @@ int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, f
   if (traj_cost) *traj_cost = h->traj_cost;
   if (costs || weights) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    OWN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   if (costs) HIPCHK(h, hipMemcpy(costs, h->d_costs, sizeof(float) * h->K, hipMemcpyDeviceToHost));
@@ -1250,6 +1436,7 @@ int mppi_get_applied_controls(mppi_handle *h, float *V, size_t n)
   int rc = mppi_synchronize(h);
   if (rc) return rc;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
   HIPCHK(h, launch_tk_to_kt(h->v_buf, h->d_stage, h->K, h->T, h->stream));
   HIPCHK(h, hipMemcpyAsync(V, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1264,7 +1451,8 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   HIPCHK(h, hipSetDevice(h->cfg.device));
   rc = mppi_synchronize(h);
   if (rc) return rc;
-  rc = upload_controls_if_dirty(h);
+  OWN(h);
+  rc = upload_controls_if_dirty(h, h->stream);
   if (rc) return rc;
   const bool explicit_noise = h->explicit_iters > 0;
   const bool inline_noise = !explicit_noise && !h->prefetch_valid && has_noise_wave(h);
@@ -1436,6 +1624,7 @@ int mppi_debug_cost_raster(mppi_handle *h, float x, float y, float heading, int 
   if (W > 8192 || H > 8192 || n != W * H) return fail(h, MPPI_ERR_INVALID, "n != (width_m*ppm) * (height_m*ppm)");
   if (!h->have_map) return fail(h, MPPI_ERR_STATE, "mppi_set_costmap has not been called");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
   float *d = nullptr;
   HIPCHK(h, hipMalloc(&d, n * sizeof(float)));
   CostArgs c;
@@ -1549,6 +1738,7 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
   if (!h || n <= 0 || !states || !controls || !ders) return MPPI_ERR_INVALID;
   if (!h->have_nn) return fail(h, MPPI_ERR_STATE, "mppi_set_nn_params has not been called");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
   float *d_s = nullptr, *d_u = nullptr, *d_o = nullptr;
   HIPCHK(h, hipMalloc(&d_s, sizeof(float) * 7 * n));
   HIPCHK(h, hipMalloc(&d_u, sizeof(float) * 2 * n));

@@ -56,6 +56,15 @@ struct RolloutArgs {
   CostArgs cost;
 };
 
+// Argument block of the batched quad kernel (rollout_quad_batch_kernel): instance i owns the workgroups
+// [first[i], first[i + 1]).
+constexpr int kMaxBatch = 4;
+struct QuadBatchArgs {
+  int n;
+  int first[kMaxBatch + 1];
+  RolloutArgs inst[kMaxBatch];
+};
+
 // Thresholds for the reference's float-vs-double-literal comparisons, as floats:
 //   (double)x > 1.57   <=>  x >= kRollCrash   (costs.cu:302)
 //   (double)x > 0.001  <=>  x >= kMinSpeed    (costs.cu:340)

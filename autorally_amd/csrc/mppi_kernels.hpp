@@ -26,6 +26,8 @@ bool mfma_variant_supported(int hidden, int n_hidden);
 int mfma_pack_floats_per_lane(int hidden, int n_hidden);
 hipError_t launch_rollout_mfma(int hidden, int n_hidden, const RolloutArgs &a, int block_threads,
                                hipStream_t stream);
+// several instances in one launch of the quad form (every instance: 6 -> hidden x n_hidden -> 4)
+hipError_t launch_rollout_quad_batch(int hidden, int n_hidden, const QuadBatchArgs &b, hipStream_t stream);
 hipError_t launch_dynamics_mfma(int hidden, int n_hidden, const float *wpack, const float *states,
                                 const float *controls, float *ders, int n, int negate_yaw_der,
                                 hipStream_t stream);
@@ -61,10 +63,18 @@ hipError_t launch_dynamics_bf(const float *W, const float *states, const float *
                               hipStream_t stream);
 
 // solve_kernels.hip
-hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
-                             float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,
-                             int last_iter, unsigned seq, float *slid, int slide_stride, float init0,
-                             float init1, hipStream_t stream);
+// everything of one solve iteration after the rollout (solve_tail_kernel; preceded by weights_kernel for K > 4096)
+struct TailLaunch {
+  const float *costs, *V, *hist;
+  float *U, *w, *scal, *res, *part, *slid;
+  unsigned *counter;
+  int K, T, last_iter, slide_stride;
+  unsigned seq;
+  float gamma, init0, init1;
+};
+hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream);
+// the tails of n <= kMaxBatch instances (K <= 4096 each) in one launch
+hipError_t launch_solve_tail_batch(const TailLaunch *l, int n, hipStream_t stream);
 hipError_t launch_debug_cost(const CostArgs &c, float x, float y, float heading, int width_m, int height_m,
                              int ppm, float *out, hipStream_t stream);
 hipError_t launch_slide(float *in, int T, int stride, float init0, float init1, hipStream_t stream);

@@ -453,16 +453,18 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[W]));
 }
 
+// One group of 16 rollouts of problem instance `a`: the body of the quad kernel.  `group` is the group's index
+// INSIDE its instance (the stand-alone kernel: blockIdx.x; the batched kernel below: blockIdx.x minus the
+// instance's first workgroup).
 template <int H, int NHID, bool AFFINE, bool CTRL>
-__global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
+__device__ __forceinline__ void quad_group(const RolloutArgs &a, QuadShared<H, NHID> &sh, const int group)
 {
   static_assert((H / 16) % 2 == 0 && NHID >= 2, "needs two M tiles and a hidden layer to split");
   constexpr int NSW = NHID - 1;
-  __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;  // wave-uniform
   const int j = lane & 15;
-  const int k = blockIdx.x * kRolloutsPerWave + j;
+  const int k = group * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
   // sequence words start at 0, the constant rows of the layer-0 operand at 0; the only barrier
   if (role == 0) { sh.xseq[0][lane] = 0; sh.xseq[1][lane] = 0; sh.cost_done[lane] = 0; sh.ctl_pub[lane] = 0; sh.fail[lane & 3] = 0; sh.fin[lane & 3] = 0; }
@@ -606,6 +608,29 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
   }
 }
 
+template <int H, int NHID, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
+{
+  __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
+  quad_group<H, NHID, AFFINE, CTRL>(a, sh, (int)blockIdx.x);
+}
+
+// Several independent MPPI instances in ONE launch (mppi_compute_control_batch: the actual-state and the
+// predicted-state controller of runControlLoop, run_control_loop.cuh:218-219, K = 1920 each -- 120 + 120 groups on
+// 256 CUs): workgroups [first[i], first[i+1]) run instance i with that instance's own argument block (state, U,
+// noise / generator states, costmap, cost parameters).  The per-group code is quad_group, so every instance's
+// results equal a stand-alone launch bit for bit.
+template <int H, int NHID, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatchArgs b)
+{
+  __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
+  int i = 0;  // wave-uniform
+#pragma unroll
+  for (int q = 1; q < kMaxBatch; q++)
+    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
+  quad_group<H, NHID, AFFINE, CTRL>(b.inst[i], sh, (int)blockIdx.x - b.first[i]);
+}
+
 // Debug/test entry: state derivative of n independent (state, control) pairs through the
 // same device functions as the rollout (used to check the golden vectors on the GPU).
 template <int H, int NHID>
@@ -658,6 +683,34 @@ static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipS
   else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_mfma_kernel<H, NHID, false, false>), grid, block, 0, stream, a);
   else MPPI_LAUNCH_ROLLOUT((rollout_mfma_kernel<H, NHID, false, true>), grid, block, 0, stream, a);
   return hipGetLastError();
+}
+
+template <int H, int NHID>
+static hipError_t launch_quad_batch_t(const QuadBatchArgs &b, bool affine, bool ctrl, hipStream_t stream)
+{
+  const dim3 grid(b.first[b.n]), block(256);
+  if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, false>), grid, block, 0, stream, b);
+  else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, true>), grid, block, 0, stream, b);
+  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, false>), grid, block, 0, stream, b);
+  else hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, true>), grid, block, 0, stream, b);
+  return hipGetLastError();
+}
+
+// The kernel instance is chosen for the whole batch: the general forms are exact supersets (u / w with w == 1 is
+// u, the control-cost term with zero coefficients is +0), so an instance's bits do not depend on its partners.
+hipError_t launch_rollout_quad_batch(int hidden, int n_hidden, const QuadBatchArgs &b, hipStream_t stream)
+{
+  if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;
+  bool affine = true, ctrl = false;
+  for (int i = 0; i < b.n; i++) {
+    affine = affine && b.inst[i].cost.affine != 0;
+    ctrl = ctrl || b.inst[i].cost.need_control_cost != 0;
+  }
+  if (hidden == 32 && n_hidden == 2) return launch_quad_batch_t<32, 2>(b, affine, ctrl, stream);
+  if (hidden == 64 && n_hidden == 2) return launch_quad_batch_t<64, 2>(b, affine, ctrl, stream);
+  if (hidden == 32 && n_hidden == 4) return launch_quad_batch_t<32, 4>(b, affine, ctrl, stream);
+  if (hidden == 64 && n_hidden == 4) return launch_quad_batch_t<64, 4>(b, affine, ctrl, stream);
+  return hipErrorInvalidValue;
 }
 
 bool mfma_variant_supported(int hidden, int n_hidden)

@@ -2,6 +2,7 @@
 // the rollout: baseline/normExp/normaliser, weightedReductionKernel, savitskyGolay, plus the
 // [K][T][2] <-> [T][K][2] layout transposes used at the ABI boundary.
 #include "mppi_device.hpp"
+#include "mppi_kernels.hpp"
 
 namespace mppi {
 
@@ -211,7 +212,9 @@ struct TailArgs {
   unsigned seq;         // sequence number published in res[3] once everything else is visible
 };
 
-__global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs a)
+// body of solve_tail_kernel for workgroup `block` of the instance `a` (the batched kernel passes blockIdx.x minus
+// the instance's first workgroup)
+__device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int block)
 {
   // chunk rows padded by 2 floats per 64-rollout group: lanes of one wave (m varies) hit
   // distinct banks when they walk their chains in lock step.
@@ -225,9 +228,9 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   const int tid = threadIdx.x;
   const int K = a.K, T = a.T;
   const int C = (K + kRedChunk - 1) / kRedChunk;  // workgroups per row
-  const bool extra = ((int)blockIdx.x == T * C);  // (single-launch form) publishes w[], beta, eta, trajectory cost
-  const int t = extra ? 0 : (int)blockIdx.x / C;
-  const int base = extra ? 0 : ((int)blockIdx.x % C) * kRedChunk;
+  const bool extra = (block == T * C);  // (single-launch form) publishes w[], beta, eta, trajectory cost
+  const int t = extra ? 0 : block / C;
+  const int base = extra ? 0 : (block % C) * kRedChunk;
   const int n = min(kRedChunk, K - base);  // rollouts of this workgroup's chunk (multiple of 64)
 
   // The chunk of row t is requested NOW, before anything else, so that its HBM latency overlaps the
@@ -450,6 +453,27 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
   }
 }
 
+__global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs a)
+{
+  solve_tail_body(a, (int)blockIdx.x);
+}
+
+// The tails of several instances (K <= kRedChunk each: T + 1 workgroups per instance) in one launch, behind
+// rollout_quad_batch_kernel: workgroups [first[i], first[i + 1]) are instance i's.
+struct TailBatchArgs {
+  int n;
+  int first[kMaxBatch + 1];
+  TailArgs inst[kMaxBatch];
+};
+__global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const TailBatchArgs b)
+{
+  int i = 0;  // workgroup-uniform
+#pragma unroll
+  for (int q = 1; q < kMaxBatch; q++)
+    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
+  solve_tail_body(b.inst[i], (int)blockIdx.x - b.first[i]);
+}
+
 // slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
 // solve -> slide -> solve loop never re-uploads the sequence.  One workgroup; mirrors the host code.
 __global__ void slide_kernel(float *__restrict__ in, int T, int stride, float init0, float init1)
@@ -551,23 +575,53 @@ hipError_t launch_debug_cost(const CostArgs &c, float x, float y, float heading,
 }
 
 // ---- launchers ----
-hipError_t launch_solve_tail(const float *costs, const float *V, float *U, const float *hist, float *w,
-                             float *scal, float *res, unsigned *counter, float *part, int K, int T, float gamma,
-                             int last_iter, unsigned seq, float *slid, int slide_stride, float init0,
-                             float init1, hipStream_t stream)
+static size_t tail_dyn_bytes(int K, int T)
+{
+  return ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2 + (size_t)T * 2) * sizeof(float);
+}
+
+static TailArgs fill_tail(const TailLaunch &l)
 {
   TailArgs a;
-  a.slid = slid; a.slide_stride = slide_stride; a.init0 = init0; a.init1 = init1;
-  a.costs = costs; a.V = V; a.U = U; a.hist = hist; a.w = w; a.scal = scal; a.res = res; a.counter = counter; a.part = part;
-  a.K = K; a.T = T; a.gamma = gamma; a.last_iter = last_iter; a.seq = seq;
-  const size_t dyn = ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2 + (size_t)T * 2) * sizeof(float);
+  a.slid = l.slid; a.slide_stride = l.slide_stride; a.init0 = l.init0; a.init1 = l.init1;
+  a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res;
+  a.counter = l.counter; a.part = l.part;
+  a.K = l.K; a.T = l.T; a.gamma = l.gamma; a.last_iter = l.last_iter; a.seq = l.seq;
+  a.pre = (l.K > kRedChunk) ? 1 : 0;
+  return a;
+}
+
+hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
+{
+  const TailArgs a = fill_tail(l);
+  const int K = l.K, T = l.T;
   const int C = (K + kRedChunk - 1) / kRedChunk;
-  if (C > 1 && part == nullptr) return hipErrorInvalidValue;
-  a.pre = (C > 1) ? 1 : 0;
+  if (C > 1 && l.part == nullptr) return hipErrorInvalidValue;
   if (a.pre)
-    hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, costs, w, scal, K, gamma,
-                       last_iter ? res : nullptr, T, seq);
-  hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), dyn, stream, a);
+    hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, l.costs, l.w, l.scal, K, l.gamma,
+                       l.last_iter ? l.res : nullptr, T, l.seq);
+  hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_solve_tail_batch(const TailLaunch *l, int n, hipStream_t stream)
+{
+  if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
+  TailBatchArgs b;
+  b.n = n;
+  b.first[0] = 0;
+  size_t dyn = 0;
+  for (int i = 0; i < n; i++) {
+    if (l[i].K > kRedChunk) return hipErrorInvalidValue;  // one workgroup per row only
+    b.inst[i] = fill_tail(l[i]);
+    b.first[i + 1] = b.first[i] + l[i].T + 1;
+    dyn = tail_dyn_bytes(l[i].K, l[i].T) > dyn ? tail_dyn_bytes(l[i].K, l[i].T) : dyn;
+  }
+  for (int i = n; i < kMaxBatch; i++) {
+    b.inst[i] = b.inst[0];
+    b.first[i + 1] = b.first[n];
+  }
+  hipLaunchKernelGGL(solve_tail_batch_kernel, dim3(b.first[n]), dim3(kTailThreads), dyn, stream, b);
   return hipGetLastError();
 }
 

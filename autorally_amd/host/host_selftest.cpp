@@ -54,6 +54,7 @@ struct FakeController {
       for (int j = 0; j < 7; j++) state_seq[t * 7 + j] = s[j] + (j == 0 ? 0.1f * t : 0.0f);
   }
   void startControl() { float s[7]; for (int i = 0; i < 7; i++) s[i] = state_seq[i]; startControl(s); }
+  static void startControlPair(FakeController *a, const float *s, FakeController *p) { a->startControl(s); p->startControl(); }
   void finishControl() {}
   float getComputedTrajectoryCost() const { return cost; }
   std::vector<float> getControlSeq() const { return control_seq; }
@@ -213,6 +214,26 @@ int main(int argc, char **argv)
     for (int i = 0; i < 7; i++) REQUIRE(model.state_der_[i] == 0.0f);
     model.computeKinematics(x); model.computeDynamics(x, us);
     for (int i = 0; i < 7; i++) REQUIRE(xs[i] == fmaf(model.state_der_[i], 0.02f, x[i]));
+  }
+  // --- MPPICosts: the non-caller public names (costs.cuh:170,186-191) and the list of bound controller handles ---
+  {
+    MPPICosts c(4, 4);
+    c.getCostInfo();          // empty in the reference too (costs.cu:240-242)
+    c.debugDisplayInit();     // 10 m x 10 m at 50 px/m (costs.cu:255-258)
+    c.debugDisplayInit(6, 4, 20);
+    bool threw = false;
+    try { c.getDebugDisplay(0.0f, 0.0f, 0.0f); } catch (const std::runtime_error &) { threw = true; }
+    REQUIRE(threw);  // no controller uses this costs object yet
+    mppi_handle *h1 = reinterpret_cast<mppi_handle *>(0x10), *h2 = reinterpret_cast<mppi_handle *>(0x20);
+    c.bindHandle(h1);  // actual-state controller
+    c.bindHandle(h2);  // predicted-state controller
+    REQUIRE(c.boundHandles() == 2);
+    c.unbindHandle(h2);  // destroying the last-constructed controller leaves the other one bound
+    REQUIRE(c.boundHandles() == 1);
+    c.unbindHandle(h2);
+    REQUIRE(c.boundHandles() == 1);
+    c.unbindHandle(h1);
+    REQUIRE(c.boundHandles() == 0);
   }
   // --- MPPICosts::loadTrackData (costs.cu:190-232) on a file produced by the reference's writer ---
   if (argc > 4) {

@@ -409,21 +409,48 @@ class MPPICosts {
   void updateCostmap(const std::vector<int> &, const std::vector<float> &) {}
   void updateObstacles(const std::vector<int> &, const std::vector<float> &) {}
 
-  // getDebugDisplay(x, y, heading), costs.cu:272-285 -> debugCostKernel (debug_kernels.cuh:39-88), without the
-  // cv::Mat: the raster [height_m*ppm][width_m*ppm], debugDisplayInit's default window 10 m x 10 m at 50 px/m.
-  // The costs object owns no device state here; the raster runs on the handle of a controller that uses
-  // this object (the last one constructed binds itself), with the current params_ pushed first.
-  std::vector<float> getDebugDisplay(float x, float y, float heading, int width_m = 10, int height_m = 10, int ppm = 50)
+  // getCostInfo(), costs.cuh:170 / costs.cu:240-242: an empty body in the reference ("TODO: Return some useful
+  // information about the cost"); kept so that code calling it compiles
+  void getCostInfo() {}
+  // debugDisplayInit() / debugDisplayInit(width_m, height_m, ppm), costs.cuh:186-191, costs.cu:255-269: the window
+  // of the debug raster (the reference also allocates its buffers here; the handle allocates per call)
+  void debugDisplayInit() { debugDisplayInit(10, 10, 50); }
+  void debugDisplayInit(int width_m, int height_m, int ppm)
   {
-    if (!bound_) throw std::runtime_error("MPPICosts::getDebugDisplay: no controller uses this costs object");
-    paramsToDevice(bound_, false);
-    NeuralNetModel::check(mppi_set_costmap_transform(bound_, params_.r_c1, params_.r_c2, params_.trs), bound_);
+    debug_img_width_ = width_m;
+    debug_img_height_ = height_m;
+    debug_img_ppm_ = ppm;
+    debugging_ = true;
+  }
+  // getDebugDisplay(x, y, heading), costs.cu:272-285 -> debugCostKernel (debug_kernels.cuh:39-88), without the
+  // cv::Mat: the raster [height_m*ppm][width_m*ppm] of the window debugDisplayInit set (default 10 m x 10 m at
+  // 50 px/m, :274-276).  The costs object owns no device state here; the raster runs on the handle of a controller
+  // that uses this object (the most recently constructed one still alive), after that handle's pending solve
+  // and with the current params_ pushed first.
+  std::vector<float> getDebugDisplay(float x, float y, float heading)
+  {
+    if (!debugging_) debugDisplayInit();
+    return getDebugDisplay(x, y, heading, debug_img_width_, debug_img_height_, debug_img_ppm_);
+  }
+  std::vector<float> getDebugDisplay(float x, float y, float heading, int width_m, int height_m, int ppm)
+  {
+    if (bound_.empty()) throw std::runtime_error("MPPICosts::getDebugDisplay: no controller uses this costs object");
+    mppi_handle *h = bound_.back();
+    NeuralNetModel::check(mppi_synchronize(h), h);  // no parameter push under an asynchronous solve
+    paramsToDevice(h, false);
+    NeuralNetModel::check(mppi_set_costmap_transform(h, params_.r_c1, params_.r_c2, params_.trs), h);
     std::vector<float> img((size_t)width_m * ppm * height_m * ppm);
-    NeuralNetModel::check(mppi_debug_cost_raster(bound_, x, y, heading, width_m, height_m, ppm, img.data(), img.size()), bound_);
+    NeuralNetModel::check(mppi_debug_cost_raster(h, x, y, heading, width_m, height_m, ppm, img.data(), img.size()), h);
     return img;
   }
-  void bindHandle(mppi_handle *h) { bound_ = h; }
-  void unbindHandle(mppi_handle *h) { if (bound_ == h) bound_ = nullptr; }
+  // every controller constructed on this costs object binds its handle; a destroyed one leaves the others bound
+  void bindHandle(mppi_handle *h) { bound_.push_back(h); }
+  void unbindHandle(mppi_handle *h)
+  {
+    for (size_t i = 0; i < bound_.size(); i++)
+      if (bound_[i] == h) { bound_.erase(bound_.begin() + (long)i); break; }
+  }
+  size_t boundHandles() const { return bound_.size(); }
   // Managed interface of the reference (managed.cuh): nothing to do here, see NeuralNetModel::bindToStream.
   // paramsToDevice() without a handle asks every controller to push params_ again at its next solve (they do
   // so anyway whenever params_ differs from what they pushed last, like mppi_controller.cu:605).
@@ -446,7 +473,9 @@ class MPPICosts {
   unsigned version_ = 0, map_version_ = 0;
 
  private:
-  mppi_handle *bound_ = nullptr;
+  std::vector<mppi_handle *> bound_;
+  int debug_img_width_ = 10, debug_img_height_ = 10, debug_img_ppm_ = 50;
+  bool debugging_ = false;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -493,7 +522,9 @@ class MPPIControllerT {
     if (rc != MPPI_OK) throw std::runtime_error(std::string("mppi_create: ") + mppi_strerror(rc));
     state_solution_.assign((size_t)numTimesteps_ * STATE_DIM, 0.0f);
     control_solution_.assign((size_t)numTimesteps_ * CONTROL_DIM, 0.0f);
+    setCudaStream(nullptr);  // mppi_controller.cu:335
     syncParams(true);
+    initDDP();               // :359
     costs_->bindHandle(h_);
   }
   ~MPPIControllerT() { deallocateCudaMem(); }
@@ -510,6 +541,20 @@ class MPPIControllerT {
   }
   mppi_handle *handle() { return h_; }
 
+  // setCudaStream(stream), mppi_controller.cuh:109 / mppi_controller.cu:365-370: the handle owns its stream (one
+  // per controller, created with it), so there is nothing to rebind; kept for code written against the reference
+  void setCudaStream(void * /*hipStream_t*/) {}
+  // initDDP(), mppi_controller.cuh:121 / mppi_controller.cu:402-429: the tracking weights of the feedback
+  // controller, Q = diag(.5,.5,.25,0,.05,.01,.01), R = diag(10,10), Qf = 0 (:410-417); one DDP iteration, dt = 1/hz
+  void initDDP()
+  {
+    const float Q[STATE_DIM] = {0.5f, 0.5f, 0.25f, 0.0f, 0.05f, 0.01f, 0.01f}, R[CONTROL_DIM] = {10.0f, 10.0f};
+    const float Qf[STATE_DIM] = {0, 0, 0, 0, 0, 0, 0};
+    ck(mppi_set_ddp_weights(h_, Q, R, Qf));
+  }
+  // savitskyGolay(), mppi_controller.cuh:134 / mppi_controller.cu:468-499: smooths U_ in place (computeControl
+  // already ends with it; public in the reference)
+  void savitskyGolay() { ck(mppi_savitsky_golay(h_)); }
   void resetControls() { ck(mppi_reset_controls(h_)); }
   void cutThrottle()  // mppi_controller.cu:460-466: plain writes to the public members; the next solve pushes them
   {
@@ -579,6 +624,25 @@ class MPPIControllerT {
     float s[STATE_DIM];
     for (int i = 0; i < STATE_DIM; i++) s[i] = state_solution_[i];
     startControl(s);
+  }
+  // Both solves of runControlLoop's tick (run_control_loop.cuh:218-219) enqueued TOGETHER: where the two
+  // controllers' rollouts fit the chip side by side (2 x 1920 rollouts = 240 groups on 256 CUs) they are one
+  // launch of the rollout kernel and one of the tail kernel (mppi_compute_control_batch_async); results per
+  // controller are bit for bit those of startControl.  finishControl() of each controller collects them.
+  static void startControlPair(MPPIControllerT *actual, const float *state, MPPIControllerT *predicted)
+  {
+    actual->syncParams(false);
+    predicted->syncParams(false);
+    float st[2 * STATE_DIM];
+    for (int i = 0; i < STATE_DIM; i++) {
+      st[i] = actual->solve_state_[i] = state[i];
+      st[STATE_DIM + i] = predicted->solve_state_[i] = predicted->state_solution_[i];
+    }
+    mppi_handle *hs[2] = {actual->h_, predicted->h_};
+    const int rc = mppi_compute_control_batch_async(hs, st, 2);
+    if (rc != MPPI_OK)  // the text sits on whichever handle recorded it
+      throw std::runtime_error(std::string("libmppi_hip: ") + mppi_strerror(rc) + " (" + mppi_last_error(actual->h_) +
+                               " | " + mppi_last_error(predicted->h_) + ")");
   }
   void finishControl()
   {

@@ -248,9 +248,8 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
       st.strides.push_back(-1);
     }
     // computeControl(state) / computeControl() (:218-219); the two solves are independent, so both are
-    // put on the GPU (one stream per controller) before either is waited for
-    actual_state_controller->startControl(state);
-    predicted_state_controller->startControl();
+    // put on the GPU together -- one launch for the rollouts of both controllers -- before either is waited for
+    CONTROLLER_T::startControlPair(actual_state_controller, state, predicted_state_controller);
     actual_state_controller->finishControl();
     predicted_state_controller->finishControl();
     if (use_feedback_gains) {  // :220-225: both controllers, from the measured state

@@ -65,23 +65,30 @@ def flops_per_update(layers):
     return sum(2 * a * b + b for a, b in zip(layers[:-1], layers[1:]))
 
 
-def init_dist(backend):
-    """(rank, local_rank, world, dist-or-None); one process per GPU, env from torch.distributed.run."""
+def init_dist(backend, devices=None):
+    """(rank, device, world, dist-or-None); one process per GPU, env from torch.distributed.run.
+    `devices` (--devices "0,0"): rank -> device map for rehearsing the N > 1 path on fewer GPUs than ranks
+    (then with --dist-backend gloo: RCCL refuses two ranks on one device); default device = LOCAL_RANK."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = local_rank
+    if devices:
+        if len(devices) != world:
+            raise SystemExit("--devices names %d devices for WORLD_SIZE=%d" % (len(devices), world))
+        device = devices[rank]
     if world == 1:
-        return rank, local_rank, world, None
+        return rank, device, world, None
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
     else:
         dist.init_process_group(backend=backend)
-    return rank, local_rank, world, dist
+    return rank, device, world, dist
 
 
 def pin_to_gpu_numa(device):
@@ -120,15 +127,15 @@ def rank_workload(args, rank):
     over = {}
     if args.dynamics == "basis":
         from autorally_amd import params as P
-        over["bf_W"] = P.load_bf_npz(os.path.join(ROOT, "tests", "golden", "models", "basis_function_09_12_2018.npz"))
+        over["bf_W"] = P.load_bf_npz(os.path.join(S.MODELS_DIR, "basis_function_09_12_2018.npz"))
     return S.make_config(args.K, args.T, layers=layers, track="oval", instance=rank, seed=1234 + rank, **over)
 
 
-def max_over_ranks(dist, value, cuda):
+def max_over_ranks(dist, value, on_gpu):
     if dist is None:
         return value
     import torch
-    t = torch.tensor([value], dtype=torch.float64, device="cuda" if cuda else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -225,10 +232,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the multi-process driver with gloo and the CPU oracle (no GPU, not a benchmark)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process group for barrier / max / gather (never on the data path); nccl = RCCL (default), "
+                         "gloo for rehearsing N > 1 with several ranks on one GPU")
+    ap.add_argument("--devices", type=str, default="",
+                    help="rank -> device map, e.g. '0,0' (default: device = LOCAL_RANK)")
     args = ap.parse_args()
 
     selftest = args.selftest_cpu
-    rank, local_rank, world, dist = init_dist("gloo" if selftest else "nccl")
+    backend = "gloo" if selftest else args.dist_backend
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else None
+    rank, local_rank, world, dist = init_dist(backend, devices)  # local_rank: this rank's DEVICE from here on
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
@@ -290,7 +304,7 @@ def main():
         local_s.append(time.perf_counter() - t0)
         if dist is not None:
             dist.barrier()
-        return max_over_ranks(dist, time.perf_counter() - t0, cuda)
+        return max_over_ranks(dist, time.perf_counter() - t0, cuda and backend == "nccl")
 
     # Initialisation, before the W warm-up steps: the same step repeated for --prime-ms of wall time, so
     # that code objects are loaded, allocations are settled and the GPU has left its idle clock state (a
@@ -330,7 +344,7 @@ def main():
         dist.barrier()
 
     # what every rank ran (proves the instances are distinct), gathered off the timed region
-    mine = {"rank": rank, "start_state": [round(float(x), 4) for x in cfg["start_state"]],
+    mine = {"rank": rank, "device": local_rank, "start_state": [round(float(x), 4) for x in cfg["start_state"]],
             "map_checksum": float(np.asarray(cfg["map_rgba"], dtype=np.float64).sum()),
             "U0": [round(float(x), 5) for x in sol.get_control_seq()[0]],
             "own_ms_per_step": 1e3 * local_s[0] / args.steps,  # the timed block, this GPU alone (no closing barrier)
@@ -360,7 +374,8 @@ def main():
                        "timed_loop": ("native (mppi_control_ticks)" if native else "python (one ctypes call per ABI call)"),
                        "host_affinity": affinity if cuda else "unchanged",
                        "priming": "%d untimed solves (%.0f ms) before the %d warm-up steps" % (n_prime, args.prime_ms, args.warmup),
-                       "parallelism": "replicas x%d (no collective)" % world},
+                       "parallelism": "replicas x%d (no collective)" % world,
+                       "process_group": backend if world > 1 else "none"},
             "state_updates_per_s": value * T,
             "repeats": len(block_s),
             "median_ms_per_step": 1e3 * float(np.median(block_s)) / args.steps,

@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 1
+/* 2: + mppi_set_costmap_transform, mppi_savitsky_golay, mppi_compute_control_batch[_async], mppi_control_ticks_batch,
+ *    mppi_debug_inject_handover_fault; mppi_slide_control_seq(h, 0) is MPPI_OK (was MPPI_ERR_INVALID); "fused" =
+ *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w". */
+#define MPPI_ABI_VERSION 2
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
 #define MPPI_MAX_LAYERS 8
@@ -140,6 +143,9 @@ int mppi_get_control_seq(mppi_handle *h, float *U, size_t n);
 /* control_hist_ (mppi_controller.cu:347, 528-541): two controls executed before U_0. */
 int mppi_set_control_hist(mppi_handle *h, const float hist[4]);
 int mppi_get_control_hist(mppi_handle *h, float hist[4]);
+/* savitskyGolay() (mppi_controller.cuh:134, mppi_controller.cu:468-499) as a call of its own: smooths the
+ * handle's current U_ in place with control_hist_ as left padding (computeControl already ends with it). */
+int mppi_savitsky_golay(mppi_handle *h);
 /* slideControlSeq (mppi_controller.cu:527-554), flat-index quirk for stride>2 kept. */
 int mppi_slide_control_seq(mppi_handle *h, int stride);
 
@@ -164,6 +170,19 @@ int mppi_control_ticks(mppi_handle *h, const float state[MPPI_STATE_DIM], int n_
 /* Same solve, enqueued only; results are valid after mppi_synchronize. */
 int mppi_compute_control_async(mppi_handle *h, const float state[MPPI_STATE_DIM]);
 int mppi_synchronize(mppi_handle *h);
+/* The solves of n independent controllers enqueued together -- runControlLoop's tick
+ * (PI/run_control_loop.cuh:218-219: actual-state and predicted-state controller, both of path_integral_main.cu:119-122)
+ * -- states is [n][7], handles[i] solves from states + 7 i.  Where the handles' rollout kernels can share a launch
+ * (network model, the four-wavefront form, same layer list and num_iters, all groups of 16 rollouts together at
+ * most one per CU: 2 x K=1920 on 256 CUs) the n solves cost TWO kernel launches in all, on a stream of the library
+ * shared by the device's handles; otherwise this is n calls of mppi_compute_control_async.  Either way every
+ * handle's results are bit for bit those of its own mppi_compute_control, collected per handle with
+ * mppi_synchronize / mppi_get_results.  The blocking form waits for all of them. */
+int mppi_compute_control_batch_async(mppi_handle *const *handles, const float *states, int n);
+int mppi_compute_control_batch(mppi_handle *const *handles, const float *states, int n);
+/* mppi_control_ticks for several controllers: n_ticks times { mppi_compute_control_batch; mppi_slide_control_seq
+ * (handles[i], stride) for every i } -- the solve part of runControlLoop's tick for its two controllers. */
+int mppi_control_ticks_batch(mppi_handle *const *handles, const float *states, int n, int n_ticks, int stride);
 /* getComputedTrajectoryCost (:683-687) + optional per-rollout vectors of the last
  * iteration: costs[K] (traj_costs_ after the rollout), weights[K] (after normExpKernel). */
 int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, float *weights);

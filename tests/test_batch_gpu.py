@@ -1,0 +1,168 @@
+"""mppi_compute_control_batch: the solves of several controllers in one launch (runControlLoop's two controllers,
+run_control_loop.cuh:218-219).  Every instance's results must equal its own stand-alone solve bit for bit --
+explicit noise, generator mode over successive ticks with slides, different K / costmaps / cost parameters per
+instance, two iterations -- and a batch the kernels cannot share a launch for must fall back to per-handle solves
+with the same results."""
+import numpy as np
+import pytest
+
+from autorally_amd import capi
+from autorally_amd import params as P
+from autorally_amd import synthetic as S
+from oracle import oracle as O
+from tests.helpers import noise_for, warm_U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from autorally_amd import build as B
+    B.build()
+    assert capi.lib().mppi_device_count() >= 1
+
+
+def _same(a, b):
+    for k in ("U", "costs", "w"):
+        np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32), err_msg=k)
+    assert a["traj_cost"] == b["traj_cost"]
+
+
+def test_two_controllers_one_launch_equal_their_own_solves_and_the_oracle():
+    """The reference's deployment shape: two controllers of K=1920, T=100 on one costs / model object, solving
+    from the measured and from the predicted state.  Explicit noise: batch == stand-alone == oracle."""
+    cfg = S.make_config(1920, 100, track="oval")
+    st_a = cfg["start_state"].copy()
+    st_p = st_a.copy()
+    st_p[0] += 0.4
+    st_p[4] -= 0.5
+    U0 = warm_U(cfg)
+    eps = [noise_for(cfg, seed=11), noise_for(cfg, seed=12)]
+    states = [st_a, st_p]
+    alone = []
+    for e, st in zip(eps, states):
+        s = capi.Solver(cfg)
+        s.set_control_seq(U0)
+        s.set_noise(e)
+        s.compute_control(st)
+        alone.append(dict(s.get_results(), V=s.get_applied_controls()))
+        s.close()
+    sols = [capi.Solver(cfg), capi.Solver(cfg)]
+    for s, e in zip(sols, eps):
+        s.set_control_seq(U0)
+        s.set_noise(e)
+    capi.compute_control_batch(sols, states)
+    for s, ref, e, st in zip(sols, alone, eps, states):
+        got = dict(s.get_results(), V=s.get_applied_controls())
+        _same(got, ref)
+        np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"].view(np.uint32))
+        orc = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(st, U0, np.zeros(4, np.float32), e)
+        np.testing.assert_array_equal(got["V"].view(np.uint32), orc["V"][-1].view(np.uint32))
+        assert np.max(np.abs(got["U"] - orc["U"])) <= 1e-4
+        assert abs(got["traj_cost"] - orc["traj_cost"]) <= 1e-4 * abs(orc["traj_cost"])
+    for s in sols:
+        s.close()
+
+
+@pytest.mark.parametrize("shapes", [
+    [(1920, 100, None), (1920, 100, None)],
+    [(1024, 60, None), (2048, 37, None), (512, 100, None)],          # different K and T per instance
+    [(1024, 50, [6, 64, 64, 4]), (1024, 50, [6, 64, 64, 4])],        # a 64-wide net forced into the quad form
+    [(640, 33, None), (640, 33, None), (640, 33, None), (640, 33, None)],
+])
+def test_batched_ticks_in_generator_mode_equal_separate_handles(shapes):
+    """Six ticks of solve + slide per controller, device generators, asynchronous batch + per-handle collection:
+    the batched controllers follow stand-alone controllers bit for bit (control sequence, history, costs)."""
+    cfgs = []
+    for i, (K, T, layers) in enumerate(shapes):
+        kw = {}
+        if layers:
+            l, th = P.synthetic_model(layers, seed=4)
+            kw = dict(layers=l, theta=th)
+        cost = dict(P.DEFAULT_COST)
+        if i % 2:
+            cost.update(steering_coeff=0.3, desired_speed=5.0)  # a control-cost instance next to one without
+        cfgs.append(S.make_config(K, T, track="oval", instance=i, seed=77 + i, cost=cost, **kw))
+    ref, bat = [capi.Solver(c) for c in cfgs], [capi.Solver(c) for c in cfgs]
+    for s in ref + bat:
+        s.set_rollout_variant("quad")
+    states = [c["start_state"].copy() for c in cfgs]
+    for tick in range(6):
+        for s, st in zip(ref, states):
+            s.compute_control(st)
+        capi.compute_control_batch(bat, states, blocking=(tick % 2 == 0))
+        for r, b, c in zip(ref, bat, cfgs):
+            _same(b.get_results(), r.get_results())
+            np.testing.assert_array_equal(b.get_control_hist(), r.get_control_hist())
+            stride = 1 if tick % 3 else 2
+            r.slide_control_seq(stride)
+            b.slide_control_seq(stride)
+            np.testing.assert_array_equal(b.get_control_seq().view(np.uint32), r.get_control_seq().view(np.uint32))
+        states = [st + np.float32(0.01) * np.arange(7, dtype=np.float32) for st in states]
+    assert all("quad" in s.rollout_variant() for s in bat)
+    for s in ref + bat:
+        s.close()
+
+
+def test_batch_then_single_then_batch_and_two_iterations():
+    """Transitions between the batch stream and a handle's own stream (single solve, result vectors, applied
+    controls, set_noise, seed) keep every handle's sequence of results; num_iters = 2 batches both iterations."""
+    cfg = S.make_config(1024, 40, track="ring", num_iters=2)
+    ref, bat = [capi.Solver(cfg) for _ in range(2)], [capi.Solver(cfg) for _ in range(2)]
+    for i in range(2):
+        ref[i].seed(500 + i, 0)
+        bat[i].seed(500 + i, 0)
+    st = [cfg["start_state"].copy(), cfg["start_state"].copy()]
+    st[1][1] += 0.3
+    seq = ["batch", "single", "batch", "explicit", "batch", "batch"]
+    for step, op in enumerate(seq):
+        if op == "explicit":
+            eps = noise_for(cfg, seed=900 + step)
+            for s in ref + bat:
+                s.set_noise(eps)
+        for i in range(2):
+            ref[i].compute_control(st[i])
+        if op == "single":
+            for i in range(2):
+                bat[i].compute_control(st[i])
+        else:
+            capi.compute_control_batch(bat, st)
+        for i in range(2):
+            a, b = bat[i].get_results(), ref[i].get_results()
+            _same(a, b)
+            np.testing.assert_array_equal(bat[i].get_applied_controls().view(np.uint32),
+                                          ref[i].get_applied_controls().view(np.uint32))
+            ref[i].slide_control_seq(1)
+            bat[i].slide_control_seq(1)
+    for s in ref + bat:
+        s.close()
+
+
+def test_batches_the_library_cannot_share_a_launch_for_fall_back_to_per_handle_solves(golden_dir):
+    """More groups than CUs, different layer lists, the basis-function model, a single handle: the call still
+    solves every handle (on its own stream), with its own results."""
+    import os
+    W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    l64, th64 = P.synthetic_model([6, 64, 64, 4], seed=4)
+    groups = [
+        [S.make_config(4096, 30, track="oval"), S.make_config(4096, 30, track="oval", instance=1)],   # 512 groups
+        [S.make_config(512, 30, track="oval"), S.make_config(512, 30, track="oval", layers=l64, theta=th64)],
+        [S.make_config(640, 30, track="ring", bf_W=W), S.make_config(512, 30, track="ring")],
+        [S.make_config(256, 30, track="ring")],
+    ]
+    for cfgs in groups:
+        ref, bat = [capi.Solver(c) for c in cfgs], [capi.Solver(c) for c in cfgs]
+        states = [c["start_state"] for c in cfgs]
+        for _ in range(2):
+            for s, st in zip(ref, states):
+                s.compute_control(st)
+            capi.compute_control_batch(bat, states)
+            for r, b in zip(ref, bat):
+                _same(b.get_results(), r.get_results())
+        for s in ref + bat:
+            s.close()
+    # the same handle twice / an empty batch are refused
+    s = capi.Solver(groups[3][0])
+    with pytest.raises(capi.MppiError):
+        capi.compute_control_batch([s, s], [states[0], states[0]])
+    s.close()

@@ -35,3 +35,33 @@ def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu", "--steps", "1",
                         "--warmup", "0", "--K", "64", "--T", "10"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_real_solver_on_one_gpu():
+    """The driver's N > 1 launch with the REAL solver: two ranks under torch.distributed.run, both mapped to
+    GPU 0 (--devices 0,0), process group gloo (RCCL refuses two ranks on one device; the group only carries
+    barrier / max / gather -- there is no collective on the data path, so nothing else differs from the 8-GPU
+    launch: rank-0 build + barrier, capi.Solver(device), all_gather_object, one JSON line)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--devices", "0,0",
+           "--repeats", "3", "--latency-solves", "20", "--event-solves", "8", "--prime-ms", "50"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["config"]["process_group"] == "gloo" and "quad" in d["config"]["rollout_variant"]
+    assert abs(d["value"] - 4096 * 20 * 2 / (d["ms_per_step"] * 20 / 1e3)) < 1e-6 * d["value"]
+    a, b = d["instances"]
+    assert (a["rank"], b["rank"]) == (0, 1) and a["device"] == b["device"] == 0
+    assert a["map_checksum"] != b["map_checksum"] and a["start_state"] != b["start_state"] and a["U0"] != b["U0"]
+    for inst in (a, b):  # every rank's own time for the timed block (per-GPU spread on the real node)
+        assert 0.0 < inst["own_ms_per_step"] <= d["ms_per_step"] * 1.001
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d  # the CPU leg runs at N = 1 only

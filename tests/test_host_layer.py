@@ -134,9 +134,11 @@ def test_path_integral_binaries_match_python_loop(bins, golden_dir, tmp_path, bi
         state, _ = orc.update_state(state, u)   # (shared model object, run_control_loop.cuh:299-300)
     np.testing.assert_allclose(out["final_state"], state, atol=2e-4, rtol=1e-4)
     assert out["actual_state_used"] == n_actual
-    # the basis-function model has no analytic gradient: its gains come from fp32 central differences
-    # (ddp_dynamics.h:71-84), which amplify the last-digit differences between the two loops
-    gtol = 3e-2 if binary == "path_integral_bf" else 2e-3
+    # both model families to the same bound: since the host replays of the basis-function model call powf like
+    # car_bfs.cuh the binary's plant and this loop's oracle plant agree to the last digit,
+    # so the fp32 central differences of ddp_dynamics.h:71-84 see the same inputs in both loops
+    gtol = 2e-3
+    print("gain row sums: binary", out["feedback_gain_row_sums_t0"], "python loop", gains[0].sum(axis=1).tolist())
     np.testing.assert_allclose(out["feedback_gain_row_sums_t0"], gains[0].sum(axis=1), rtol=gtol, atol=2e-4)
     assert np.abs(gains[0]).max() > 1e-3
     assert abs(state[4]) > 0.5  # the car actually drove

@@ -25,6 +25,15 @@ def _oracle_for(golden_dir, name, g, fma_mode):
     return O.Oracle(cfg, fma_mode=fma_mode)
 
 
+def test_package_default_models_equal_the_golden_fixtures(golden_dir):
+    """autorally_amd/data/models (the package's default dynamics; the package does not reach into tests/) holds
+    the same bytes as the fixtures gen_golden.py copied from the reference's params/models."""
+    for f in sorted(os.listdir(S.MODELS_DIR)):
+        with open(os.path.join(S.MODELS_DIR, f), "rb") as a, open(os.path.join(golden_dir, "models", f), "rb") as b:
+            assert a.read() == b.read(), f
+    assert "autorally_nnet_09_12_2018.npz" in os.listdir(S.MODELS_DIR)
+
+
 def test_num_params(golden_dir):
     # NUM_PARAMS = 1412 for 6-32-32-4, 4868 for 6-64-64-4 (SURVEY 3.5)
     for layers, n in (([6, 32, 32, 4], 1412), ([6, 64, 64, 4], 4868)):
