@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmppi_hip.so")
 SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_multi.hip", "rollout_oct.hip", "rollout_valu.hip", "solve_kernels.hip",
            "noise_mrg32k3a.hip", "rollout_bf.hip", "ddp_feedback.cpp"]
-HEADERS = ["mppi_device.hpp", "mfma_net.hpp", "group_roles.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", "basis_funcs.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
+HEADERS = ["mppi_device.hpp", "mfma_net.hpp", "group_roles.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", "basis_funcs.hpp", "host_net.hpp", "tanhf_vec.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file), which removes
 # the v_accvgpr_read per accumulator register after every layer
@@ -78,7 +78,7 @@ def build_host(force=False):
     os.makedirs(BIN, exist_ok=True)
     cxx = shutil.which("g++") or "g++"
     hdrs = [os.path.join(HOST, h) for h in ("npz.hpp", "param_getter.hpp", "mppi_controller_hip.hpp",
-                                            "run_control_loop.hpp", "path_integral_main.hpp")] + [os.path.join(CSRC, "basis_funcs.hpp")] + [os.path.join(HERE, "..", "include", "mppi_hip.h")]
+                                            "run_control_loop.hpp", "path_integral_main.hpp")] + [os.path.join(CSRC, h) for h in ("basis_funcs.hpp", "host_net.hpp", "tanhf_vec.hpp")] + [os.path.join(HERE, "..", "include", "mppi_hip.h")]
     outs = []
     link = ["-L" + HERE, "-lmppi_hip", "-Wl,-rpath,$ORIGIN/.."]
     for name, libs in (("host_selftest", link), ("path_integral_nn", link), ("path_integral_bf", link)):

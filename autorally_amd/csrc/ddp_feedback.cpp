@@ -3,6 +3,7 @@
 // expressions of ddp.h (e.g. (B^T Vxx) Phi).
 #include "ddp_feedback.hpp"
 #include "basis_funcs.hpp"
+#include "tanhf_vec.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -69,8 +70,11 @@ struct HostNet : HostModel {
   std::vector<float> a_, b_;            // activations (padded)
   std::vector<float> d_, dn_;           // delta, struct of arrays: [4][pmax]
   int pmax;
+  bool vec_tanh;
   explicit HostNet(const DdpNet &net) : n(net), L(net.n_layers - 1)
   {
+    static const bool vec_ok = tanhf_vec_selfcheck();
+    vec_tanh = vec_ok;
     pmax = 8;
     size_t off = 0;
     for (int l = 0; l < L; l++) {
@@ -123,8 +127,14 @@ struct HostNet : HostModel {
       if (l < L - 1) {
         float *t = th[l].data();
         // tanhf as in the reference's host code (MPPI_NNET_NONLINEARITY): the Riccati recursion amplifies a
-        // 1e-7 difference in these values to 1e-3 of the feedforward term at T = 250, so no fast substitute
-        for (int j = 0; j < nout; j++) b[j] = t[j] = std::tanh(b[j]);
+        // 1e-7 difference in these values to 1e-3 of the feedforward term at T = 250, so no merely accurate
+        // substitute -- tanhf_vec.hpp is libm's own algorithm on eight lanes (the same bits, checked at start-up)
+        if (vec_tanh) {
+          tanhf_vec(b, po);  // padded lanes: tanhf(0) = 0
+          for (int j = 0; j < nout; j++) t[j] = b[j];
+        } else {
+          for (int j = 0; j < nout; j++) b[j] = t[j] = std::tanh(b[j]);
+        }
       }
       std::swap(a, b);
     }

@@ -23,6 +23,7 @@
 #include "mppi_kernels.hpp"
 #include "ddp_feedback.hpp"
 #include "basis_funcs.hpp"
+#include "host_net.hpp"
 
 using namespace mppi;
 
@@ -82,7 +83,7 @@ struct mppi_handle {
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
   int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 0;    // 0: auto; 512: quad (2 dynamics + cost + control waves per 16 rollouts); 800: oct (4 dynamics waves, one M tile of a
+  int block_threads = 0;    // 0: auto; 1040: multi form with ND = 4 and six waves (one cost wave); 512: quad (2 dynamics + cost + control waves per 16 rollouts); 800: oct (4 dynamics waves, one M tile of a
                             // 64-wide net each, + pose, cost, control, noise wave); 64, 256: single-wave form;
                             // 1000 + ND: multi form (ND dynamics waves of 16 rollouts + cost wave + control wave), ND = 1, 2, 4
   bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
@@ -107,6 +108,7 @@ struct mppi_handle {
   float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
 
   std::vector<float> U, hist, theta, map_rgba;
+  HostNetFma hnet;  // host twin of the network for computeNominalTraj (rebuilt with every mppi_set_nn_params)
   int map_w = 0, map_h = 0;
   mppi_cost_params cost{};
   float r_c1[3] = {0, 0, 0}, r_c2[3] = {0, 0, 0}, trs[3] = {0, 0, 1};
@@ -129,6 +131,10 @@ struct mppi_handle {
   float *v_buf = nullptr;      // where the last solve's applied controls are
   hipStream_t gstream = nullptr;
   hipEvent_t ev_gen = nullptr, ev_s1 = nullptr;
+  // stage timing of the asynchronous generator: begin / end of the generator launch on gstream that was enqueued
+  // during a timed solve (it runs BESIDE that solve's rollout or tail: reported as noise_ms, not additive)
+  hipEvent_t ev_gt[2] = {nullptr, nullptr};
+  bool gen_timed = false, gen_time_now = false;
   float *d_costs = nullptr, *d_w = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
   float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
@@ -307,6 +313,9 @@ int effective_block(const mppi_handle *h)
   if (multi_variant_supported(h->hidden, h->n_hidden)) {
     if (groups <= cus) return 512;
     if (groups <= 2 * cus) return 1002;
+    // 64-wide nets beyond one group per SIMD: the six-wave form (168 VGPRs, three waves per SIMD: two workgroups
+    // = two dynamics waves + one rider per SIMD); the eight-wave form (172 VGPRs) fits one workgroup per CU only
+    if (h->hidden == 64 && groups > h->num_simds) return 1040;
     return 1004;
   }
   return (4 * groups <= h->num_simds) ? 512 : 256;
@@ -316,7 +325,7 @@ int effective_block(const mppi_handle *h)
 bool multi_gen(const mppi_handle *h)
 {
   if (h->block_threads != 0) return h->multi_standalone_noise;
-  return effective_block(h) == 1004;
+  return effective_block(h) == 1004 || effective_block(h) == 1040;
 }
 
 // basis-function model, wavefronts per 64 rollouts: dynamics + cost + control wave (in-kernel generator) while
@@ -481,8 +490,14 @@ int check_ready(mppi_handle *h)
 // the handle's stream has passed the wait enqueued here.
 int launch_generator(mppi_handle *h, float *dst)
 {
+  const bool timed = h->gen_time_now && !h->gen_timed;
+  if (timed) HIPCHK(h, hipEventRecord(h->ev_gt[0], h->gstream));
   HIPCHK(h, launch_noise(h->d_rng[h->rng_cur], h->d_rng[1 - h->rng_cur], h->d_jump, h->K, h->T, h->noise_L,
                          h->noise_C, dst, h->gstream));
+  if (timed) {
+    HIPCHK(h, hipEventRecord(h->ev_gt[1], h->gstream));
+    h->gen_timed = true;
+  }
   h->rng_cur = 1 - h->rng_cur;
   HIPCHK(h, hipEventRecord(h->ev_gen, h->gstream));
   return MPPI_OK;
@@ -522,6 +537,13 @@ int acquire_noise(mppi_handle *h, float **buf_out)
 // one, which the host has collected.  Only for single-iteration solves of a generator-kernel form.
 int prefetch_noise(mppi_handle *h)
 {
+  // INVARIANT the target buffer relies on: d_gen[1 - gen_cur] holds the applied controls of the solve BEFORE the
+  // one just enqueued; its readers were that solve's tail kernel -- every row workgroup published its row after
+  // reading it, and the host has seen all rows (wait_pending at the top of enqueue_solve) -- and calls that
+  // synchronise the stream themselves (mppi_get_applied_controls, mppi_rollout_only).  No device-side ordering
+  // against h->stream is needed as long as no solve is pending here; a reader that does not synchronise would
+  // have to be ordered explicitly (an event after the tail kernel, waited for by gstream).
+  if (h->pending) return fail(h, MPPI_ERR_STATE, "prefetch with a solve pending");
   // While every SIMD runs at most one dynamics wave (K <= 16 x #SIMDs) the generator starts at once, beside the
   // rollout: its instructions fit the dependency bubbles of the dynamics waves (config 4 0.317 -> 0.309 ms per
   // solve, K=16384 6-32-32-4 0.122 -> 0.117).  With several workgroups per CU there are no bubbles left
@@ -640,6 +662,12 @@ int wait_pending(mppi_handle *h)
       h->acc.reduction_ms += ms[2];
       h->acc.total_ms += ms[0] + ms[1] + ms[2];
     }
+    if (h->gen_timed) {  // the generator launch enqueued during this solve (on gstream, beside the rollout / tail)
+      h->gen_timed = false;
+      float gms = 0.0f;
+      HIPCHK(h, hipEventSynchronize(h->ev_gt[1]));
+      if (hipEventElapsedTime(&gms, h->ev_gt[0], h->ev_gt[1]) == hipSuccess && gms > 0.0f) h->acc.noise_ms += gms;
+    }
     h->acc.n_solves += 1;
   }
   return MPPI_OK;
@@ -729,7 +757,9 @@ int enqueue_solve(mppi_handle *h, const float *state)
     HIPCHK(h, launch_solve_tail(tail_launch(h, noise, last), h->stream));
     if (last) h->slid_valid = want_slid;
     if (prefetch) {
+      h->gen_time_now = timed;  // only the prefetch launch: a generator the stream waits for sits between e[0] and e[1]
       rc = prefetch_noise(h);
+      h->gen_time_now = false;
       if (rc) return rc;
     }
 #ifdef MPPI_HOSTPROF
@@ -767,6 +797,8 @@ void free_all(mppi_handle *h)
   for (float *p : h->d_gen)
     if (p) (void)hipFree(p);
   if (h->ev_gen) (void)hipEventDestroy(h->ev_gen);
+  for (auto &e : h->ev_gt)
+    if (e) (void)hipEventDestroy(e);
   if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
   if (h->gstream) (void)hipStreamDestroy(h->gstream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -884,6 +916,8 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CR(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
   CR(hipEventCreateWithFlags(&h->ev_gen, hipEventDisableTiming));
+  CR(hipEventCreate(&h->ev_gt[0]));
+  CR(hipEventCreate(&h->ev_gt[1]));
   CR(hipEventCreateWithFlags(&h->ev_s1, hipEventDisableTiming));
   h->n_slots = std::max(1, cfg->num_iters);
   CR(hipMalloc(&h->d_in_buf[0], sizeof(float) * (2 * (size_t)h->T + 4)));
@@ -987,6 +1021,7 @@ int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
     }
     HIPCHK(h, hipMemcpy(h->d_theta_s, ts.data(), n * sizeof(float), hipMemcpyHostToDevice));
   }
+  h->hnet.init(h->net.layers, h->net.n_layers, h->theta.data());
   if (h->mfma_ok) {
     const std::vector<float> pk = pack_mfma_weights(h->theta, h->hidden, h->n_hidden);
     HIPCHK(h, hipMemcpy(h->d_wpack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1492,7 +1527,6 @@ int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   // like the reference this replay runs on the host (T sequential 1.4k-MAC steps).
   float s[kStateDim];
   for (int i = 0; i < kStateDim; i++) s[i] = state[i];
-  std::vector<float> a(std::max(h->net.max_width, 8)), b(std::max(h->net.max_width, 8));
   for (int t = 0; t < h->T; t++) {
     for (int i = 0; i < kStateDim; i++) state_seq[t * kStateDim + i] = s[i];
     float u[2] = {h->U[2 * t], h->U[2 * t + 1]};
@@ -1515,37 +1549,10 @@ int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
       control_seq[2 * t + 1] = u[1];
       continue;
     }
-    a[0] = s[3]; a[1] = s[4]; a[2] = s[5]; a[3] = s[6]; a[4] = u[0]; a[5] = u[1];
-    size_t off = 0;
-    for (int l = 0; l + 1 < h->net.n_layers; l++) {
-      const int nin = h->net.layers[l], nout = h->net.layers[l + 1];
-      const float *W = &h->theta[off], *bias = &h->theta[off + (size_t)nin * nout];
-      // four output neurons at a time: four independent k-ascending fmaf chains (same values, 4x the ILP)
-      int j = 0;
-      for (; j + 4 <= nout; j += 4) {
-        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-        const float *w0 = W + (size_t)j * nin, *w1 = w0 + nin, *w2 = w1 + nin, *w3 = w2 + nin;
-        for (int k = 0; k < nin; k++) {
-          const float ak = a[k];
-          t0 = fmaf(w0[k], ak, t0);
-          t1 = fmaf(w1[k], ak, t1);
-          t2 = fmaf(w2[k], ak, t2);
-          t3 = fmaf(w3[k], ak, t3);
-        }
-        const float tv[4] = {t0 + bias[j], t1 + bias[j + 1], t2 + bias[j + 2], t3 + bias[j + 3]};
-        for (int q = 0; q < 4; q++) b[j + q] = (l < h->net.n_layers - 2) ? tanhf(tv[q]) : tv[q];
-      }
-      for (; j < nout; j++) {
-        float tmp = 0.0f;
-        for (int k = 0; k < nin; k++) tmp = fmaf(W[j * nin + k], a[k], tmp);
-        tmp += bias[j];
-        if (l < h->net.n_layers - 2) tmp = tanhf(tmp);
-        b[j] = tmp;
-      }
-      off += (size_t)nin * nout + nout;
-      std::swap(a, b);
-    }
-    for (int i = 0; i < 4; i++) sd[3 + i] = a[i];
+    // the network: per neuron the k-ascending fmaf chain, bias added afterwards, tanhf -- eight neurons per AVX2
+    // register (host_net.hpp; the same values as the scalar loops, bit for bit)
+    const float nin6[6] = {s[3], s[4], s[5], s[6], u[0], u[1]};
+    h->hnet.forward(nin6, sd + 3);
     for (int i = 0; i < kStateDim; i++) s[i] = fmaf(sd[i], h->dt, s[i]);
     control_seq[2 * t] = u[0];
     control_seq[2 * t + 1] = u[1];
@@ -1672,7 +1679,9 @@ const char *mppi_rollout_variant(const mppi_handle *h)
   if (!use_mfma(h)) return use_valu_reg(h) ? "valu_reg_lds" : "valu_lds";
   static thread_local char buf[64];
   const int b = effective_block(h);
-  if (b > 1000)
+  if (b == 1040)
+    snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi4u%s", h->hidden, h->n_hidden, multi_gen(h) ? "_gen" : "");
+  else if (b > 1000)
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi%d%s", h->hidden, h->n_hidden, b - 1000,
              multi_gen(h) ? "_gen" : "");
   else
@@ -1703,6 +1712,13 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
       return fail(h, MPPI_ERR_UNSUPPORTED, "oct form exists for 6-64x2-4 and 6-64x4-4");
     h->block_threads = 800;
     h->multi_standalone_noise = name[3] != 0;
+  }
+  else if (strcmp(name, "multi4u") == 0 || strcmp(name, "multi4u_gen") == 0) {  // ND = 4, six waves (one cost wave)
+    if (h->K % 64 != 0) return fail(h, MPPI_ERR_UNSUPPORTED, "multi form needs K to be a multiple of 16 ND");
+    if (!h->mfma_ok || !multi_variant_supported(h->hidden, h->n_hidden))
+      return fail(h, MPPI_ERR_UNSUPPORTED, "multi form exists for 6-32x2-4, 6-32x4-4 and 6-64x2-4");
+    h->block_threads = 1040;
+    h->multi_standalone_noise = name[7] != 0;
   }
   else if (strncmp(name, "multi", 5) == 0) {
     const int nd = name[5] - '0';

@@ -29,9 +29,9 @@ namespace mppi {
 constexpr int kMRing = 16;    // steps in flight between the waves (power of two)
 constexpr int kMCtlChunk = 4;  // steps of U / explicit eps the control wave requests at once
 
-template <int ND>
+template <int ND, bool SPLIT_ = (ND == 4)>
 struct MultiShared {
-  static constexpr bool SPLIT = (ND == 4);  // cost work on two wavefronts (pose | cost), see the kernel
+  static constexpr bool SPLIT = SPLIT_;  // cost work on three wavefronts (pose | fetch | cost), see the kernel
   static constexpr int NR = 16 * ND;       // rollouts per workgroup
   float rec[kMRing][NR][4];                // s3..s6 before the update of step t (dynamics waves)
   float ctl_rec[kMRing][NR][4];            // clamped u0, u1, du0, du1 (control wave -> cost wave)
@@ -77,8 +77,8 @@ __device__ unsigned long long g_multi_stamps[8];
 #define MSTAMP(var) do { } while (0)
 #endif
 
-template <int H, int NHID, int ND>
-__device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared<ND> &sh, const int w)
+template <int H, int NHID, int ND, class SH>
+__device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, const int w)
 {
   using N = MfmaNet<H, NHID>;
   const int lane = threadIdx.x & 63;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
 
   const uint32_t a_mypub = lds_addr(&sh.dyn_pub[w][lane]);
   const uint32_t a_rec = lds_addr(&sh.rec[0][16 * w + j][g]);
-  constexpr uint32_t kRecSlot = MultiShared<ND>::NR * 16, kB1Slot = ND * 64 * 4;
+  constexpr uint32_t kRecSlot = SH::NR * 16, kB1Slot = ND * 64 * 4;
   // LDS-typed volatile pointers: plain ds_read instructions in program order, the compiler keeps track of
   // their completion itself (s_waitcnt at the first use), so a value requested early costs nothing later
   typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
@@ -186,10 +186,15 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, MultiShared
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
-template <int H, int NHID, int ND>
-__global__ __launch_bounds__((ND + 2 + (ND == 4 ? 2 : 0)) * 64) void rollout_multi_kernel(const RolloutArgs a)
+// SPLIT_ = false at ND = 4 ("multi4u"): six waves per workgroup -- four dynamics waves, ONE cost wave, one control
+// wave -- compiled for THREE waves per SIMD (<= 168 VGPRs), so that two workgroups share a CU: two dynamics waves
+// and one rider per SIMD.  For 64-wide nets beyond one group per SIMD (K > 16384): the eight-wave form needs 172
+// VGPRs = two waves per SIMD = ONE workgroup per CU, and a second round of workgroups simply doubles the time
+// (K=32768, T=150, 6-64-64-4: 0.547 ms = 2 x 0.272).
+template <int H, int NHID, int ND, bool SPLIT_ = (ND == 4)>
+__global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLIT_) ? 3 : 1) void rollout_multi_kernel(const RolloutArgs a)
 {
-  using SH = MultiShared<ND>;
+  using SH = MultiShared<ND, SPLIT_>;
   constexpr int NR = SH::NR;
   constexpr bool SPLIT = SH::SPLIT;
   // Roles: 0..ND-1 dynamics; then [pose,] cost, control.  With ND = 4 every SIMD of the CU carries a dynamics wave
@@ -226,7 +231,7 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 2 : 0)) * 64) void rollout_mul
   __syncthreads();
 
   if (role < ND) {
-    multi_dynamics<H, NHID, ND>(a, sh, role);
+    multi_dynamics<H, NHID, ND, SH>(a, sh, role);
   } else if (role == kCtl) {
     // -------------------------------- control wave: one lane per rollout --------------------------------
     const bool inl = a.inline_noise != 0;
@@ -500,7 +505,8 @@ __global__ __launch_bounds__((ND + 2 + (ND == 4 ? 2 : 0)) * 64) void rollout_mul
 template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
+  if (nd == 40) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, false>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
+  else if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
   else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
   else if (nd == 1) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
   else return hipErrorInvalidValue;
@@ -516,7 +522,7 @@ bool multi_variant_supported(int hidden, int n_hidden)
 
 hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (a.K % (16 * nd) != 0) return hipErrorInvalidValue;
+  if (a.K % (16 * (nd == 40 ? 4 : nd)) != 0) return hipErrorInvalidValue;  // nd = 40: ND = 4, six-wave form
   if (hidden == 32 && n_hidden == 2) return launch_multi_t<32, 2>(a, nd, stream);
   if (hidden == 64 && n_hidden == 2) return launch_multi_t<64, 2>(a, nd, stream);
   if (hidden == 32 && n_hidden == 4) return launch_multi_t<32, 4>(a, nd, stream);

@@ -9,10 +9,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "npz.hpp"
 #include "param_getter.hpp"
 #include "run_control_loop.hpp"
+#include "../csrc/host_net.hpp"
 
 using namespace mppi_host;
 
@@ -214,6 +216,30 @@ int main(int argc, char **argv)
     for (int i = 0; i < 7; i++) REQUIRE(model.state_der_[i] == 0.0f);
     model.computeKinematics(x); model.computeDynamics(x, us);
     for (int i = 0; i < 7; i++) REQUIRE(xs[i] == fmaf(model.state_der_[i], 0.02f, x[i]));
+  }
+  // --- HostNetFma (csrc/host_net.hpp: the AVX2 replay of computeNominalTraj, tanhf_vec.hpp inside) against the
+  //     scalar statement of the same arithmetic (NeuralNetModel::computeDynamics: k-ascending fmaf, + bias,
+  //     libm tanhf): 2000 steps of a driven trajectory, every output bit for bit ---
+  {
+    const float2_ rng[2] = {{-0.99f, 0.99f}, {-0.99f, 0.65f}};
+    NeuralNetModel model({6, 32, 32, 4}, 0.02f, rng);
+    model.loadParams(argv[1]);
+    mppi::HostNetFma net;
+    const int layers[4] = {6, 32, 32, 4};
+    net.init(layers, 4, model.packedParams().data());
+    REQUIRE(net.vec_tanh);  // tanhf8 equals this machine's libm (tanhf_vec_selfcheck)
+    float x[7] = {0.0f, 0.0f, 0.1f, 0.02f, 3.0f, 0.2f, -0.1f};
+    for (int t = 0; t < 2000; t++) {
+      float u[2] = {0.6f * sinf(0.013f * t), 0.4f + 0.3f * cosf(0.007f * t)};
+      const float in6[6] = {x[3], x[4], x[5], x[6], u[0], u[1]};
+      float out[4];
+      net.forward(in6, out);
+      model.computeDynamics(x, u);
+      for (int i = 0; i < 4; i++) REQUIRE(memcmp(&out[i], &model.state_der_[3 + i], 4) == 0);
+      model.computeKinematics(x);
+      for (int i = 0; i < 7; i++) x[i] = fmaf(model.state_der_[i], 0.02f, x[i]);
+    }
+    REQUIRE(std::fabs(x[4]) > 0.5f && std::isfinite(x[0]));
   }
   // --- MPPICosts: the non-caller public names (costs.cuh:170,186-191) and the list of bound controller handles ---
   {

@@ -399,11 +399,16 @@ def main():
             out["stage_ms"]["note"] = ("HIP events on the handle's stream, %d solves, separate pass after the timed region: markers around the "
                                        "noise and tail stages; the rollout stage is the begin / end of the rollout kernel's own dispatch "
                                        "(hipExtLaunchKernelGGL start / stop events: the quantity rocprofv3 --kernel-trace reports)" % n)
+            if variant.endswith("_gen") or "fused" in variant or variant.startswith("valu") or variant == "basis_funcs25_valu":
+                out["stage_ms"]["note"] += ("; noise_ms = the stand-alone generator kernel's launch (its own begin / end events): in the "
+                                            "prefetching forms it runs on a second stream BESIDE the rollout or the tail of the same "
+                                            "solve, so noise + rollout + tail is more than the step")
             traffic, traffic_file = measured_traffic(cfg, variant)
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, %s)" % traffic_file,
+                "traffic_unit": ("HBM bytes per launch (rocprofv3 PMC passes, %s)" % traffic_file) if traffic_file else
+                                "null: no committed PMC pass (tools/prof_run.sh -> profiles/) for this workload and kernel form",
                 "kernel": "rollout (%s)" % variant, "kernel_ms": rollout_s * 1e3,
                 "flop_per_state_update": fl, "state_updates_per_launch": K * T,
                 "algorithmic_bytes_per_launch": bpu * K * T,
