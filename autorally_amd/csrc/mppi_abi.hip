@@ -313,9 +313,12 @@ int effective_block(const mppi_handle *h)
   if (multi_variant_supported(h->hidden, h->n_hidden)) {
     if (groups <= cus) return 512;
     if (groups <= 2 * cus) return 1002;
-    // 64-wide nets beyond one group per SIMD: the six-wave form (168 VGPRs, three waves per SIMD: two workgroups
-    // = two dynamics waves + one rider per SIMD); the eight-wave form (172 VGPRs) fits one workgroup per CU only
-    if (h->hidden == 64 && groups > h->num_simds) return 1040;
+    // (64-wide nets beyond one group per SIMD: the eight-wave form needs 172 VGPRs = one workgroup per CU, so K = 32768
+    // runs in two rounds.  The six-wave form "multi4u" -- 168 VGPRs, three waves per SIMD, two workgroups per CU =
+    // two dynamics waves + one rider per SIMD -- was measured against it: K=32768, T=150, 6-64-64-4 0.584 ms vs
+    // 0.538 ms; K=16384 0.298 vs 0.272 ms.  Two f32-MFMA waves on one SIMD take the sum of their times (the f32
+    // MFMA occupies the vector datapath), so co-residence buys nothing and the single cost wave is the
+    // slower rider.  Not chosen automatically; kept as an A/B arm.)
     return 1004;
   }
   return (4 * groups <= h->num_simds) ? 512 : 256;
@@ -1336,15 +1339,18 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
   // n calls of mppi_compute_control_async would do.
   mppi_handle *h0 = hs[0];
   bool together = n >= 2 && n <= kMaxBatch;
-  int groups = 0;
+  int waves = 0;
   for (int i = 0; i < n && together; i++) {
     const mppi_handle *h = hs[i];
-    together = h->cfg.device == h0->cfg.device && !h->basis && use_mfma(h) && effective_block(h) == 512 &&
-               h->hidden == h0->hidden && h->n_hidden == h0->n_hidden && h->cfg.num_iters == h0->cfg.num_iters &&
+    // network model: the four-wavefront form; basis-function model: its three-wavefront form (in-kernel generator)
+    const bool form_ok = h->basis ? (h0->basis && bf_waves(h) == 3)
+                                  : (!h0->basis && use_mfma(h) && effective_block(h) == 512 &&
+                                     h->hidden == h0->hidden && h->n_hidden == h0->n_hidden);
+    together = form_ok && h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
                h->K <= 4096 && !h->timing && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
-    groups += h->K / kRolloutsPerWave;
+    waves += h->basis ? 3 * (h->K / 64) : 4 * (h->K / kRolloutsPerWave);
   }
-  together = together && groups <= h0->num_simds / 4;
+  together = together && waves <= h0->num_simds;  // every wave of every group still gets a SIMD of its own
   if (!together) {
     for (int i = 0; i < n; i++) {
       const int rc = mppi_compute_control_async(hs[i], states + (size_t)MPPI_STATE_DIM * i);
@@ -1391,7 +1397,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
         a.rng_out = h->d_rng[1 - h->rng_cur];
         h->rng_cur = 1 - h->rng_cur;
       }
-      qb.first[i + 1] = qb.first[i] + h->K / kRolloutsPerWave;
+      qb.first[i + 1] = qb.first[i] + (h->basis ? h->K / 64 : h->K / kRolloutsPerWave);
       tl[i] = tail_launch(h, noise, last);
       if (last) h->slid_valid = wants_slid_copy(h);
     }
@@ -1399,7 +1405,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
       qb.inst[i] = qb.inst[0];
       qb.first[i + 1] = qb.first[n];
     }
-    hipError_t e = launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
+    hipError_t e = h0->basis ? launch_rollout_bf_batch(qb, S) : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
     if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
     if (e != hipSuccess) return fail(h0, MPPI_ERR_HIP, "batched launch", e);
   }

@@ -59,6 +59,8 @@ hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const fl
 
 // rollout_bf.hip (GeneralizedLinear basis-function dynamics, W[4][25] in a.wpack)
 hipError_t launch_rollout_bf(const RolloutArgs &a, int waves, hipStream_t stream);  // waves per 64 rollouts: 1, 2, 3
+// several instances of the three-wave form in one launch (first[] in workgroups of 64 rollouts)
+hipError_t launch_rollout_bf_batch(const QuadBatchArgs &b, hipStream_t stream);
 hipError_t launch_dynamics_bf(const float *W, const float *states, const float *controls, float *ders, int n,
                               hipStream_t stream);
 

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(2 * kBfLanes) void rollout_bf2_kernel(const Rollout
 // nothing, mppi_controller.cu:160-177).  Same arithmetic, same order: bit-identical to the other two forms.
 //   roles: 0 dynamics, 1 cost, 2 control (a.fault_wave == role + 1: mppi_debug_inject_handover_fault)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const RolloutArgs a)
+// body of rollout_bf3_kernel for group `group` (64 rollouts) of instance `a`
+__device__ __forceinline__ void bf3_group(const RolloutArgs &a, const int group)
 {
   __shared__ __attribute__((aligned(16))) float W_s[4 * kNumBfs];  // transposed: [25][4]
   __shared__ float rec[kBfRing][8][kBfLanes];  // [slot][field][lane]: s3 s4 s5 s6 (dynamics) | u0 u1 du0 du1 (control)
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const Rollout
   for (int i = threadIdx.x; i < 4 * kNumBfs; i += 3 * kBfLanes) W_s[(i % kNumBfs) * 4 + i / kNumBfs] = a.wpack[i];
   if (role == 0) { pub[lane] = 0; cpub[lane] = 0; done[lane] = 0; fail[lane & 3] = 0; fin[lane & 3] = 0; }
   __syncthreads();  // the only barrier
-  const int k = blockIdx.x * kBfLanes + lane;
+  const int k = group * kBfLanes + lane;
   const int K = a.K, T = a.T;
   const uint32_t a_pub = lds_addr(&pub[0]), a_cpub = lds_addr(&cpub[0]), a_done = lds_addr(&done[0]);
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == role + 1);  // mppi_device.hpp
@@ -443,6 +444,19 @@ __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const Rollout
   }
 }
 
+__global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const RolloutArgs a) { bf3_group(a, (int)blockIdx.x); }
+
+// several instances in one launch (mppi_compute_control_batch: the two controllers of path_integral_bf's control
+// loop): workgroups [first[i], first[i+1]) run instance i
+__global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const QuadBatchArgs b)
+{
+  int i = 0;  // workgroup-uniform
+#pragma unroll
+  for (int q = 1; q < kMaxBatch; q++)
+    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
+  bf3_group(b.inst[i], (int)blockIdx.x - b.first[i]);
+}
+
 // test entry (mppi_debug_dynamics): state derivative of n independent (state, control) pairs
 __global__ __launch_bounds__(kBfLanes) void dynamics_bf_kernel(const float *W, const float *states,
                                                                const float *controls, float *ders, int n)
@@ -471,6 +485,13 @@ hipError_t launch_rollout_bf(const RolloutArgs &a, int waves, hipStream_t stream
   if (waves == 3) MPPI_LAUNCH_ROLLOUT(rollout_bf3_kernel, dim3(a.K / kBfLanes), dim3(3 * kBfLanes), 0, stream, a);
   else if (waves == 2) MPPI_LAUNCH_ROLLOUT(rollout_bf2_kernel, dim3(a.K / kBfLanes), dim3(2 * kBfLanes), 0, stream, a);
   else MPPI_LAUNCH_ROLLOUT(rollout_bf_kernel, dim3(a.K / kBfLanes), dim3(kBfLanes), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_rollout_bf_batch(const QuadBatchArgs &b, hipStream_t stream)
+{
+  if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rollout_bf3_batch_kernel, dim3(b.first[b.n]), dim3(3 * kBfLanes), 0, stream, b);
   return hipGetLastError();
 }
 

@@ -104,6 +104,36 @@ def test_batched_ticks_in_generator_mode_equal_separate_handles(shapes):
         s.close()
 
 
+def test_basis_function_controllers_share_a_launch_too(golden_dir):
+    """path_integral_bf's two controllers (K = 2560 each, three wavefronts per 64 rollouts: 240 waves): batched
+    ticks in generator mode follow stand-alone handles bit for bit."""
+    import os
+    W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    cfgs = [S.make_config(2560, 100, track="oval", bf_W=W, seed=5), S.make_config(2560, 100, track="oval", bf_W=W, seed=6)]
+    ref, bat = [capi.Solver(c) for c in cfgs], [capi.Solver(c) for c in cfgs]
+    assert all(s.rollout_variant() == "basis_funcs25_valu_3w" for s in bat)
+    states = [c["start_state"].copy() for c in cfgs]
+    states[1][0] += 0.5
+    for tick in range(5):
+        for s, st in zip(ref, states):
+            s.compute_control(st)
+        capi.compute_control_batch(bat, states)
+        for r, b in zip(ref, bat):
+            _same(b.get_results(), r.get_results())
+            r.slide_control_seq(1)
+            b.slide_control_seq(1)
+    # a mixed pair (network + basis functions) cannot share a kernel: per-handle solves, same results
+    mixed_cfg = S.make_config(1024, 100, track="oval")
+    m_ref, m_bat = capi.Solver(mixed_cfg), capi.Solver(mixed_cfg)
+    m_ref.compute_control(mixed_cfg["start_state"])
+    ref[0].compute_control(states[0])
+    capi.compute_control_batch([m_bat, bat[0]], [mixed_cfg["start_state"], states[0]])
+    _same(m_bat.get_results(), m_ref.get_results())
+    _same(bat[0].get_results(), ref[0].get_results())
+    for s in ref + bat + [m_ref, m_bat]:
+        s.close()
+
+
 def test_batch_then_single_then_batch_and_two_iterations():
     """Transitions between the batch stream and a handle's own stream (single solve, result vectors, applied
     controls, set_noise, seed) keep every handle's sequence of results; num_iters = 2 batches both iterations."""

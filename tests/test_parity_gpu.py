@@ -199,7 +199,7 @@ def test_quad_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
     np.testing.assert_array_equal(a["V"].view(np.uint32), c["V"].view(np.uint32))
     np.testing.assert_array_equal(a["U"].view(np.uint32), c["U"].view(np.uint32))
     # the multi form (ND dynamics waves + one cost wave + one control wave per 16 ND rollouts), ND = 4, 2, 1
-    for v in ("multi4", "multi2", "multi1"):
+    for v in ("multi4", "multi2", "multi1", "multi4u", "multi4u_gen"):
         _, m = _solve_both(cfg, U0=U0, variant=v)
         assert v in m["variant"]
         np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))

@@ -17,4 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- $B $PM > /dev/null 2> "$out/fetch.err" || { tail -5 "$out/fetch.err"; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -- $B $PM > /dev/null 2> "$out/write.err" || { tail -5 "$out/write.err"; exit 1; }
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/tcc" -- $B $PM > /dev/null 2> "$out/tcc.err" || { tail -5 "$out/tcc.err"; exit 1; }
-PROF_BENCH_JSON="$out/bench_trace.json" python3 tools/prof_summary.py pmc "$out/summary/pmc.json" "rocprofv3 --kernel-trace --pmc (4 separate passes: SQ set | FETCH_SIZE | WRITE_SIZE | TCC set) -- $B $PM" "$out/sq" "$out/fetch" "$out/write" "$out/tcc"
+# optional fifth pass: matrix-pipe counters (names differ between ROCm releases: skipped when the profiler refuses them)
+extra=""
+if rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CU_CYCLES --output-format csv -d "$out/mfma" -- $B $PM > /dev/null 2> "$out/mfma.err"; then extra="$out/mfma"; else echo "matrix-pipe counter pass skipped: $(tail -1 "$out/mfma.err")"; rm -rf "$out/mfma"; fi
+PROF_BENCH_JSON="$out/bench_trace.json" python3 tools/prof_summary.py pmc "$out/summary/pmc.json" "rocprofv3 --kernel-trace --pmc (4 separate passes: SQ set | FETCH_SIZE | WRITE_SIZE | TCC set) -- $B $PM" "$out/sq" "$out/fetch" "$out/write" "$out/tcc" $extra

@@ -57,13 +57,17 @@ __device__ __forceinline__ void phase_b(const float *costs, float *result)
   const int tid = threadIdx.x;
   float4 cv[4];
   const float4 *c4 = reinterpret_cast<const float4 *>(costs);
+  if (SC1) {  // four 16-B sc1 loads in flight, one wait: a single asm block, so that no use can slip in front of the wait
+    const float4 *p0 = c4 + tid, *p1 = p0 + THREADS, *p2 = p1 + THREADS, *p3 = p2 + THREADS;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float4 *p = c4 + i * THREADS + tid;
-    if (SC1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(cv[i]) : "v"(p) : "memory");
-    else cv[i] = *p;
+    for (int i = 0; i < 4; i++) cv[i] = c4[i * THREADS + tid];
   }
-  if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   float m = INFINITY;
 #pragma unroll
   for (int i = 0; i < 4; i++) m = fminf(fminf(m, fminf(cv[i].x, cv[i].y)), fminf(cv[i].z, cv[i].w));
