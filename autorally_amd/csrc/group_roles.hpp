@@ -56,7 +56,7 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
 {
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * kRolloutsPerWave + (lane & 15);
+  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + (lane & 15);
   const int K = a.K, T = a.T;
   const bool active = lane < kRolloutsPerWave;
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kRng + 1);
@@ -70,7 +70,11 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
     const uint32_t a_mypub = lds_addr(&sh.rng_pub[lane]);
     int seen = 0;
     for (int t = 0; t < T; t++) {
+#ifdef MPPI_DIAG_NORNG  // diagnostic build: the hand-overs without the generator steps (which rider paces the group?)
+      const float2 e = make_float2(0.25f + 0.001f * (float)t, 0.5f);
+#else
       const float2 e = active ? uniform_pair(gsta) : make_float2(0.5f, 0.5f);
+#endif
       // slot t % kGRing held step t - kGRing, consumed once the control wave has published that step
       const int need = t - kGRing + 1;
       while (seen < need && --budget > 0) {
@@ -89,16 +93,22 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
 }
 
 // ---------------------------------- control wave ----------------------------------
+// FOUR steps per iteration, one lane per (step, rollout): lane = 16 q + j works on step t0 + q of rollout j.  Nothing
+// of mppi_controller.cu:136-153 depends on the state or on the previous step, and a rider only gets the issue slots
+// its SIMD's dynamics wave leaves free: with one step per iteration on 16 lanes the Box-Muller chain (a division, a
+// square root, three polynomials: ~100 dependent instructions) made this wave the pace of the whole group (row form,
+// K=4096, T=100: 68.7 us; 55.6 us with the transform removed).  Per step it now issues a quarter of that.
 template <class SH>
 __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
 {
   using R = GroupRoles<SH>;
   constexpr int NSW = SH::NSW;
+  static_assert(kGCtlChunk == 4 && kGRing >= 2 * kGCtlChunk, "four steps per iteration, lanes 16 q + j");
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * kRolloutsPerWave + (lane & 15);
+  const int j = lane & 15, q = lane >> 4;
+  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
   const bool inl = a.inline_noise != 0;
-  const bool active = lane < kRolloutsPerWave;
   float2 *const noise = reinterpret_cast<float2 *>(a.noise);
   const float2 *const Useq = reinterpret_cast<const float2 *>(a.U);
   const bool noise_free_k = (k == 0);      // mppi_controller.cu:136
@@ -109,53 +119,51 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kCtl + 1);
   int seen_x = 0, seen_c = 0, seen_r = 0;  // swaps published by all dynamics waves / steps consumed by the cost wave / pairs drawn
   for (int t0 = 0; t0 < T; t0 += kGCtlChunk) {
-    // the chunk's nominal controls and (explicit noise) eps are requested together
-    float2 Uq[kGCtlChunk], eq[kGCtlChunk];
-#pragma unroll
-    for (int q = 0; q < kGCtlChunk; q++) {
-      const int tq = min(t0 + q, T - 1);
-      Uq[q] = Useq[tq];
-      eq[q] = (active && !inl) ? noise[(size_t)tq * K + k] : make_float2(0.0f, 0.0f);
+    const int t = t0 + q;
+    const bool live = t < T;
+    const int tl = live ? t : T - 1;
+    // this lane's nominal control and (explicit noise) eps
+    const float2 Ut = Useq[tl];
+    float2 e = (live && !inl) ? noise[(size_t)tl * K + k] : make_float2(0.0f, 0.0f);
+    // the last slot of the chunk: slot t % kGRing held step t - kGRing -- the dynamics waves read it during step
+    // t - kGRing - 1 (done once all of them published the first swap of step t - kGRing), the cost wave in step t - kGRing
+    const int tm = min(t0 + kGCtlChunk, T) - 1;
+    const int need_x = (tm >= kGRing) ? (tm - kGRing) * NSW + 1 : 0;
+    const int need_c = tm - kGRing + 1;
+    while ((seen_x < need_x || seen_c < need_c) && --budget > 0) {
+      seen_x = group_seq_min(sh);
+      seen_c = lds_peek(a_cd);
+      if (seen_x < need_x || seen_c < need_c) __builtin_amdgcn_s_sleep(2);
     }
-#pragma unroll
-    for (int q = 0; q < kGCtlChunk; q++) {
-      const int t = t0 + q;
-      if (t < T) {
-        // slot t % kGRing held step t - kGRing: the dynamics waves read it during step t - kGRing - 1 (done
-        // once all of them published the first swap of step t - kGRing), the cost wave in step t - kGRing
-        const int need_x = (t >= kGRing) ? (t - kGRing) * NSW + 1 : 0;
-        const int need_c = t - kGRing + 1;
-        while ((seen_x < need_x || seen_c < need_c) && --budget > 0) {
-          seen_x = group_seq_min(sh);
-          seen_c = lds_peek(a_cd);
-          if (seen_x < need_x || seen_c < need_c) __builtin_amdgcn_s_sleep(2);
-        }
-        float2 e = eq[q];
-        if (inl) {  // generator mode: the pair of step t from the noise wave's ring
-          while (seen_r < t + 1 && --budget > 0) {
-            seen_r = lds_peek(a_rng);
-            if (seen_r < t + 1) __builtin_amdgcn_s_sleep(1);
-          }
-          e = box_muller(*reinterpret_cast<const float2 *>(&sh.eps[t & (kGRing - 1)][lane & 15][0]));
-        }
-        if (active) {
-          // control perturbation, mppi_controller.cu:136-153
-          const bool nf = noise_free_k | (t < a.opt_delay);
-          const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
-          const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
-          float u0 = nf ? Uq[q].x : (pure_noise_k ? n0 : Uq[q].x + n0);
-          float u1 = nf ? Uq[q].y : (pure_noise_k ? n1 : Uq[q].y + n1);
-          noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
-          u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
-          u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
-          const int slot = t & (kGRing - 1);
-          sh.ctl_b1[slot][lane] = u0;
-          sh.ctl_b1[slot][kRolloutsPerWave + lane] = u1;
-          *reinterpret_cast<float4 *>(&sh.ctl_rec[slot][lane][0]) = make_float4(u0, u1, du0, du1);
-        }
-        lds_publish(a_mypub, t + 1);  // after the read of eps(t): releases that slot to the noise wave
+    if (inl) {  // generator mode: the pairs of the chunk's steps from the noise wave's ring
+      while (seen_r < tm + 1 && --budget > 0) {
+        seen_r = lds_peek(a_rng);
+        if (seen_r < tm + 1) __builtin_amdgcn_s_sleep(1);
       }
+#ifdef MPPI_DIAG_NOBM  // diagnostic build: no Box-Muller
+      e = *reinterpret_cast<const float2 *>(&sh.eps[tl & (kGRing - 1)][j][0]);
+#else
+      e = box_muller(*reinterpret_cast<const float2 *>(&sh.eps[tl & (kGRing - 1)][j][0]));
+#endif
     }
+    if (live) {
+      // control perturbation, mppi_controller.cu:136-153
+      const bool nf = noise_free_k | (t < a.opt_delay);
+      const float n0 = e.x * a.nu[0], n1 = e.y * a.nu[1];
+      const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
+      float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
+      float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
+      noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+      u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
+      u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
+      const int slot = t & (kGRing - 1);
+      sh.ctl_b1[slot][j] = u0;
+      sh.ctl_b1[slot][kRolloutsPerWave + j] = u1;
+      *reinterpret_cast<float4 *>(&sh.ctl_rec[slot][j][0]) = make_float4(u0, u1, du0, du1);
+    }
+    // after the reads of eps(t0 .. tm) and the records of all four steps (the LDS runs a wave's instructions in order):
+    // releases those eps slots to the noise wave
+    lds_publish(a_mypub, tm + 1);
   }
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kCtl]));
 }
@@ -180,16 +188,22 @@ __device__ __forceinline__ void group_pose_wave(const RolloutArgs &a, SH &sh)
   for (int t = 0; t <= T; t++) {
     float tf = 0.0f, tb = 0.0f;
     if (t < T) {
-      const int need = t * NSW + 1;  // rec(t) is written before wave 0 publishes the first swap of step t
+      // rec(t) is written before wave 0 publishes the first swap of step t (forms whose dynamics waves each write
+      // the records of their own rollouts, SH::kRecByAll: before every one of them has published step t)
+      const int need = t * NSW + 1;
       while (seen < need && --budget > 0) {
-        seen = lds_peek(a_seq0);
+        seen = SH::kRecByAll ? group_seq_min(sh) : lds_peek(a_seq0);
         if (seen < need) __builtin_amdgcn_s_sleep(1);
       }
       const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kGRing - 1)][j][0]);  // s3 s4 s5 s6
       float spsi, cpsi;
+#ifdef MPPI_DIAG_NOPOSE  // diagnostic build: no sin/cos, no texel fetches
+      spsi = 0.0f; cpsi = 1.0f; tf = x; tb = y;
+#else
       sincos_fast(yaw, spsi, cpsi);
       const float st[3] = {x, y, yaw};
       track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
+#endif
       // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
       const float sd0 = fmaf(cpsi, r0.y, -(spsi * r0.z));
       const float sd1 = fmaf(spsi, r0.y, cpsi * r0.z);
@@ -237,7 +251,7 @@ __device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
-  const int k = blockIdx.x * kRolloutsPerWave + j;
+  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
   const int T = a.T;
   const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
   const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
@@ -256,6 +270,11 @@ __device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
     const float2 tx = *reinterpret_cast<const float2 *>(&sh.tex[t & (kGRing - 1)][j][0]);      // front, back texel
     lds_publish(a_mydone, t + 1);  // executes after the three reads (the LDS runs a wave's instructions in order)
     const int rc = (int)((t > 0) & (fabsf(r0.x) >= kRollCrash));  // getCrash of update t-1
+#ifdef MPPI_DIAG_NOCOST  // diagnostic build: no cost arithmetic
+    crash |= rc;
+    int crash_new = crash;
+    const float Jn = J + r0.y + r1.x + tx.x + (float)rt;
+#else
     CostTerms ct;
     cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
     // running mean over 1..T-1 (Q5); the t = 0 evaluation is discarded
@@ -263,6 +282,7 @@ __device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
     int crash_new = crash;
     const float c = cost_terms_b(a.cost, ct, tx.x, tx.y, crash_new);
     const float Jn = running_mean(J, c, t, rt);
+#endif
     J = (t > 0) ? Jn : J;
     crash = (t > 0) ? crash_new : crash;
   }

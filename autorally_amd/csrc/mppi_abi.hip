@@ -311,6 +311,10 @@ int effective_block(const mppi_handle *h)
   const int cus = h->num_simds / 4;
   if (groups <= 2 * cus && oct_variant_supported(h->hidden, h->n_hidden)) return 800;
   if (multi_variant_supported(h->hidden, h->n_hidden)) {
+    // 6-32-32-4 at one group per CU: the vector-ALU ROW form (rollout_row.hip) -- the shortest recurrence of all
+    // (K=4096, T=100: 56.8 us; quad 68.2 us)
+    // ("mfma" asked for explicitly -- the A/B arm of SURVEY cfg 4 -- keeps the matrix-instruction forms)
+    if (groups <= cus && row_variant_supported(h->hidden, h->n_hidden) && h->variant_pref != 1) return 900;
     if (groups <= cus) return 512;
     if (groups <= 2 * cus) return 1002;
     // (64-wide nets beyond one group per SIMD: the eight-wave form needs 172 VGPRs = one workgroup per CU, so K = 32768
@@ -348,7 +352,7 @@ bool has_noise_wave(const mppi_handle *h)
   if (h->basis) return bf_waves(h) == 3;
   if (!use_mfma(h)) return false;
   const int b = effective_block(h);
-  return b == 512 || ((b == 800 || b > 1000) && !multi_gen(h));
+  return b == 512 || b == 900 || ((b == 800 || b > 1000) && !multi_gen(h));
 }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
@@ -387,7 +391,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.U = h->d_in;
   a.noise = noise;
   a.costs = h->d_costs;
-  a.wpack = use_mfma(h) ? h->d_wpack : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
+  a.wpack = use_mfma(h) ? (effective_block(h) == 900 ? h->d_theta_s : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
   a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
@@ -405,6 +409,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.inline_noise = 0;
   a.spin_budget = h->spin_budget;
   a.fault_wave = h->fault_wave;
+  a.group0 = 0;
   fill_cost_args(h, a.cost);
 }
 
@@ -415,6 +420,7 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
                  : (use_mfma(h) && effective_block(h) > 1000)
                      ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
                  : (use_mfma(h) && effective_block(h) == 800) ? launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream)
+                 : (use_mfma(h) && effective_block(h) == 900) ? launch_rollout_row(h->hidden, h->n_hidden, a, h->stream)
                  : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
                                    : launch_rollout_valu(h->net, a, h->stream);
@@ -1344,10 +1350,13 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     const mppi_handle *h = hs[i];
     // network model: the four-wavefront form; basis-function model: its three-wavefront form (in-kernel generator)
     const bool form_ok = h->basis ? (h0->basis && bf_waves(h) == 3)
-                                  : (!h0->basis && use_mfma(h) && effective_block(h) == 512 &&
+                                  : (!h0->basis && use_mfma(h) && use_mfma(h0) &&
+                                     (effective_block(h) == 512 || effective_block(h) == 900) &&
+                                     effective_block(h) == effective_block(h0) &&
                                      h->hidden == h0->hidden && h->n_hidden == h0->n_hidden);
     together = form_ok && h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
                h->K <= 4096 && !h->timing && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
+    // waves of a group that need a SIMD each: quad 4, row 4 dynamics waves (its riders ride), basis functions 3
     waves += h->basis ? 3 * (h->K / 64) : 4 * (h->K / kRolloutsPerWave);
   }
   together = together && waves <= h0->num_simds;  // every wave of every group still gets a SIMD of its own
@@ -1397,6 +1406,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
         a.rng_out = h->d_rng[1 - h->rng_cur];
         h->rng_cur = 1 - h->rng_cur;
       }
+      a.group0 = qb.first[i];
       qb.first[i + 1] = qb.first[i] + (h->basis ? h->K / 64 : h->K / kRolloutsPerWave);
       tl[i] = tail_launch(h, noise, last);
       if (last) h->slid_valid = wants_slid_copy(h);
@@ -1405,7 +1415,9 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
       qb.inst[i] = qb.inst[0];
       qb.first[i + 1] = qb.first[n];
     }
-    hipError_t e = h0->basis ? launch_rollout_bf_batch(qb, S) : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
+    hipError_t e = h0->basis ? launch_rollout_bf_batch(qb, S)
+                   : effective_block(h0) == 900 ? launch_rollout_row_batch(qb, S)
+                                                : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
     if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
     if (e != hipSuccess) return fail(h0, MPPI_ERR_HIP, "batched launch", e);
   }
@@ -1690,6 +1702,8 @@ const char *mppi_rollout_variant(const mppi_handle *h)
   else if (b > 1000)
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi%d%s", h->hidden, h->n_hidden, b - 1000,
              multi_gen(h) ? "_gen" : "");
+  else if (b == 900)
+    snprintf(buf, sizeof(buf), "valu_row8w_h%d_l%d", h->hidden, h->n_hidden);
   else
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
              b == 512 ? "quad4w" : b == 800 ? (multi_gen(h) ? "oct8w_gen" : "oct8w") : (b == 256 ? "fused_b256" : "fused_b64"));
@@ -1712,6 +1726,11 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   else if (strcmp(name, "bf3") == 0) {
     if (!h->basis) return fail(h, MPPI_ERR_UNSUPPORTED, "bf3 is a form of the basis-function model");
     h->block_threads = 768;
+  }
+  else if (strcmp(name, "row") == 0) {
+    if (!h->mfma_ok || !row_variant_supported(h->hidden, h->n_hidden))
+      return fail(h, MPPI_ERR_UNSUPPORTED, "row form exists for 6-32x2-4");
+    h->block_threads = 900;
   }
   else if (strcmp(name, "oct") == 0 || strcmp(name, "oct_gen") == 0) {
     if (!h->mfma_ok || !oct_variant_supported(h->hidden, h->n_hidden))

@@ -53,6 +53,9 @@ struct RolloutArgs {
   // and -- tests only -- the wavefront role (1-based, 0 = none) that starts with that budget exhausted
   // (mppi_debug_inject_handover_fault)
   int spin_budget, fault_wave;
+  // first workgroup of this instance inside a batched launch (kernels built on group_roles.hpp index their rollouts
+  // by blockIdx.x - group0); 0 in a stand-alone launch
+  int group0;
   CostArgs cost;
 };
 

@@ -1,0 +1,259 @@
+// rollout_row.hip -- rolloutKernel (PI/mppi_controller.cu:72-184) for gfx950, the LATENCY form of 32-wide nets:
+// the network on the VECTOR ALU, four rollouts per dynamics wavefront, four dynamics wavefronts + the four riders of
+// group_roles.hpp (pose -> cost, noise -> control) per 16 rollouts.  Used while every group has a CU of its own
+// (K <= 16 x #CUs: BASELINE configs 1-3, the reference's K = 1920).
+//
+// Why not the matrix instruction here: at one group per CU the T-step recurrence is a latency chain, and a dependent
+// k-step of v_mfma_f32_16x16x4_f32 costs ~8 cycles (4 k per 32-cycle instruction), so a 32-input layer
+// is 8 x 33 = 264 cycles on top of a hand-over between the two waves that share the layer (the quad form: ~1 530
+// cycles per step).  A dependent v_pk_fma_f32 also issues every 8 cycles but carries TWO neurons and needs no partner:
+//   * one dynamics wave = 4 rollouts x 16 lanes; lane (r, p) owns neurons 2p, 2p+1 of every hidden layer of rollout r
+//     (outputs 2(p&1), 2(p&1)+1 of the last layer), their weights in registers as pairs;
+//   * a layer = per lane the k-ascending fmaf chain of mppi_controller.cu's dot product (neural_net_model.cu:379-394;
+//     bias afterwards) -- bit-identical to every other form -- with the activation a_k broadcast to both halves of the
+//     packed multiply-add (op_sel);
+//   * the activations of a layer go through LDS inside the wave: one 8-B write per lane, eight 16-B reads per lane that
+//     are broadcasts within the 16 lanes of a rollout.  No other wave is involved: no sequence word, no poll, no
+//     barrier on the recurrence (tools/ub/row_lds_ub.hip: 1 154 cycles per step alone on a SIMD);
+//   * state records, controls, texels, noise: the rings and riders of group_roles.hpp, one rider per SIMD beside one
+//     dynamics wave.
+#include "group_roles.hpp"
+#include "mppi_kernels.hpp"
+
+namespace mppi {
+
+template <int H>
+struct RowShared {
+  static constexpr int NW = 4;            // dynamics waves per group, four rollouts each
+  static constexpr int NSW = 1;           // xseq[w] = steps published by dynamics wave w
+  static constexpr bool kRecByAll = true; // every dynamics wave writes the state records of its own rollouts
+  int xseq[NW][64];
+  float rec[kGRing][kRolloutsPerWave][4];   // s3..s6 before the update of step t; also the layer-0 input of that step
+  int cost_done[64];
+  float ctl_b1[kGRing][64];
+  float ctl_rec[kGRing][kRolloutsPerWave][4];
+  int ctl_pub[64];
+  float tex[kGRing][kRolloutsPerWave][2];
+  int pose_pub[64];
+  float eps[kGRing][kRolloutsPerWave][2];
+  int rng_pub[64];
+  int fail[4];
+  int fin[8];
+  float act[NW][2][4][H];                   // per dynamics wave: activations of layer 0 / layer 1 of its four rollouts
+};
+
+template <int H>
+struct RowWeights {
+  f32x2 w1[kNetIn], w2[H], w3[H];
+  f32x2 b1s, b2s, b3;  // hidden biases pre-scaled for tanh_bias2 (theta_s of the register VALU kernel)
+};
+
+// theta_s: packed [W1|b1|W2|b2|W3|b3] (neural_net_model.cu:120-141), hidden biases already times kTanhScale
+template <int H>
+__device__ __forceinline__ void row_load(const float *theta_s, int p, RowWeights<H> &W)
+{
+  const float *W1 = theta_s, *B1 = W1 + H * kNetIn, *W2 = B1 + H, *B2 = W2 + H * H, *W3 = B2 + H, *B3 = W3 + kNetOut * H;
+  const int j0 = 2 * p, j1 = 2 * p + 1, o0 = 2 * (p & 1), o1 = o0 + 1;
+#pragma unroll
+  for (int k = 0; k < kNetIn; k++) W.w1[k] = f32x2{W1[j0 * kNetIn + k], W1[j1 * kNetIn + k]};
+#pragma unroll
+  for (int q = 0; q < H / 4; q++) {
+    const float4 r0 = *reinterpret_cast<const float4 *>(W2 + j0 * H + 4 * q), r1 = *reinterpret_cast<const float4 *>(W2 + j1 * H + 4 * q);
+    W.w2[4 * q + 0] = f32x2{r0.x, r1.x}; W.w2[4 * q + 1] = f32x2{r0.y, r1.y};
+    W.w2[4 * q + 2] = f32x2{r0.z, r1.z}; W.w2[4 * q + 3] = f32x2{r0.w, r1.w};
+    const float4 q0 = *reinterpret_cast<const float4 *>(W3 + o0 * H + 4 * q), q1 = *reinterpret_cast<const float4 *>(W3 + o1 * H + 4 * q);
+    W.w3[4 * q + 0] = f32x2{q0.x, q1.x}; W.w3[4 * q + 1] = f32x2{q0.y, q1.y};
+    W.w3[4 * q + 2] = f32x2{q0.z, q1.z}; W.w3[4 * q + 3] = f32x2{q0.w, q1.w};
+  }
+  W.b1s = f32x2{B1[j0], B1[j1]};
+  W.b2s = f32x2{B2[j0], B2[j1]};
+  W.b3 = f32x2{B3[o0], B3[o1]};
+}
+
+// z = sum_k w[k] * a[k], k ascending, one fmaf per k and neuron (the pair shares a[k])
+template <int N>
+__device__ __forceinline__ f32x2 row_dot(const f32x2 (&w)[N], const float4 (&v)[N / 4])
+{
+  f32x2 z = {0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < N / 4; q++) {
+    z = __builtin_elementwise_fma(w[4 * q + 0], f32x2{v[q].x, v[q].x}, z);
+    z = __builtin_elementwise_fma(w[4 * q + 1], f32x2{v[q].y, v[q].y}, z);
+    z = __builtin_elementwise_fma(w[4 * q + 2], f32x2{v[q].z, v[q].z}, z);
+    z = __builtin_elementwise_fma(w[4 * q + 3], f32x2{v[q].w, v[q].w}, z);
+  }
+  return z;
+}
+
+template <int H>
+__device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> &sh, const int w)
+{
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 4, p = lane & 15;
+  const int jr = 4 * w + r;  // rollout of the group
+  const int T = a.T;
+  RowWeights<H> W;
+  row_load<H>(a.wpack, p, W);
+  // pinned: the waits for the weight loads sit here, not at their first use inside the T loop
+#pragma unroll
+  for (int k = 0; k < H; k++) { asm volatile("" : "+v"(W.w2[k])); asm volatile("" : "+v"(W.w3[k])); }
+
+  const uint32_t a_myseq = lds_addr(&sh.xseq[w][lane]);
+  typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
+  const lds_int_p p_pub = (lds_int_p)&sh.ctl_pub[0];
+  const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
+  float(*act0)[H] = sh.act[w][0];
+  float(*act1)[H] = sh.act[w][1];
+
+  // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p
+  f32x2 sp = (p & 1) ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
+  while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+
+  // Steps 0 .. T-2 in full; of step T-1 only the state record goes out (its update feeds nothing: the cost is the
+  // running mean over the states BEFORE the updates of steps 1..T-1, mppi_controller.cu:160-177)
+  for (int t = 0; t < T - 1; t++) {
+    const int slot = t & (kGRing - 1);
+    // record for the pose / cost waves = the layer-0 input of this step: the state BEFORE the update (the ring slot
+    // was checked at the end of the previous step)
+    if (p < 2) *reinterpret_cast<f32x2 *>(&sh.rec[slot][jr][2 * p]) = sp;
+    __builtin_amdgcn_wave_barrier();
+    const float4 s = *reinterpret_cast<const float4 *>(&sh.rec[slot][jr][0]);
+    const float2 u = *reinterpret_cast<const float2 *>(&sh.ctl_rec[slot][jr][0]);  // clamped u0, u1 (control wave)
+    // published AFTER the read of ctl(t) was issued (the LDS runs a wave's instructions in order): the record of step t
+    // is there, and this wave is done with the control record of step t
+    lds_publish(a_myseq, t + 1);
+    // layer 0: [s3, s4, s5, s6, u0, u1]
+    f32x2 z = {0.0f, 0.0f};
+    z = __builtin_elementwise_fma(W.w1[0], f32x2{s.x, s.x}, z);
+    z = __builtin_elementwise_fma(W.w1[1], f32x2{s.y, s.y}, z);
+    z = __builtin_elementwise_fma(W.w1[2], f32x2{s.z, s.z}, z);
+    z = __builtin_elementwise_fma(W.w1[3], f32x2{s.w, s.w}, z);
+    z = __builtin_elementwise_fma(W.w1[4], f32x2{u.x, u.x}, z);
+    z = __builtin_elementwise_fma(W.w1[5], f32x2{u.y, u.y}, z);
+    *reinterpret_cast<f32x2 *>(&act0[r][2 * p]) = tanh_bias2(z, W.b1s);
+    __builtin_amdgcn_wave_barrier();
+    // requested now, used at the end of the step: the control wave's count and the cost wave's progress
+    const int cp_v = *p_pub, cd_v = *p_cd;
+    {
+      float4 v[H / 4];
+#pragma unroll
+      for (int q = 0; q < H / 4; q++) v[q] = *reinterpret_cast<const float4 *>(&act0[r][4 * q]);
+      *reinterpret_cast<f32x2 *>(&act1[r][2 * p]) = tanh_bias2(row_dot<H>(W.w2, v), W.b2s);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      float4 v[H / 4];
+#pragma unroll
+      for (int q = 0; q < H / 4; q++) v[q] = *reinterpret_cast<const float4 *>(&act1[r][4 * q]);
+      const f32x2 d = row_dot<H>(W.w3, v) + W.b3;
+      sp = __builtin_elementwise_fma(d, f32x2{a.dt, a.dt}, sp);  // incrementState, neural_net_model.cu:334-344
+    }
+    // step t+1 may start when the control wave has published it (it runs ahead) and the ring slot of its state record
+    // is free: that slot held step t+1 - kGRing, consumed once cost_done >= t+2 - kGRing
+    const int want = t + 2, want_cd = t + 2 - kGRing;
+    int cp = __builtin_amdgcn_readfirstlane(cp_v), cd = __builtin_amdgcn_readfirstlane(cd_v);
+    while (((cp < want) | (cd < want_cd)) && --budget > 0) {
+      cp = __builtin_amdgcn_readfirstlane(*p_pub);
+      cd = __builtin_amdgcn_readfirstlane(*p_cd);
+    }
+  }
+  {  // the record of step T-1
+    const int t = T - 1;
+    if (p < 2) *reinterpret_cast<f32x2 *>(&sh.rec[t & (kGRing - 1)][jr][2 * p]) = sp;
+    __builtin_amdgcn_wave_barrier();
+    lds_publish(a_myseq, t + 1);
+  }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
+}
+
+template <int H, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
+{
+  using SH = RowShared<H>;
+  using R = GroupRoles<SH>;
+  __shared__ __attribute__((aligned(16))) SH sh;
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (role == 0) {  // sequence words start at 0; the only barrier
+#pragma unroll
+    for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
+    sh.cost_done[lane] = 0;
+    sh.ctl_pub[lane] = 0;
+    sh.pose_pub[lane] = 0;
+    sh.rng_pub[lane] = 0;
+    sh.fail[lane & 3] = 0;
+    sh.fin[lane & 7] = 0;
+  }
+  __syncthreads();
+  if (role < 4) row_dynamics<H>(a, sh, role);
+  else if (role == R::kCost) group_cost_wave<SH, CTRL>(a, sh);
+  else if (role == R::kCtl) group_control_wave(a, sh);
+  else if (role == R::kPose) group_pose_wave<SH, AFFINE>(a, sh);
+  else group_rng_wave(a, sh);
+}
+
+// several instances in one launch (mppi_compute_control_batch): workgroups [first[i], first[i+1]) run instance i, whose
+// argument block carries group0 = first[i]
+template <int H, bool AFFINE, bool CTRL>
+__global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchArgs b)
+{
+  using SH = RowShared<H>;
+  using R = GroupRoles<SH>;
+  __shared__ __attribute__((aligned(16))) SH sh;
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int i = 0;  // workgroup-uniform
+#pragma unroll
+  for (int q = 1; q < kMaxBatch; q++)
+    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
+  const RolloutArgs &a = b.inst[i];
+  if (role == 0) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
+    sh.cost_done[lane] = 0;
+    sh.ctl_pub[lane] = 0;
+    sh.pose_pub[lane] = 0;
+    sh.rng_pub[lane] = 0;
+    sh.fail[lane & 3] = 0;
+    sh.fin[lane & 7] = 0;
+  }
+  __syncthreads();
+  if (role < 4) row_dynamics<H>(a, sh, role);
+  else if (role == R::kCost) group_cost_wave<SH, CTRL>(a, sh);
+  else if (role == R::kCtl) group_control_wave(a, sh);
+  else if (role == R::kPose) group_pose_wave<SH, AFFINE>(a, sh);
+  else group_rng_wave(a, sh);
+}
+
+bool row_variant_supported(int hidden, int n_hidden) { return hidden == 32 && n_hidden == 2; }
+
+hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream)
+{
+  if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;
+  bool affine = true, ctrl = false;  // the general forms are exact supersets (rollout_mfma.hip)
+  for (int i = 0; i < b.n; i++) {
+    affine = affine && b.inst[i].cost.affine != 0;
+    ctrl = ctrl || b.inst[i].cost.need_control_cost != 0;
+  }
+  const dim3 grid(b.first[b.n]), block(512);
+  if (affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, false>), grid, block, 0, stream, b);
+  else if (affine && ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, true>), grid, block, 0, stream, b);
+  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, false>), grid, block, 0, stream, b);
+  else hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, true>), grid, block, 0, stream, b);
+  return hipGetLastError();
+}
+
+hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream)
+{
+  if (!row_variant_supported(hidden, n_hidden) || a.K % kRolloutsPerWave != 0) return hipErrorInvalidValue;
+  const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
+  const dim3 grid(a.K / kRolloutsPerWave), block(512);
+  if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, true, false>), grid, block, 0, stream, a);
+  else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, true, true>), grid, block, 0, stream, a);
+  else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, false, false>), grid, block, 0, stream, a);
+  else MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, false, true>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace mppi

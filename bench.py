@@ -392,7 +392,7 @@ def main():
             fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            inline_noise = (("quad" in variant or "oct8w" in variant or "multi" in variant) and not variant.endswith("_gen")) \
+            inline_noise = (("quad" in variant or "oct8w" in variant or "row8w" in variant or "multi" in variant) and not variant.endswith("_gen")) \
                 or variant.endswith("_3w")  # the kernel's own noise / control wavefront draws eps
             bpu = ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
@@ -415,6 +415,20 @@ def main():
                 "algorithmic_GBps": bpu * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
             }
+            if "row8w" in variant:
+                # The latency form on the vector ALU (rollout_row.hip): no MFMA is issued; the f32 vector peak with packed
+                # multiply-adds equals the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), so the roofline block keeps
+                # that ceiling.  The configuration is latency bound: cycles per step against the recurrence of one dynamics
+                # wavefront alone on a SIMD (tools/ub/row_lds_ub.hip: 70 dependent v_pk_fma_f32 at 8 cycles, two tanh, three
+                # LDS round trips = 1 154 cycles).
+                clk_ghz = 2.3
+                cyc = rollout_s / T * clk_ghz * 1e9
+                out["roofline"]["pipe"] = "vector ALU (v_pk_fma_f32), no MFMA issued; f32 vector peak = f32 MFMA peak"
+                out["roofline"]["recurrence"] = {
+                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": 1154.0, "frac_of_floor": 1154.0 / cyc if cyc > 0 else 0.0,
+                    "clock_GHz": clk_ghz,
+                    "note": "event-measured kernel time / T (launch, prologue and riders included) against one dynamics wavefront's "
+                            "recurrence measured alone on a SIMD (tools/ub/row_lds_ub.hip)"}
             if "quad" in variant and cfg.get("bf_W") is None:
                 # The configuration is latency bound (one 16-rollout group per CU, T sequential steps), so next
                 # to the throughput roofline: the step time of the recurrence against (a) what its two dynamics

@@ -167,7 +167,7 @@ def test_edge_sizes(K, T):
     eps = noise_for(cfg)
     U0 = warm_U(cfg)
     ref = O.Oracle(cfg).compute_control(cfg["start_state"], U0, np.zeros(4, np.float32), eps)
-    for variant in ("quad", "fused", "valu"):
+    for variant in ("row", "quad", "fused", "valu"):
         sol = capi.Solver(cfg)
         sol.set_rollout_variant(variant)
         sol.set_control_seq(U0)
@@ -317,7 +317,8 @@ def test_control_ticks_equals_the_call_by_call_loop():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
+@pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2),
+                                         ("row", 1), ("row", 2), ("row", 3), ("row", 4), ("row", 5), ("row", 6), ("row", 7), ("row", 8), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
                                          ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7), ("multi4", 8),
                                          ("multi2", 2), ("multi2", 3), ("multi2", 4),
                                          ("multi4u", 3), ("multi4u", 5), ("multi4u", 6),
@@ -342,7 +343,7 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
         sol.set_rollout_variant("quad")  # dynamics + cost wave; "bf": + control wave (the automatic choice)
     elif family != "bf":  # multi form: roles 1..ND = dynamics waves, then [pose wave (ND = 4),] cost wave, control wave[, fetch wave (ND = 4)];
         # oct form: 1..4 dynamics, 5 pose, 6 cost, 7 control, 8 noise wave
-        sol.set_rollout_variant(family if family.startswith(("multi", "oct")) else "quad")
+        sol.set_rollout_variant(family if family.startswith(("multi", "oct", "row")) else "quad")
     sol.compute_control(cfg["start_state"])          # healthy
     good = sol.get_results()
     assert np.all(np.isfinite(good["costs"])) and np.all(np.isfinite(good["U"]))

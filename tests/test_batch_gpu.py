@@ -70,9 +70,12 @@ def test_two_controllers_one_launch_equal_their_own_solves_and_the_oracle():
     [(1024, 50, [6, 64, 64, 4]), (1024, 50, [6, 64, 64, 4])],        # a 64-wide net forced into the quad form
     [(640, 33, None), (640, 33, None), (640, 33, None), (640, 33, None)],
 ])
-def test_batched_ticks_in_generator_mode_equal_separate_handles(shapes):
+@pytest.mark.parametrize("form", ["quad", "row"])
+def test_batched_ticks_in_generator_mode_equal_separate_handles(shapes, form):
     """Six ticks of solve + slide per controller, device generators, asynchronous batch + per-handle collection:
     the batched controllers follow stand-alone controllers bit for bit (control sequence, history, costs)."""
+    if form == "row" and any(layers for _, _, layers in shapes):
+        pytest.skip("the row form exists for 6-32-32-4")
     cfgs = []
     for i, (K, T, layers) in enumerate(shapes):
         kw = {}
@@ -85,7 +88,7 @@ def test_batched_ticks_in_generator_mode_equal_separate_handles(shapes):
         cfgs.append(S.make_config(K, T, track="oval", instance=i, seed=77 + i, cost=cost, **kw))
     ref, bat = [capi.Solver(c) for c in cfgs], [capi.Solver(c) for c in cfgs]
     for s in ref + bat:
-        s.set_rollout_variant("quad")
+        s.set_rollout_variant(form)
     states = [c["start_state"].copy() for c in cfgs]
     for tick in range(6):
         for s, st in zip(ref, states):
@@ -99,7 +102,7 @@ def test_batched_ticks_in_generator_mode_equal_separate_handles(shapes):
             b.slide_control_seq(stride)
             np.testing.assert_array_equal(b.get_control_seq().view(np.uint32), r.get_control_seq().view(np.uint32))
         states = [st + np.float32(0.01) * np.arange(7, dtype=np.float32) for st in states]
-    assert all("quad" in s.rollout_variant() for s in bat)
+    assert all(("row8w" if form == "row" else "quad") in s.rollout_variant() for s in bat)
     for s in ref + bat:
         s.close()
 

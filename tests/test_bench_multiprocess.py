@@ -57,7 +57,7 @@ def test_bench_two_ranks_real_solver_on_one_gpu():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["data"] == "synthetic"
-    assert d["config"]["process_group"] == "gloo" and "quad" in d["config"]["rollout_variant"]
+    assert d["config"]["process_group"] == "gloo" and "row8w" in d["config"]["rollout_variant"]
     assert abs(d["value"] - 4096 * 20 * 2 / (d["ms_per_step"] * 20 / 1e3)) < 1e-6 * d["value"]
     a, b = d["instances"]
     assert (a["rank"], b["rank"]) == (0, 1) and a["device"] == b["device"] == 0

@@ -56,7 +56,7 @@ def _draw(golden_dir, seed):
         variants = ["auto", "fused"]
     else:
         cfg = S.make_config(K, T, layers=layers, track=track, **over)
-        variants = ["auto", "quad", "fused", "multi4", "multi2", "multi1", "multi4_gen", "multi4u", "multi4u_gen", "valu", "valu_lds"]
+        variants = ["auto", "row", "quad", "fused", "multi4", "multi2", "multi1", "multi4_gen", "multi4u", "multi4u_gen", "valu", "valu_lds"]
         if layers is not None and len(layers) > 1 and layers[1] == 64:
             variants += ["oct", "oct_gen"]
     st = cfg["start_state"].copy()
@@ -245,7 +245,7 @@ def test_random_call_sequences_match_the_oracle(block):
                 orc = O.Oracle(cfg, fma_mode=1, nthreads=16)
             elif op == "variant":
                 try:
-                    sol.set_rollout_variant(str(rng.choice(["auto", "quad", "fused", "valu", "valu_lds"])))
+                    sol.set_rollout_variant(str(rng.choice(["auto", "row", "quad", "fused", "valu", "valu_lds"])))
                 except capi.MppiError:
                     pass
             elif op == "rollout_only":  # rolloutKernel alone: one draw of the generator
@@ -283,7 +283,7 @@ def _check_against_oracle(cfg, variants):
 @pytest.mark.parametrize("K,T", [(256, 1000), (64, 4000)])
 def test_long_horizons(golden_dir, K, T):
     """20 s / 80 s of horizon at 50 Hz: rings wrap hundreds of times, the smoothing buffers grow with T."""
-    _check_against_oracle(S.make_config(K, T, track="ring"), ("quad", "fused", "valu", "valu_lds"))
+    _check_against_oracle(S.make_config(K, T, track="ring"), ("row", "quad", "fused", "valu", "valu_lds"))
     W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
     _check_against_oracle(S.make_config(K, T, track="ring", bf_W=W), ("auto", "fused"))
 
@@ -298,7 +298,7 @@ def test_degenerate_and_large_costmaps(W, H, ppm):
     xw, yh = W / ppm, H / ppm
     r_c1, r_c2, trs = P.costmap_transform(-xw / 2 + 9.0, xw / 2 + 9.0, -yh / 2, yh / 2)
     cfg = dict(S.make_config(256, 30, track="ring"), map_rgba=m, r_c1=r_c1, r_c2=r_c2, trs=trs)
-    _check_against_oracle(cfg, ("quad", "fused", "valu"))
+    _check_against_oracle(cfg, ("row", "quad", "fused", "valu"))
 
 
 def test_handles_driven_from_concurrent_host_threads():
@@ -342,7 +342,7 @@ def test_non_finite_and_huge_start_states(golden_dir, family):
     extra = {}
     if family == "bf":
         extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
-    variants = ["quad", "fused", "valu"] if family == "nn" else ["auto", "fused"]
+    variants = ["row", "quad", "fused", "valu"] if family == "nn" else ["auto", "fused"]
     for which, val in [(4, np.nan), (0, np.inf), (2, np.nan), (6, -np.inf), (4, 1e30), (0, 1e20)]:
         cfg = S.make_config(256, 20, track="oval", **extra)
         st = cfg["start_state"].copy()

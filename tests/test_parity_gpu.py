@@ -141,7 +141,7 @@ def test_config5_eight_independent_instances(instance):
     assert not (on[0].any() or on[-1].any() or on[:, 0].any() or on[:, -1].any())
     U0 = warm_U(cfg, seed=7 + instance)
     ref, got = _solve_both(cfg, U0=U0, seed=1234 + instance)
-    assert "quad" in got["variant"]
+    assert "row8w" in got["variant"]  # 6-32-32-4 at one group per CU: the vector-ALU row form
     np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
     err = rel_err(got["costs"], ref["costs"])
     assert int(np.sum(err > 1e-4)) <= cfg["K"] // 200, (instance, float(err.max()))
@@ -199,6 +199,12 @@ def test_quad_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
     np.testing.assert_array_equal(a["V"].view(np.uint32), c["V"].view(np.uint32))
     np.testing.assert_array_equal(a["U"].view(np.uint32), c["U"].view(np.uint32))
     # the multi form (ND dynamics waves + one cost wave + one control wave per 16 ND rollouts), ND = 4, 2, 1
+    if layers is None:  # the row form exists for 6-32-32-4
+        _, m = _solve_both(cfg, U0=U0, variant="row")
+        assert "row8w" in m["variant"]
+        np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))
+        np.testing.assert_array_equal(a["V"].view(np.uint32), m["V"].view(np.uint32))
+        np.testing.assert_array_equal(a["U"].view(np.uint32), m["U"].view(np.uint32))
     for v in ("multi4", "multi2", "multi1", "multi4u", "multi4u_gen"):
         _, m = _solve_both(cfg, U0=U0, variant=v)
         assert v in m["variant"]
