@@ -118,16 +118,18 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
   const uint32_t a_rng = lds_addr(&sh.rng_pub[0]);
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kCtl + 1);
   int seen_x = 0, seen_c = 0, seen_r = 0;  // swaps published by all dynamics waves / steps consumed by the cost wave / pairs drawn
-  for (int t0 = 0; t0 < T; t0 += kGCtlChunk) {
+  // The first iteration is ONE step (lanes of q = 0 only), so that the dynamics waves can start as soon as the noise
+  // wave has drawn its first pair instead of its first four (~1 us of every launch); four steps from then on.
+  for (int t0 = 0, n = 1; t0 < T; t0 += n, n = kGCtlChunk) {
     const int t = t0 + q;
-    const bool live = t < T;
+    const bool live = (t < T) & (q < n);
     const int tl = live ? t : T - 1;
     // this lane's nominal control and (explicit noise) eps
     const float2 Ut = Useq[tl];
     float2 e = (live && !inl) ? noise[(size_t)tl * K + k] : make_float2(0.0f, 0.0f);
     // the last slot of the chunk: slot t % kGRing held step t - kGRing -- the dynamics waves read it during step
     // t - kGRing - 1 (done once all of them published the first swap of step t - kGRing), the cost wave in step t - kGRing
-    const int tm = min(t0 + kGCtlChunk, T) - 1;
+    const int tm = min(t0 + n, T) - 1;
     const int need_x = (tm >= kGRing) ? (tm - kGRing) * NSW + 1 : 0;
     const int need_c = tm - kGRing + 1;
     while ((seen_x < need_x || seen_c < need_c) && --budget > 0) {

@@ -138,6 +138,7 @@ struct mppi_handle {
   float *d_costs = nullptr, *d_w = nullptr;
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
   float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
+  float *d_rowpack = nullptr;  // 6-32-32-4: the weights in the register order of the row form (rollout_row.hip)
   bool valu_reg_ok = false;
   double *d_invt = nullptr;
   uint32_t *d_rng[2] = {nullptr, nullptr};
@@ -274,6 +275,33 @@ std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int
   return out;
 }
 
+// Register image of the row form (rollout_row.hip: row_load): lane p of a rollout owns neurons 2p, 2p+1 of the hidden layers
+// and outputs 2(p&1), 2(p&1)+1; entry i of lane p is float4 index i * 16 + p.  Hidden biases times kTanhScale.
+std::vector<float> pack_row_weights(const std::vector<float> &theta)
+{
+  const int H = 32;
+  const float *W1 = theta.data(), *B1 = W1 + H * kNetIn, *W2 = B1 + H, *B2 = W2 + H * H, *W3 = B2 + H, *B3 = W3 + kNetOut * H;
+  std::vector<float> out((size_t)row_pack_floats(), 0.0f);
+  for (int p = 0; p < 16; p++) {
+    const int j0 = 2 * p, j1 = 2 * p + 1, o0 = 2 * (p & 1), o1 = o0 + 1;
+    auto entry = [&](int i) { return &out[((size_t)i * 16 + p) * 4]; };
+    for (int i = 0; i < 3; i++) {
+      float *e = entry(i);
+      e[0] = W1[j0 * kNetIn + 2 * i]; e[1] = W1[j1 * kNetIn + 2 * i];
+      e[2] = W1[j0 * kNetIn + 2 * i + 1]; e[3] = W1[j1 * kNetIn + 2 * i + 1];
+    }
+    for (int i = 0; i < H / 2; i++) {
+      float *e = entry(3 + i), *f = entry(3 + H / 2 + i);
+      e[0] = W2[j0 * H + 2 * i]; e[1] = W2[j1 * H + 2 * i]; e[2] = W2[j0 * H + 2 * i + 1]; e[3] = W2[j1 * H + 2 * i + 1];
+      f[0] = W3[o0 * H + 2 * i]; f[1] = W3[o1 * H + 2 * i]; f[2] = W3[o0 * H + 2 * i + 1]; f[3] = W3[o1 * H + 2 * i + 1];
+    }
+    float *b = entry(35), *c = entry(36);
+    b[0] = B1[j0] * kTanhScale; b[1] = B1[j1] * kTanhScale; b[2] = B2[j0] * kTanhScale; b[3] = B2[j1] * kTanhScale;
+    c[0] = B3[o0]; c[1] = B3[o1];
+  }
+  return out;
+}
+
 bool use_mfma(const mppi_handle *h)
 {
   if (h->basis || h->variant_pref == 2 || h->variant_pref == 3) return false;
@@ -391,7 +419,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.U = h->d_in;
   a.noise = noise;
   a.costs = h->d_costs;
-  a.wpack = use_mfma(h) ? (effective_block(h) == 900 ? h->d_theta_s : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
+  a.wpack = use_mfma(h) ? (effective_block(h) == 900 ? h->d_rowpack : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
   a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
@@ -790,7 +818,7 @@ void free_all(mppi_handle *h)
 {
   if (!h) return;
   float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_scal, h->d_noise, h->d_stage, h->d_costs,
-                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part};
+                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part, h->d_rowpack};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
@@ -948,6 +976,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_theta_s, sizeof(float) * h->net.num_params));
   if (h->mfma_ok)
     CR(hipMalloc(&h->d_wpack, sizeof(float) * 64 * (size_t)mfma_pack_floats_per_lane(h->hidden, h->n_hidden)));
+  if (h->mfma_ok && row_variant_supported(h->hidden, h->n_hidden)) CR(hipMalloc(&h->d_rowpack, sizeof(float) * (size_t)row_pack_floats()));
   CR(hipMalloc(&h->d_rng[0], sizeof(uint32_t) * 6 * h->K));
   CR(hipMalloc(&h->d_rng[1], sizeof(uint32_t) * 6 * h->K));
   CR(hipMalloc(&h->d_jump, sizeof(uint32_t) * 18 * h->noise_C));
@@ -1034,6 +1063,10 @@ int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
   if (h->mfma_ok) {
     const std::vector<float> pk = pack_mfma_weights(h->theta, h->hidden, h->n_hidden);
     HIPCHK(h, hipMemcpy(h->d_wpack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (h->d_rowpack) {
+    const std::vector<float> pk = pack_row_weights(h->theta);
+    HIPCHK(h, hipMemcpy(h->d_rowpack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   h->have_nn = true;
   return MPPI_OK;

@@ -42,8 +42,9 @@ bool oct_variant_supported(int hidden, int n_hidden);
 hipError_t launch_rollout_oct(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
 
 // rollout_row.hip: latency form of 6-32-32-4 on the vector ALU -- four dynamics waves (four rollouts each) + pose, cost,
-// control and noise wave per 16 rollouts; a.wpack = packed theta with pre-scaled hidden biases (theta_s)
+// control and noise wave per 16 rollouts; a.wpack = the weights in register order (pack_row_weights, mppi_abi.hip)
 bool row_variant_supported(int hidden, int n_hidden);
+int row_pack_floats();
 hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
 hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream);  // inst[i].group0 = first[i]
 

@@ -15,6 +15,8 @@
 //   * the activations of a layer go through LDS inside the wave: one 8-B write per lane, eight 16-B reads per lane that
 //     are broadcasts within the 16 lanes of a rollout.  No other wave is involved: no sequence word, no poll, no
 //     barrier on the recurrence (tools/ub/row_lds_ub.hip: 1 154 cycles per step alone on a SIMD);
+//   * every lane pair (p, p ^ 1) computes the same two outputs of the last layer, so the new state reaches layer 0 of
+//     the next step through one DPP move instead of a third LDS round trip;
 //   * state records, controls, texels, noise: the rings and riders of group_roles.hpp, one rider per SIMD beside one
 //     dynamics wave.
 #include "group_roles.hpp"
@@ -48,26 +50,34 @@ struct RowWeights {
   f32x2 b1s, b2s, b3;  // hidden biases pre-scaled for tanh_bias2 (theta_s of the register VALU kernel)
 };
 
-// theta_s: packed [W1|b1|W2|b2|W3|b3] (neural_net_model.cu:120-141), hidden biases already times kTanhScale
+// rowpack: the weights in REGISTER order, written by the host (pack_row_weights, mppi_abi.hip): 16-B entry i of lane p at
+// float4 index i * 16 + p -- a load instruction of a wave reads 256 contiguous bytes (the four rollouts of a wave share
+// them).  Entries: 0..2 = w1[0..5], 3..18 = w2[0..31], 19..34 = w3[0..31] (pairs, two per entry), 35 = (b1s, b2s), 36 = b3.
+// (Loading the rows straight from the packed theta -- 44 scattered 16-B loads per lane -- cost 2.1 us per launch.)
+constexpr int kRowPackEntries = 37;
 template <int H>
-__device__ __forceinline__ void row_load(const float *theta_s, int p, RowWeights<H> &W)
+__device__ __forceinline__ void row_load(const float *rowpack, int p, RowWeights<H> &W)
 {
-  const float *W1 = theta_s, *B1 = W1 + H * kNetIn, *W2 = B1 + H, *B2 = W2 + H * H, *W3 = B2 + H, *B3 = W3 + kNetOut * H;
-  const int j0 = 2 * p, j1 = 2 * p + 1, o0 = 2 * (p & 1), o1 = o0 + 1;
+  static_assert(H == 32, "entry layout of pack_row_weights");
+  const float4 *pk = reinterpret_cast<const float4 *>(rowpack) + p;
 #pragma unroll
-  for (int k = 0; k < kNetIn; k++) W.w1[k] = f32x2{W1[j0 * kNetIn + k], W1[j1 * kNetIn + k]};
-#pragma unroll
-  for (int q = 0; q < H / 4; q++) {
-    const float4 r0 = *reinterpret_cast<const float4 *>(W2 + j0 * H + 4 * q), r1 = *reinterpret_cast<const float4 *>(W2 + j1 * H + 4 * q);
-    W.w2[4 * q + 0] = f32x2{r0.x, r1.x}; W.w2[4 * q + 1] = f32x2{r0.y, r1.y};
-    W.w2[4 * q + 2] = f32x2{r0.z, r1.z}; W.w2[4 * q + 3] = f32x2{r0.w, r1.w};
-    const float4 q0 = *reinterpret_cast<const float4 *>(W3 + o0 * H + 4 * q), q1 = *reinterpret_cast<const float4 *>(W3 + o1 * H + 4 * q);
-    W.w3[4 * q + 0] = f32x2{q0.x, q1.x}; W.w3[4 * q + 1] = f32x2{q0.y, q1.y};
-    W.w3[4 * q + 2] = f32x2{q0.z, q1.z}; W.w3[4 * q + 3] = f32x2{q0.w, q1.w};
+  for (int i = 0; i < 3; i++) {
+    const float4 v = pk[i * 16];
+    W.w1[2 * i] = f32x2{v.x, v.y};
+    W.w1[2 * i + 1] = f32x2{v.z, v.w};
   }
-  W.b1s = f32x2{B1[j0], B1[j1]};
-  W.b2s = f32x2{B2[j0], B2[j1]};
-  W.b3 = f32x2{B3[o0], B3[o1]};
+#pragma unroll
+  for (int i = 0; i < H / 2; i++) {
+    const float4 v = pk[(3 + i) * 16], u = pk[(3 + H / 2 + i) * 16];
+    W.w2[2 * i] = f32x2{v.x, v.y};
+    W.w2[2 * i + 1] = f32x2{v.z, v.w};
+    W.w3[2 * i] = f32x2{u.x, u.y};
+    W.w3[2 * i + 1] = f32x2{u.z, u.w};
+  }
+  const float4 b = pk[35 * 16], c = pk[36 * 16];
+  W.b1s = f32x2{b.x, b.y};
+  W.b2s = f32x2{b.z, b.w};
+  W.b3 = f32x2{c.x, c.y};
 }
 
 // z = sum_k w[k] * a[k], k ascending, one fmaf per k and neuron (the pair shares a[k])
@@ -85,56 +95,74 @@ __device__ __forceinline__ f32x2 row_dot(const f32x2 (&w)[N], const float4 (&v)[
   return z;
 }
 
+// the partner lane's pair (lane p ^ 1 of the same rollout): one DPP move per register, no LDS
+__device__ __forceinline__ f32x2 row_partner(f32x2 v)
+{
+  f32x2 o;
+  o.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+  o.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0xB1, 0xF, 0xF, false));
+  return o;
+}
+
 template <int H>
 __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> &sh, const int w)
 {
   const int lane = threadIdx.x & 63;
   const int r = lane >> 4, p = lane & 15;
   const int jr = 4 * w + r;  // rollout of the group
+  const bool odd = (p & 1) != 0;
   const int T = a.T;
   RowWeights<H> W;
+#ifdef MPPI_DIAG_NOWLOAD  // diagnostic build: what do the weight loads cost at the start of a launch?
+  for (int k = 0; k < kNetIn; k++) W.w1[k] = f32x2{0.01f * k, 0.02f};
+  for (int k = 0; k < H; k++) { W.w2[k] = f32x2{0.001f * k, 0.002f * p}; W.w3[k] = f32x2{0.003f, 0.001f * k}; }
+  W.b1s = W.b2s = W.b3 = f32x2{0.01f, 0.02f};
+#else
   row_load<H>(a.wpack, p, W);
+#endif
   // pinned: the waits for the weight loads sit here, not at their first use inside the T loop
 #pragma unroll
   for (int k = 0; k < H; k++) { asm volatile("" : "+v"(W.w2[k])); asm volatile("" : "+v"(W.w3[k])); }
 
   const uint32_t a_myseq = lds_addr(&sh.xseq[w][lane]);
   typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
+  typedef const volatile float __attribute__((address_space(3))) *lds_float_p;
   const lds_int_p p_pub = (lds_int_p)&sh.ctl_pub[0];
   const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
+  const lds_float_p p_u = (lds_float_p)&sh.ctl_rec[0][jr][0];  // clamped u0, u1 of this lane's rollout (control wave)
+  constexpr int kCtlSlot = kRolloutsPerWave * 4;                // floats per ring slot of ctl_rec
   float(*act0)[H] = sh.act[w][0];
   float(*act1)[H] = sh.act[w][1];
 
-  // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p
-  f32x2 sp = (p & 1) ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
+  // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p -- every lane pair (p, p ^ 1) of a rollout
+  // computes the same output pair, so the whole state is one DPP move away
+  f32x2 sp = odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+  float u0n = p_u[0], u1n = p_u[1];
+  asm volatile("" : "+v"(u0n), "+v"(u1n));  // pinned: the wait for these reads sits here, not inside the loop
 
   // Steps 0 .. T-2 in full; of step T-1 only the state record goes out (its update feeds nothing: the cost is the
   // running mean over the states BEFORE the updates of steps 1..T-1, mppi_controller.cu:160-177)
   for (int t = 0; t < T - 1; t++) {
     const int slot = t & (kGRing - 1);
-    // record for the pose / cost waves = the layer-0 input of this step: the state BEFORE the update (the ring slot
-    // was checked at the end of the previous step)
+    const float u0 = u0n, u1 = u1n;
+    const f32x2 so = row_partner(sp);
+    const f32x2 slo = odd ? so : sp, shi = odd ? sp : so;  // (s3, s4), (s5, s6)
+    // record for the pose / cost waves: the state BEFORE the update (the ring slot was checked at the end of the
+    // previous step); then the publication -- which also says: this wave is done with the control record of step t
     if (p < 2) *reinterpret_cast<f32x2 *>(&sh.rec[slot][jr][2 * p]) = sp;
-    __builtin_amdgcn_wave_barrier();
-    const float4 s = *reinterpret_cast<const float4 *>(&sh.rec[slot][jr][0]);
-    const float2 u = *reinterpret_cast<const float2 *>(&sh.ctl_rec[slot][jr][0]);  // clamped u0, u1 (control wave)
-    // published AFTER the read of ctl(t) was issued (the LDS runs a wave's instructions in order): the record of step t
-    // is there, and this wave is done with the control record of step t
     lds_publish(a_myseq, t + 1);
     // layer 0: [s3, s4, s5, s6, u0, u1]
     f32x2 z = {0.0f, 0.0f};
-    z = __builtin_elementwise_fma(W.w1[0], f32x2{s.x, s.x}, z);
-    z = __builtin_elementwise_fma(W.w1[1], f32x2{s.y, s.y}, z);
-    z = __builtin_elementwise_fma(W.w1[2], f32x2{s.z, s.z}, z);
-    z = __builtin_elementwise_fma(W.w1[3], f32x2{s.w, s.w}, z);
-    z = __builtin_elementwise_fma(W.w1[4], f32x2{u.x, u.x}, z);
-    z = __builtin_elementwise_fma(W.w1[5], f32x2{u.y, u.y}, z);
+    z = __builtin_elementwise_fma(W.w1[0], f32x2{slo.x, slo.x}, z);
+    z = __builtin_elementwise_fma(W.w1[1], f32x2{slo.y, slo.y}, z);
+    z = __builtin_elementwise_fma(W.w1[2], f32x2{shi.x, shi.x}, z);
+    z = __builtin_elementwise_fma(W.w1[3], f32x2{shi.y, shi.y}, z);
+    z = __builtin_elementwise_fma(W.w1[4], f32x2{u0, u0}, z);
+    z = __builtin_elementwise_fma(W.w1[5], f32x2{u1, u1}, z);
     *reinterpret_cast<f32x2 *>(&act0[r][2 * p]) = tanh_bias2(z, W.b1s);
     __builtin_amdgcn_wave_barrier();
-    // requested now, used at the end of the step: the control wave's count and the cost wave's progress
-    const int cp_v = *p_pub, cd_v = *p_cd;
     {
       float4 v[H / 4];
 #pragma unroll
@@ -142,6 +170,12 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
       *reinterpret_cast<f32x2 *>(&act1[r][2 * p]) = tanh_bias2(row_dot<H>(W.w2, v), W.b2s);
     }
     __builtin_amdgcn_wave_barrier();
+    // requested now, used at the end of the step (behind the output layer): the control wave's count, then this
+    // rollout's controls of step t+1 (valid if the count read before them is >= t+2), and the cost wave's progress
+    const int sn = ((t + 1) & (kGRing - 1)) * kCtlSlot;
+    const int cp_v = *p_pub;
+    float un0_v = p_u[sn], un1_v = p_u[sn + 1];
+    const int cd_v = *p_cd;
     {
       float4 v[H / 4];
 #pragma unroll
@@ -155,8 +189,12 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
     int cp = __builtin_amdgcn_readfirstlane(cp_v), cd = __builtin_amdgcn_readfirstlane(cd_v);
     while (((cp < want) | (cd < want_cd)) && --budget > 0) {
       cp = __builtin_amdgcn_readfirstlane(*p_pub);
+      un0_v = p_u[sn];
+      un1_v = p_u[sn + 1];
       cd = __builtin_amdgcn_readfirstlane(*p_cd);
     }
+    u0n = un0_v;
+    u1n = un1_v;
   }
   {  // the record of step T-1
     const int t = T - 1;
@@ -227,6 +265,7 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
 }
 
 bool row_variant_supported(int hidden, int n_hidden) { return hidden == 32 && n_hidden == 2; }
+int row_pack_floats() { return kRowPackEntries * 16 * 4; }
 
 hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream)
 {

@@ -116,6 +116,77 @@ __global__ __launch_bounds__(256) void k_row(const float *theta, float *out, uns
   if (p < 2) { out[gk * 4 + 2 * p] = sp.x; out[gk * 4 + 2 * p + 1] = sp.y; }
 }
 
+// The product's form of the step (rollout_row.hip): the new state reaches layer 0 through one DPP move (every lane pair
+// computes the same two outputs) instead of a third LDS round trip.  With s_memtime stamps around the three layers.
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool STAMPS>
+__global__ __launch_bounds__(256) void k_row_dpp(const float *theta, float *out, unsigned long long *cyc, int iters, float dt)
+{
+  __shared__ __attribute__((aligned(16))) RowLds lds[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane >> 4, p = lane & 15;
+  const bool odd = (p & 1) != 0;
+  RowWeights W;
+  row_load(theta, p, W);
+  RowLds &L = lds[w];
+  const int gk = (blockIdx.x * 4 + w) * 4 + r;
+  f32x2 sp = odd ? f32x2{0.1f, 0.0f} : f32x2{0.01f * (float)(gk % 64), 5.0f};
+  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, acc[3] = {0, 0, 0};
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+    if (STAMPS) STAMP(q0);
+    f32x2 so;
+    so.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sp.x), 0xB1, 0xF, 0xF, false));
+    so.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sp.y), 0xB1, 0xF, 0xF, false));
+    const f32x2 slo = odd ? so : sp, shi = odd ? sp : so;
+    f32x2 z = {0.0f, 0.0f};
+    z = __builtin_elementwise_fma(W.w1[0], f32x2{slo.x, slo.x}, z);
+    z = __builtin_elementwise_fma(W.w1[1], f32x2{slo.y, slo.y}, z);
+    z = __builtin_elementwise_fma(W.w1[2], f32x2{shi.x, shi.x}, z);
+    z = __builtin_elementwise_fma(W.w1[3], f32x2{shi.y, shi.y}, z);
+    z = __builtin_elementwise_fma(W.w1[4], f32x2{0.1f, 0.1f}, z);
+    z = __builtin_elementwise_fma(W.w1[5], f32x2{0.1f, 0.1f}, z);
+    *reinterpret_cast<f32x2 *>(&L.act[0][r][2 * p]) = tanh_bias2(z, W.b1s);
+    __builtin_amdgcn_wave_barrier();
+    if (STAMPS) STAMP(q1);
+    {
+      float4 v[H / 4];
+#pragma unroll
+      for (int q = 0; q < H / 4; q++) v[q] = *reinterpret_cast<const float4 *>(&L.act[0][r][4 * q]);
+      z = f32x2{0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < H / 4; q++) {
+        z = __builtin_elementwise_fma(W.w2[4 * q + 0], f32x2{v[q].x, v[q].x}, z);
+        z = __builtin_elementwise_fma(W.w2[4 * q + 1], f32x2{v[q].y, v[q].y}, z);
+        z = __builtin_elementwise_fma(W.w2[4 * q + 2], f32x2{v[q].z, v[q].z}, z);
+        z = __builtin_elementwise_fma(W.w2[4 * q + 3], f32x2{v[q].w, v[q].w}, z);
+      }
+      *reinterpret_cast<f32x2 *>(&L.act[1][r][2 * p]) = tanh_bias2(z, W.b2s);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (STAMPS) STAMP(q2);
+    {
+      float4 v[H / 4];
+#pragma unroll
+      for (int q = 0; q < H / 4; q++) v[q] = *reinterpret_cast<const float4 *>(&L.act[1][r][4 * q]);
+      z = f32x2{0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < H / 4; q++) {
+        z = __builtin_elementwise_fma(W.w3[4 * q + 0], f32x2{v[q].x, v[q].x}, z);
+        z = __builtin_elementwise_fma(W.w3[4 * q + 1], f32x2{v[q].y, v[q].y}, z);
+        z = __builtin_elementwise_fma(W.w3[4 * q + 2], f32x2{v[q].z, v[q].z}, z);
+        z = __builtin_elementwise_fma(W.w3[4 * q + 3], f32x2{v[q].w, v[q].w}, z);
+      }
+      sp = __builtin_elementwise_fma(z + W.b3, f32x2{dt, dt}, sp);
+    }
+    if (STAMPS) { STAMP(q3); acc[0] += q1 - q0; acc[1] += q2 - q1; acc[2] += q3 - q2; }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[blockIdx.x * 4 + w] = c1 - c0;
+  if (STAMPS && blockIdx.x == 0 && w == 0 && lane == 0) { cyc[4096] = acc[0]; cyc[4097] = acc[1]; cyc[4098] = acc[2]; }
+  if (p < 2) { out[gk * 4 + 2 * p] = sp.x; out[gk * 4 + 2 * p + 1] = sp.y; }
+}
+
 static float tanh_host(float z, float b)  // the device formula cannot be reproduced bit-exactly on the host: tolerance
 {
   return tanhf(z + b);
@@ -128,7 +199,7 @@ int main(int argc, char **argv)
   for (size_t i = 0; i < th.size(); i++) th[i] = 0.25f * (float)((int)((i * 2654435761u) >> 20 & 255) - 128) / 128.0f;
   float *d_t, *d_o; unsigned long long *d_c;
   hipMalloc(&d_t, th.size() * 4); hipMemcpy(d_t, th.data(), th.size() * 4, hipMemcpyHostToDevice);
-  hipMalloc(&d_o, 1024 * 16 * 4 * 4); hipMalloc(&d_c, 1024 * 4 * 8);
+  hipMalloc(&d_o, 1024 * 16 * 4 * 4); hipMalloc(&d_c, 4100 * 8);
   const float dt = 0.02f;
   for (int blocks : {256, 512, 1024}) {
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(k_row, dim3(blocks), dim3(256), 0, 0, d_t, d_o, d_c, iters, dt);
@@ -139,6 +210,21 @@ int main(int argc, char **argv)
     for (auto v : c) { s += (double)v; mx = std::max(mx, v); }
     printf("6-32-32-4 row/LDS form, %d wave(s) per SIMD: %.0f cycles per step per wave (mean), %.0f (slowest wave)\n", blocks / 256,
            s / c.size() / iters, (double)mx / iters);
+  }
+  for (int st = 0; st < 2; st++) {
+    for (int rep = 0; rep < 3; rep++) {
+      if (st) hipLaunchKernelGGL(k_row_dpp<true>, dim3(256), dim3(256), 0, 0, d_t, d_o, d_c, iters, dt);
+      else hipLaunchKernelGGL(k_row_dpp<false>, dim3(256), dim3(256), 0, 0, d_t, d_o, d_c, iters, dt);
+    }
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> c(4099);
+    hipMemcpy(c.data(), d_c, c.size() * 8, hipMemcpyDeviceToHost);
+    double s = 0;
+    for (int i = 0; i < 1024; i++) s += (double)c[i];
+    printf("DPP form%s, 1 wave per SIMD: %.0f cycles per step", st ? " (stamped)" : "", s / 1024 / iters);
+    if (st) printf("; layer 0 (dpp, 6 fma, tanh, write) %.0f | layer 1 (8 reads, 32 fma, tanh, write) %.0f | output layer (8 reads, 32 fma, Euler) %.0f",
+                   (double)c[4096] / iters, (double)c[4097] / iters, (double)c[4098] / iters);
+    printf("\n");
   }
   // checksum of rollout 0 against a host replay of the same recurrence (libm tanhf: tolerance)
   std::vector<float> o(16); hipMemcpy(o.data(), d_o, 64, hipMemcpyDeviceToHost);
