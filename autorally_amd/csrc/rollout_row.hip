@@ -24,6 +24,22 @@
 
 namespace mppi {
 
+// Diagnostic build only (-DMPPI_ROW_STAMPS, tools/row_stamps.py): s_memtime stamps of workgroup 0 -- where the time of a
+// launch goes outside the T loop.  The product build has no stamp instruction.
+#ifdef MPPI_ROW_STAMPS
+__device__ unsigned long long g_row_stamps[16];
+#define RSTAMP(i)                                                                                         \
+  do {                                                                                                    \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                                     \
+      unsigned long long t__;                                                                             \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                           \
+      g_row_stamps[i] = t__;                                                                              \
+    }                                                                                                     \
+  } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
+
 template <int H>
 struct RowShared {
   static constexpr int NW = 4;            // dynamics waves per group, four rollouts each
@@ -138,7 +154,9 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   // computes the same output pair, so the whole state is one DPP move away
   f32x2 sp = odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
+  if (w == 0) RSTAMP(2);  // weights in registers
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+  if (w == 0) RSTAMP(3);  // first controls published: the T loop starts
   float u0n = p_u[0], u1n = p_u[1];
   asm volatile("" : "+v"(u0n), "+v"(u1n));  // pinned: the wait for these reads sits here, not inside the loop
 
@@ -196,6 +214,7 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
     u0n = un0_v;
     u1n = un1_v;
   }
+  if (w == 0) RSTAMP(4);  // T loop done
   {  // the record of step T-1
     const int t = T - 1;
     if (p < 2) *reinterpret_cast<f32x2 *>(&sh.rec[t & (kGRing - 1)][jr][2 * p]) = sp;
@@ -213,6 +232,7 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   __shared__ __attribute__((aligned(16))) SH sh;
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (role == 0) RSTAMP(0);  // first instruction
   if (role == 0) {  // sequence words start at 0; the only barrier
 #pragma unroll
     for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
@@ -224,11 +244,15 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
     sh.fin[lane & 7] = 0;
   }
   __syncthreads();
+  if (role == 0) RSTAMP(1);  // behind the barrier
+#ifdef MPPI_ROW_RIDER_PRIO
+  if (role >= 4) __builtin_amdgcn_s_setprio(MPPI_ROW_RIDER_PRIO);
+#endif
   if (role < 4) row_dynamics<H>(a, sh, role);
-  else if (role == R::kCost) group_cost_wave<SH, CTRL>(a, sh);
-  else if (role == R::kCtl) group_control_wave(a, sh);
-  else if (role == R::kPose) group_pose_wave<SH, AFFINE>(a, sh);
-  else group_rng_wave(a, sh);
+  else if (role == R::kCost) { group_cost_wave<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
+  else if (role == R::kCtl) { group_control_wave(a, sh); RSTAMP(6); }
+  else if (role == R::kPose) { group_pose_wave<SH, AFFINE>(a, sh); RSTAMP(7); }
+  else { group_rng_wave(a, sh); RSTAMP(8); }
 }
 
 // several instances in one launch (mppi_compute_control_batch): workgroups [first[i], first[i+1]) run instance i, whose
@@ -296,3 +320,10 @@ hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, hi
 }
 
 }  // namespace mppi
+
+#ifdef MPPI_ROW_STAMPS
+extern "C" int mppi_debug_read_row_stamps(unsigned long long *out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mppi::g_row_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
