@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: + mppi_set_costmap_transform, mppi_savitsky_golay, mppi_compute_control_batch[_async], mppi_control_ticks_batch,
  *    mppi_debug_inject_handover_fault; mppi_slide_control_seq(h, 0) is MPPI_OK (was MPPI_ERR_INVALID); "fused" =
- *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w". */
+ *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w", "valu_row8w_*"; variants "row", "multi4u". */
 #define MPPI_ABI_VERSION 2
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
@@ -227,12 +227,15 @@ int mppi_debug_cost_raster(mppi_handle *h, float x, float y, float heading, int 
 int mppi_enable_stage_timing(mppi_handle *h, int on);
 int mppi_reset_stage_times(mppi_handle *h);
 int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
-/* Name of the rollout kernel variant in use: "mfma16x16x4_h32_l2_quad4w" (four wavefronts per 16
+/* Name of the rollout kernel variant in use: "valu_row8w_h32_l2" (6-32-32-4 up to one group of 16 rollouts per CU: the
+ * recurrence on the vector ALU, four dynamics wavefronts of four rollouts + pose, cost, control and noise wavefront),
+ * "mfma16x16x4_h32_l2_quad4w" (four wavefronts per 16
  * rollouts), "..._oct8w[_gen]" (eight, 64-wide nets), "..._multi{1,2,4}[_gen]", "..._fused_b256" / "_b64" (one
  * wavefront per 16 rollouts), "valu_reg_lds", "valu_lds", "basis_funcs25_valu[_2w|_3w]". */
 const char *mppi_rollout_variant(const mppi_handle *h);
 /* Force a variant (A/B of SURVEY cfg 4 and of the kernel forms): "auto"; "mfma" | "valu" | "valu_lds"
- * (arithmetic unit); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
+ * (arithmetic unit: "mfma" keeps the matrix-instruction forms at every K, "valu" / "valu_lds" are the throughput-style
+ * vector kernels); "row" (the vector-ALU latency form, 6-32-32-4 only); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
  * wavefront per 16 rollouts) | "multi4" | "multi2" | "multi1" (ND dynamics wavefronts of 16 rollouts + one
  * cost + one control wavefront; "_gen" appended: eps from the stand-alone generator kernel) | "oct" | "oct_gen"
  * (64-wide nets: four dynamics wavefronts, one M tile each, + pose, cost, control, noise wavefront per 16
@@ -253,6 +256,7 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
  * dynamics waves, 3 = cost wave, 4 = control wave; of the two-wavefront basis-function kernel: 1 = dynamics,
  * 2 = cost.  The solve must then end in MPPI_ERR_HIP ("hand-over failed"), never in finite costs.
  * wave = 0 and spin_budget = 0 restore normal operation.
+ * Roles of the row form and of the oct form: 1 .. 4 = dynamics waves, 5 = pose, 6 = cost, 7 = control, 8 = noise wave.
  * Roles of the multi form: 1 .. ND = dynamics waves, then the cost wave and the control wave (ND = 4: the pose
  * wave, the cost wave, the control wave). */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
