@@ -58,7 +58,7 @@ SYMBOLS = [
     "mppi_savitsky_golay", "mppi_slide_control_seq", "mppi_seed", "mppi_set_noise", "mppi_generate_noise",
     "mppi_compute_control", "mppi_control_ticks", "mppi_compute_control_async", "mppi_synchronize",
     "mppi_compute_control_batch_async", "mppi_compute_control_batch", "mppi_control_ticks_batch", "mppi_get_results",
-    "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj",
+    "mppi_get_applied_controls", "mppi_rollout_only", "mppi_nominal_traj", "mppi_nominal_traj_pair",
     "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_debug_cost_raster", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
@@ -66,7 +66,8 @@ SYMBOLS = [
 ]
 
 ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
-                "mppi_compute_control_batch", "mppi_compute_control_batch_async", "mppi_control_ticks_batch")
+                "mppi_compute_control_batch", "mppi_compute_control_batch_async", "mppi_control_ticks_batch",
+                "mppi_nominal_traj_pair")
 
 _lib = None
 
@@ -140,6 +141,7 @@ def lib():
             L.mppi_compute_control_batch_async.argtypes = [C.POINTER(hp), fp, C.c_int]
             L.mppi_compute_control_batch.argtypes = [C.POINTER(hp), fp, C.c_int]
             L.mppi_control_ticks_batch.argtypes = [C.POINTER(hp), fp, C.c_int, C.c_int, C.c_int]
+            L.mppi_nominal_traj_pair.argtypes = [hp, fp, fp, fp, hp, fp, fp, fp]
         for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
             if v2 or s not in ABI2_SYMBOLS:
                 getattr(L, s)
@@ -416,4 +418,16 @@ def control_ticks_batch(solvers, states, n_ticks, stride=1):
     rc = solvers[0].L.mppi_control_ticks_batch(hs, _fp(st), n, int(n_ticks), int(stride))
     if rc != OK:
         raise MppiError(rc, "; ".join(s.L.mppi_last_error(s.h).decode() for s in solvers))
+
+
+def nominal_traj_pair(sol_a, state_a, sol_b, state_b):
+    """mppi_nominal_traj_pair: ((state_seq_a, control_seq_a), (state_seq_b, control_seq_b))."""
+    out = []
+    for s in (sol_a, sol_b):
+        out.append((np.zeros((s.T, 7), np.float32), np.zeros((s.T, 2), np.float32)))
+    rc = sol_a.L.mppi_nominal_traj_pair(sol_a.h, _fp(_f32(state_a, (7,))), _fp(out[0][0]), _fp(out[0][1]),
+                                        sol_b.h, _fp(_f32(state_b, (7,))), _fp(out[1][0]), _fp(out[1][1]))
+    if rc != OK:
+        raise MppiError(rc, sol_a.L.mppi_last_error(sol_a.h).decode() + " | " + sol_b.L.mppi_last_error(sol_b.h).decode())
+    return out
 

@@ -78,4 +78,49 @@ struct HostNetFma {
   }
 };
 
+// Two replays in lockstep: a layer's k-ascending fmaf chains are latency-bound (four registers of neurons = four chains in
+// flight per replay, the FMA units take eight), so the two controllers of a control tick -- two independent replays of the
+// same length -- advance together at the cost of one.  Per replay the arithmetic is HostNetFma::forward's, instruction for
+// instruction.  The two networks may be different objects (same layer list).
+inline void host_net_forward2(HostNetFma &A, HostNetFma &B, const float inA[6], const float inB[6], float outA[4], float outB[4])
+{
+  float *a0 = A.a_.data(), *b0 = A.b_.data(), *a1 = B.a_.data(), *b1 = B.b_.data();
+  for (int i = 0; i < 6; i++) { a0[i] = inA[i]; a1[i] = inB[i]; }
+  for (int l = 0; l < A.L; l++) {
+    const int ni = A.nin[l], no = A.nout[l], po = A.pout[l];
+    const float *W0 = A.Wt[l].data(), *W1 = B.Wt[l].data(), *bias0 = A.bp[l].data(), *bias1 = B.bp[l].data();
+    for (int j0 = 0; j0 < po; j0 += 32) {
+      const int nb = std::min(4, (po - j0) / 8);
+      __m256 s0[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
+      __m256 s1[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
+      for (int k = 0; k < ni; k++) {
+        const __m256 ak0 = _mm256_set1_ps(a0[k]), ak1 = _mm256_set1_ps(a1[k]);
+        const float *w0 = W0 + (size_t)k * po + j0, *w1 = W1 + (size_t)k * po + j0;
+        for (int q = 0; q < nb; q++) {
+          s0[q] = _mm256_fmadd_ps(_mm256_loadu_ps(w0 + 8 * q), ak0, s0[q]);
+          s1[q] = _mm256_fmadd_ps(_mm256_loadu_ps(w1 + 8 * q), ak1, s1[q]);
+        }
+      }
+      for (int q = 0; q < nb; q++) {
+        _mm256_storeu_ps(b0 + j0 + 8 * q, _mm256_add_ps(s0[q], _mm256_loadu_ps(bias0 + j0 + 8 * q)));
+        _mm256_storeu_ps(b1 + j0 + 8 * q, _mm256_add_ps(s1[q], _mm256_loadu_ps(bias1 + j0 + 8 * q)));
+      }
+    }
+    if (l < A.L - 1) {
+      if (A.vec_tanh) {
+        for (int j = 0; j < po; j += 8) {  // the two replays' registers alternate: independent tanhf8 chains
+          const __m256 t0 = tanhf8(_mm256_loadu_ps(b0 + j)), t1 = tanhf8(_mm256_loadu_ps(b1 + j));
+          _mm256_storeu_ps(b0 + j, t0);
+          _mm256_storeu_ps(b1 + j, t1);
+        }
+      } else {
+        for (int j = 0; j < no; j++) { b0[j] = tanhf(b0[j]); b1[j] = tanhf(b1[j]); }
+      }
+    }
+    std::swap(a0, b0);
+    std::swap(a1, b1);
+  }
+  for (int i = 0; i < 4; i++) { outA[i] = a0[i]; outB[i] = a1[i]; }
+}
+
 }  // namespace mppi

@@ -1611,6 +1611,52 @@ int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   return MPPI_OK;
 }
 
+int mppi_nominal_traj_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM], float *state_seq_a, float *control_seq_a,
+                           mppi_handle *hb, const float state_b[MPPI_STATE_DIM], float *state_seq_b, float *control_seq_b)
+{
+  if (!ha || !hb || ha == hb) return MPPI_ERR_INVALID;
+  // two network replays of the same length advance in lockstep (host_net_forward2); anything else: one after the other
+  const bool lockstep = !ha->basis && !hb->basis && ha->have_nn && hb->have_nn && ha->T == hb->T &&
+                        ha->net.n_layers == hb->net.n_layers &&
+                        memcmp(ha->net.layers, hb->net.layers, sizeof(ha->net.layers)) == 0 && state_a && state_b &&
+                        state_seq_a && state_seq_b && control_seq_a && control_seq_b;
+  if (!lockstep) {
+    const int rc = mppi_nominal_traj(ha, state_a, state_seq_a, control_seq_a);
+    return rc ? rc : mppi_nominal_traj(hb, state_b, state_seq_b, control_seq_b);
+  }
+  for (mppi_handle *h : {ha, hb})
+    if (h->pending) {
+      const int rc = mppi_synchronize(h);
+      if (rc) return rc;
+    }
+  mppi_handle *hs[2] = {ha, hb};
+  float *sseq[2] = {state_seq_a, state_seq_b}, *cseq[2] = {control_seq_a, control_seq_b};
+  float s[2][kStateDim], sd[2][kStateDim], in6[2][6];
+  for (int i = 0; i < kStateDim; i++) { s[0][i] = state_a[i]; s[1][i] = state_b[i]; }
+  for (int t = 0; t < ha->T; t++) {
+    for (int q = 0; q < 2; q++) {  // per replay exactly the statements of mppi_nominal_traj
+      const mppi_handle *h = hs[q];
+      for (int i = 0; i < kStateDim; i++) sseq[q][t * kStateDim + i] = s[q][i];
+      float u[2] = {h->U[2 * t], h->U[2 * t + 1]};
+      for (int i = 0; i < 2; i++) {
+        if (u[i] < h->u_lo[i]) u[i] = h->u_lo[i];
+        else if (u[i] > h->u_hi[i]) u[i] = h->u_hi[i];
+      }
+      const float c = cosf(s[q][2]), sn = sinf(s[q][2]);
+      sd[q][0] = fmaf(c, s[q][4], -(sn * s[q][5]));
+      sd[q][1] = fmaf(sn, s[q][4], c * s[q][5]);
+      sd[q][2] = h->cfg.negate_yaw_der ? -s[q][6] : s[q][6];
+      in6[q][0] = s[q][3]; in6[q][1] = s[q][4]; in6[q][2] = s[q][5]; in6[q][3] = s[q][6]; in6[q][4] = u[0]; in6[q][5] = u[1];
+      cseq[q][2 * t] = u[0];
+      cseq[q][2 * t + 1] = u[1];
+    }
+    host_net_forward2(ha->hnet, hb->hnet, in6[0], in6[1], sd[0] + 3, sd[1] + 3);
+    for (int q = 0; q < 2; q++)
+      for (int i = 0; i < kStateDim; i++) s[q][i] = fmaf(sd[q][i], hs[q]->dt, s[q][i]);
+  }
+  return MPPI_OK;
+}
+
 int mppi_set_ddp_weights(mppi_handle *h, const float Q[MPPI_STATE_DIM], const float R[MPPI_CONTROL_DIM],
                          const float Qf[MPPI_STATE_DIM])
 {

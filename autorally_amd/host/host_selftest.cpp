@@ -57,6 +57,7 @@ struct FakeController {
   }
   void startControl() { float s[7]; for (int i = 0; i < 7; i++) s[i] = state_seq[i]; startControl(s); }
   static void startControlPair(FakeController *a, const float *s, FakeController *p) { a->startControl(s); p->startControl(); }
+  static void finishControlPair(FakeController *a, FakeController *p) { a->finishControl(); p->finishControl(); }
   void finishControl() {}
   float getComputedTrajectoryCost() const { return cost; }
   std::vector<float> getControlSeq() const { return control_seq; }
@@ -240,6 +241,18 @@ int main(int argc, char **argv)
       for (int i = 0; i < 7; i++) x[i] = fmaf(model.state_der_[i], 0.02f, x[i]);
     }
     REQUIRE(std::fabs(x[4]) > 0.5f && std::isfinite(x[0]));
+    // two replays in lockstep (host_net_forward2) = two single replays, bit for bit
+    mppi::HostNetFma net2;
+    net2.init(layers, 4, model.packedParams().data());
+    float xa[6] = {0.02f, 3.0f, 0.2f, -0.1f, 0.3f, 0.4f}, xb[6] = {-0.05f, 6.0f, -0.4f, 0.3f, -0.7f, 0.1f};
+    for (int t = 0; t < 500; t++) {
+      float oa[4], ob[4], ra[4], rb[4];
+      mppi::host_net_forward2(net, net2, xa, xb, oa, ob);
+      net.forward(xa, ra);
+      net2.forward(xb, rb);
+      REQUIRE(memcmp(oa, ra, 16) == 0 && memcmp(ob, rb, 16) == 0);
+      for (int i = 0; i < 4; i++) { xa[i] = fmaf(oa[i], 0.02f, xa[i]); xb[i] = fmaf(ob[i], 0.02f, xb[i]); }
+    }
   }
   // --- MPPICosts: the non-caller public names (costs.cuh:170,186-191) and the list of bound controller handles ---
   {

@@ -651,6 +651,19 @@ class MPPIControllerT {
     trajectory_cost_ = tc;
     computeNominalTraj(solve_state_);
   }
+  // finishControl() of both controllers of a tick: collects the two solves, then replays the two nominal trajectories
+  // in lockstep on the host (mppi_nominal_traj_pair: about the cost of one replay)
+  static void finishControlPair(MPPIControllerT *actual, MPPIControllerT *predicted)
+  {
+    float tc = 0.0f;
+    actual->ck(mppi_get_results(actual->h_, nullptr, &tc, nullptr, nullptr));
+    actual->trajectory_cost_ = tc;
+    predicted->ck(mppi_get_results(predicted->h_, nullptr, &tc, nullptr, nullptr));
+    predicted->trajectory_cost_ = tc;
+    actual->ck(mppi_nominal_traj_pair(actual->h_, actual->solve_state_, actual->state_solution_.data(), actual->control_solution_.data(),
+                                      predicted->h_, predicted->solve_state_, predicted->state_solution_.data(),
+                                      predicted->control_solution_.data()));
+  }
   void computeNominalTraj(const float *state)  // :501-519
   {
     ck(mppi_nominal_traj(h_, state, state_solution_.data(), control_solution_.data()));

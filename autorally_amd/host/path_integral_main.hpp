@@ -142,11 +142,13 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     for (float v : robot.debug_image) img_sum += v;
     std::string strides;
     for (int v : st.strides) strides += (strides.empty() ? "" : " ") + std::to_string(v);
-    printf("{\"iterations\": %d, \"rollouts\": %d, \"timesteps\": %d, \"avg_tick_ms\": %.4f, \"avg_sleep_ms\": %.4f, "
+    printf("{\"iterations\": %d, \"rollouts\": %d, \"timesteps\": %d, \"avg_tick_ms\": %.4f, \"tick_parts_ms\": {\"slide_updates\": %.4f, "
+           "\"solves_and_replays\": %.4f, \"gains\": %.4f, \"arbitration_handover\": %.4f}, \"avg_sleep_ms\": %.4f, "
            "\"wall_s\": %.4f, \"actual_state_used\": %d, \"final_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f], "
            "\"feedback_gain_row_sums_t0\": [%.6f, %.6f], \"desired_speed\": %.4f, \"debug_image_pixels\": %zu, "
            "\"debug_image_sum\": %.4f, \"avg_loop_ms\": %.4f, \"strides\": \"%s\", \"plant_state\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f, %.6f]}\n",
-           st.iterations, actual.NUM_ROLLOUTS, T, st.avg_tick_ms, st.avg_sleep_ms, wall, robot.n_actual,
+           st.iterations, actual.NUM_ROLLOUTS, T, st.avg_tick_ms, st.avg_pre_ms, st.avg_solve_ms, st.avg_gains_ms, st.avg_post_ms,
+           st.avg_sleep_ms, wall, robot.n_actual,
            st.final_state[0], st.final_state[1], st.final_state[2], st.final_state[3], st.final_state[4],
            st.final_state[5], st.final_state[6], g0, g1, costs.params_.desired_speed, robot.debug_image.size(), img_sum,
            st.avg_loop_ms, strides.c_str(), robot.fs.x_pos, robot.fs.y_pos, robot.fs.yaw, robot.fs.roll, robot.fs.u_x,

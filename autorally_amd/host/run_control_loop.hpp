@@ -139,6 +139,9 @@ struct SimPlant {
 struct LoopStats {
   int iterations = 0;
   double avg_tick_ms = 0, avg_sleep_ms = 0, avg_loop_ms = 0;
+  // where a tick goes (ms, means): slide + live updates | both solves + both nominal replays | feedback gains | arbitration,
+  // hand-over to the plant, debug-mode state update
+  double avg_pre_ms = 0, avg_solve_ms = 0, avg_gains_ms = 0, avg_post_ms = 0;
   std::array<float, 7> final_state{};
   std::vector<int> strides;  // the stride every tick slid by (-1: no slide)
 };
@@ -249,13 +252,15 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     }
     // computeControl(state) / computeControl() (:218-219); the two solves are independent, so both are
     // put on the GPU together -- one launch for the rollouts of both controllers -- before either is waited for
+    const auto t_solve0 = std::chrono::steady_clock::now();
     CONTROLLER_T::startControlPair(actual_state_controller, state, predicted_state_controller);
-    actual_state_controller->finishControl();
-    predicted_state_controller->finishControl();
+    CONTROLLER_T::finishControlPair(actual_state_controller, predicted_state_controller);
+    const auto t_solve1 = std::chrono::steady_clock::now();
     if (use_feedback_gains) {  // :220-225: both controllers, from the measured state
       actual_state_controller->computeFeedbackGains(state);
       predicted_state_controller->computeFeedbackGains(state);
     }
+    const auto t_gains1 = std::chrono::steady_clock::now();
     feedback_gain = predicted_state_controller->getFeedbackGains().feedback_gain;  // :229
 
     ControllerType to_use = ControllerType::NONE;
@@ -299,6 +304,16 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     // sleep for any leftover time, and -- with a pose source -- until the next pose is almost due, :304-312
     std::chrono::duration<double, std::milli> fp_ms = std::chrono::steady_clock::now() - loop_start;
     const double tick = fp_ms.count();
+    {
+      const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+      };
+      const double pre = ms(loop_start, t_solve0), solve = ms(t_solve0, t_solve1), gains = ms(t_solve1, t_gains1);
+      st.avg_pre_ms += (pre - st.avg_pre_ms) / num_iter;
+      st.avg_solve_ms += (solve - st.avg_solve_ms) / num_iter;
+      st.avg_gains_ms += (gains - st.avg_gains_ms) / num_iter;
+      st.avg_post_ms += ((tick - pre - solve - gains) - st.avg_post_ms) / num_iter;
+    }
     while (sleep_to_rate && is_alive->load() &&
            (fp_ms < period || ((robot->getLastPoseTime() - last_pose_update) < (1.0 / hz - 0.0025) && status == 0))) {
       std::this_thread::sleep_for(std::chrono::microseconds(50));

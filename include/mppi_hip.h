@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-/* 2: + mppi_set_costmap_transform, mppi_savitsky_golay, mppi_compute_control_batch[_async], mppi_control_ticks_batch,
+/* 2: + mppi_set_costmap_transform, mppi_savitsky_golay, mppi_compute_control_batch[_async], mppi_control_ticks_batch, mppi_nominal_traj_pair,
  *    mppi_debug_inject_handover_fault; mppi_slide_control_seq(h, 0) is MPPI_OK (was MPPI_ERR_INVALID); "fused" =
  *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w", "valu_row8w_*"; variants "row", "multi4u". */
 #define MPPI_ABI_VERSION 2
@@ -194,6 +194,12 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
  * state_seq [T][7], control_seq [T][2] (clamped). */
 int mppi_nominal_traj(mppi_handle *h, const float state[MPPI_STATE_DIM], float *state_seq,
                       float *control_seq);
+
+/* computeNominalTraj of the two controllers of a control tick (run_control_loop.cuh:218-219: both end their
+ * computeControl with it) in one call: two network replays of the same length advance in lockstep on the host, at about the
+ * cost of one; results bit for bit those of two mppi_nominal_traj calls (which is what this does for any other pair). */
+int mppi_nominal_traj_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM], float *state_seq_a, float *control_seq_a,
+                           mppi_handle *hb, const float state_b[MPPI_STATE_DIM], float *state_seq_b, float *control_seq_b);
 
 /* computeFeedbackGains (PI/mppi_controller.cu:431-441) -> DDP::run (ddp/ddp.h:49-157), one
  * iteration, dt = 1/hz, from `state`, tracking target_state_seq [T][7] / target_control_seq [T][2]

@@ -137,6 +137,37 @@ def test_basis_function_controllers_share_a_launch_too(golden_dir):
         s.close()
 
 
+def test_nominal_trajectories_of_a_pair_in_lockstep_equal_the_single_replays(golden_dir):
+    """mppi_nominal_traj_pair (the computeNominalTraj of both controllers of a tick, two host replays advancing in
+    lockstep) returns bit for bit what two mppi_nominal_traj calls return; pairs that cannot run in lockstep (different
+    horizons, the basis-function model) are served one after the other."""
+    import os
+    cfg = S.make_config(512, 100, track="oval")
+    a, b = capi.Solver(cfg), capi.Solver(dict(cfg, seed=9))
+    sa, sb = cfg["start_state"].copy(), cfg["start_state"].copy()
+    sb[0] += 0.4
+    sb[4] -= 1.0
+    capi.compute_control_batch([a, b], [sa, sb])
+    (xa, ua), (xb, ub) = capi.nominal_traj_pair(a, sa, b, sb)
+    ra, rb = a.nominal_traj(sa), b.nominal_traj(sb)
+    for got, ref in ((xa, ra[0]), (ua, ra[1]), (xb, rb[0]), (ub, rb[1])):
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.max(np.abs(xa - xb)) > 1e-3
+    orc = O.Oracle(cfg, fma_mode=1)
+    rs, _ = orc.nominal_traj(sa, a.get_control_seq())
+    assert np.max(np.abs(xa - rs)) <= 1e-4
+    W = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
+    c = capi.Solver(S.make_config(256, 60, track="oval", bf_W=W))
+    c.compute_control(sa)
+    (xa2, _), (xc, uc) = capi.nominal_traj_pair(a, sa, c, sa)
+    np.testing.assert_array_equal(xa2.view(np.uint32), ra[0].view(np.uint32))
+    rc = c.nominal_traj(sa)
+    np.testing.assert_array_equal(xc.view(np.uint32), rc[0].view(np.uint32))
+    np.testing.assert_array_equal(uc.view(np.uint32), rc[1].view(np.uint32))
+    for s in (a, b, c):
+        s.close()
+
+
 def test_batch_then_single_then_batch_and_two_iterations():
     """Transitions between the batch stream and a handle's own stream (single solve, result vectors, applied
     controls, set_noise, seed) keep every handle's sequence of results; num_iters = 2 batches both iterations."""

@@ -18,10 +18,10 @@ for m in ("ccrf_costmap_09_29_2017.npz","marietta_costmap_09_08_2018.npz"):
 PY
 for fb in false true; do
   echo "path_integral_nn K=1920 use_feedback_gains=$fb"
-  AR_MPPI_PARAMS_PATH=$D ./autorally_amd/bin/path_integral_nn autorally_amd/host/launch/path_integral_nn.launch --rollouts 1920 --max-iter $N --no-sleep --set x_pos=0.0 --set y_pos=-10.0 --set heading=0.0 --set use_feedback_gains=$fb | tail -1 | cut -c1-160
+  AR_MPPI_PARAMS_PATH=$D ./autorally_amd/bin/path_integral_nn autorally_amd/host/launch/path_integral_nn.launch --rollouts 1920 --max-iter $N --no-sleep --set x_pos=0.0 --set y_pos=-10.0 --set heading=0.0 --set use_feedback_gains=$fb | tail -1 | cut -c1-330
 done
 for fb in false true; do
   echo "path_integral_bf K=2560 use_feedback_gains=$fb"
-  AR_MPPI_PARAMS_PATH=$D ./autorally_amd/bin/path_integral_bf autorally_amd/host/launch/path_integral_bf.launch --rollouts 2560 --max-iter $N --no-sleep --set x_pos=0.0 --set y_pos=-10.0 --set heading=0.0 --set use_feedback_gains=$fb | tail -1 | cut -c1-160
+  AR_MPPI_PARAMS_PATH=$D ./autorally_amd/bin/path_integral_bf autorally_amd/host/launch/path_integral_bf.launch --rollouts 2560 --max-iter $N --no-sleep --set x_pos=0.0 --set y_pos=-10.0 --set heading=0.0 --set use_feedback_gains=$fb | tail -1 | cut -c1-330
 done
 rm -rf "$D"
