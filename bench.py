@@ -419,13 +419,13 @@ def main():
                 # The latency form on the vector ALU (rollout_row.hip): no MFMA is issued; the f32 vector peak with packed
                 # multiply-adds equals the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), so the roofline block keeps
                 # that ceiling.  The configuration is latency bound: cycles per step against the recurrence of one dynamics
-                # wavefront alone on a SIMD (tools/ub/row_lds_ub.hip: 70 dependent v_pk_fma_f32 at 8 cycles, two tanh, three
-                # LDS round trips = 1 154 cycles).
+                # wavefront alone on a SIMD (tools/ub/row_lds_ub.hip, the kernel's form with the DPP state hand-over: 70
+                # dependent v_pk_fma_f32 at 8 cycles, two tanh, two LDS round trips = 1 090 cycles).
                 clk_ghz = 2.3
                 cyc = rollout_s / T * clk_ghz * 1e9
                 out["roofline"]["pipe"] = "vector ALU (v_pk_fma_f32), no MFMA issued; f32 vector peak = f32 MFMA peak"
                 out["roofline"]["recurrence"] = {
-                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": 1154.0, "frac_of_floor": 1154.0 / cyc if cyc > 0 else 0.0,
+                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": 1090.0, "frac_of_floor": 1090.0 / cyc if cyc > 0 else 0.0,
                     "clock_GHz": clk_ghz,
                     "note": "event-measured kernel time / T (launch, prologue and riders included) against one dynamics wavefront's "
                             "recurrence measured alone on a SIMD (tools/ub/row_lds_ub.hip)"}
