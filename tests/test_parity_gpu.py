@@ -421,7 +421,7 @@ def test_quad_kernel_loops_are_reproducible(K, T, layers):
         s.close()
 
 
-@pytest.mark.parametrize("variant", ["quad", "fused", "multi4", "valu"])
+@pytest.mark.parametrize("variant", ["row", "quad", "fused", "multi4", "valu"])
 def test_projective_costmap_transform(variant):
     """updateTransform (costs.cu:175-188) accepts a full homography: w = r_c1.z x + r_c2.z y + trs.z != 1
     takes the kernels' u/w, v/w path (the shipped maps are affine and skip the two divides)."""
@@ -489,7 +489,7 @@ def test_horizon_edge_cases(golden_dir, T, family):
     extra = {}
     if family == "bf":
         extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
-    variants = ["quad", "fused", "multi4", "multi1", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
+    variants = ["row", "quad", "fused", "multi4", "multi1", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
     for K in (64, 192):
         cfg = S.make_config(K, T, track="oval", **extra)
         U0 = warm_U(cfg)
@@ -510,7 +510,7 @@ def test_horizon_edge_cases(golden_dir, T, family):
 
 
 @pytest.mark.parametrize("opt", [1, 3, 16])
-@pytest.mark.parametrize("variant", ["quad", "fused", "multi4", "valu"])
+@pytest.mark.parametrize("variant", ["row", "quad", "fused", "multi4", "valu"])
 def test_slide_strides_up_to_the_horizon(opt, variant):
     """Device-resident loops (in-kernel generator, slid copy left by the tail kernel or made by the slide
     kernel, host re-upload every other tick) with optimization strides and slide strides from 1 to T,
