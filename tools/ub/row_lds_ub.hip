@@ -119,7 +119,13 @@ __global__ __launch_bounds__(256) void k_row(const float *theta, float *out, uns
 // The product's form of the step (rollout_row.hip): the new state reaches layer 0 through one DPP move (every lane pair
 // computes the same two outputs) instead of a third LDS round trip.  With s_memtime stamps around the three layers.
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool STAMPS>
+template <bool SC>
+__device__ __forceinline__ f32x2 tanh2(f32x2 z, f32x2 b)
+{
+  if (SC) return f32x2{tanh_bias(z.x, b.x), tanh_bias(z.y, b.y)};
+  return tanh_bias2(z, b);
+}
+template <bool STAMPS, bool SC = false>
 __global__ __launch_bounds__(256) void k_row_dpp(const float *theta, float *out, unsigned long long *cyc, int iters, float dt)
 {
   __shared__ __attribute__((aligned(16))) RowLds lds[4];
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void k_row_dpp(const float *theta, float *out,
     z = __builtin_elementwise_fma(W.w1[3], f32x2{shi.y, shi.y}, z);
     z = __builtin_elementwise_fma(W.w1[4], f32x2{0.1f, 0.1f}, z);
     z = __builtin_elementwise_fma(W.w1[5], f32x2{0.1f, 0.1f}, z);
-    *reinterpret_cast<f32x2 *>(&L.act[0][r][2 * p]) = tanh_bias2(z, W.b1s);
+    *reinterpret_cast<f32x2 *>(&L.act[0][r][2 * p]) = tanh2<SC>(z, W.b1s);
     __builtin_amdgcn_wave_barrier();
     if (STAMPS) STAMP(q1);
     {
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void k_row_dpp(const float *theta, float *out,
         z = __builtin_elementwise_fma(W.w2[4 * q + 2], f32x2{v[q].z, v[q].z}, z);
         z = __builtin_elementwise_fma(W.w2[4 * q + 3], f32x2{v[q].w, v[q].w}, z);
       }
-      *reinterpret_cast<f32x2 *>(&L.act[1][r][2 * p]) = tanh_bias2(z, W.b2s);
+      *reinterpret_cast<f32x2 *>(&L.act[1][r][2 * p]) = tanh2<SC>(z, W.b2s);
     }
     __builtin_amdgcn_wave_barrier();
     if (STAMPS) STAMP(q2);
@@ -210,6 +216,15 @@ int main(int argc, char **argv)
     for (auto v : c) { s += (double)v; mx = std::max(mx, v); }
     printf("6-32-32-4 row/LDS form, %d wave(s) per SIMD: %.0f cycles per step per wave (mean), %.0f (slowest wave)\n", blocks / 256,
            s / c.size() / iters, (double)mx / iters);
+  }
+  for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL((k_row_dpp<false, true>), dim3(256), dim3(256), 0, 0, d_t, d_o, d_c, iters, dt);
+  hipDeviceSynchronize();
+  {
+    std::vector<unsigned long long> c(1024);
+    hipMemcpy(c.data(), d_c, c.size() * 8, hipMemcpyDeviceToHost);
+    double s2 = 0;
+    for (auto v : c) s2 += (double)v;
+    printf("DPP form with scalar tanh (tanh_bias per value), 1 wave per SIMD: %.0f cycles per step\n", s2 / 1024 / iters);
   }
   for (int st = 0; st < 2; st++) {
     for (int rep = 0; rep < 3; rep++) {
