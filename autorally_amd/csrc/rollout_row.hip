@@ -6,17 +6,19 @@
 // Why not the matrix instruction here: at one group per CU the T-step recurrence is a latency chain, and a dependent
 // k-step of v_mfma_f32_16x16x4_f32 costs ~8 cycles (4 k per 32-cycle instruction), so a 32-input layer
 // is 8 x 33 = 264 cycles on top of a hand-over between the two waves that share the layer (the quad form: ~1 530
-// cycles per step).  A dependent v_pk_fma_f32 also issues every 8 cycles but carries TWO neurons and needs no partner:
-//   * one dynamics wave = 4 rollouts x 16 lanes; lane (r, p) owns neurons 2p, 2p+1 of every hidden layer of rollout r
-//     (outputs 2(p&1), 2(p&1)+1 of the last layer), their weights in registers as pairs;
+// cycles per step).  A dependent v_pk_fma_f32 issues every ~9 cycles too but carries TWO neurons and needs no partner:
+//   * one dynamics wave = 4 rollouts x 16 lanes = 4 DPP ROWS; lane (r, p) owns neurons 2p, 2p+1 of every hidden layer of
+//     rollout r (outputs 2(p&1), 2(p&1)+1 of the last layer), their weights in registers as pairs;
 //   * a layer = per lane the k-ascending fmaf chain of mppi_controller.cu's dot product (neural_net_model.cu:379-394;
 //     bias afterwards) -- bit-identical to every other form -- with the activation a_k broadcast to both halves of the
 //     packed multiply-add (op_sel);
-//   * the activations of a layer go through LDS inside the wave: one 8-B write per lane, eight 16-B reads per lane that
-//     are broadcasts within the 16 lanes of a rollout.  No other wave is involved: no sequence word, no poll, no
-//     barrier on the recurrence (tools/ub/row_lds_ub.hip: 1 154 cycles per step alone on a SIMD);
-//   * every lane pair (p, p ^ 1) computes the same two outputs of the last layer, so the new state reaches layer 0 of
-//     the next step through one DPP move instead of a third LDS round trip;
+//   * the activations of a layer never leave the registers: `row_newbcast:q` of the DPP hands every lane of a row the
+//     value of lane q, one v_mov_b32_dpp per k, issued in the shadow of the multiply-add of k-1 (round 3, second half;
+//     before that a layer's activations went through LDS -- one 8-B write and eight 16-B broadcast reads per lane and layer:
+//     tools/ub/row_bcast_ub.hip measures the recurrence alone on a SIMD at 865 cycles per step against 1 120).  No other
+//     wave is involved: no sequence word, no poll, no barrier on the recurrence;
+//   * lanes 0 and 1 of a row hold the state pair (s3, s4) / (s5, s6) (every even / odd lane computes the same two
+//     outputs), so layer 0 of the next step reads the new state through four of the same moves;
 //   * state records, controls, texels, noise: the rings and riders of group_roles.hpp, one rider per SIMD beside one
 //     dynamics wave.
 #include "group_roles.hpp"
@@ -39,7 +41,6 @@ __device__ unsigned long long g_row_stamps[16];
 #else
 #define RSTAMP(i) do { } while (0)
 #endif
-
 template <int H>
 struct RowShared {
   static constexpr int NW = 4;            // dynamics waves per group, four rollouts each
@@ -57,7 +58,7 @@ struct RowShared {
   int rng_pub[64];
   int fail[4];
   int fin[8];
-  float act[NW][2][4][H];                   // per dynamics wave: activations of layer 0 / layer 1 of its four rollouts
+  float dump[NW][64][2];                    // where lanes p >= 2 of a dynamics wave put their copy of the state pair (never read)
 };
 
 template <int H>
@@ -96,33 +97,47 @@ __device__ __forceinline__ void row_load(const float *rowpack, int p, RowWeights
   W.b3 = f32x2{c.x, c.y};
 }
 
-// z = sum_k w[k] * a[k], k ascending, one fmaf per k and neuron (the pair shares a[k])
-template <int N>
-__device__ __forceinline__ f32x2 row_dot(const f32x2 (&w)[N], const float4 (&v)[N / 4])
+// The activation of neuron k of this lane's rollout, from the registers of the lane that computed it: a rollout is one
+// 16-lane DPP row, `row_newbcast:q` hands every lane of a row the value of lane q (one v_mov_b32_dpp per k, off the
+// dependent chain).  gfx90a+ DPP control 0x150 + q; works on 32-bit operands on gfx950 (tools/ub/row_bcast_ub.hip checks
+// the bits against the LDS form).
+template <int Q>
+__device__ __forceinline__ float row_bc(float a)
+{
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0x150 + Q, 0xF, 0xF, false));
+}
+// z = sum_k w[k] * a[k] over the 32 activations of the rollout (lane q holds a[2q], a[2q+1]), k ascending.  Written as the
+// schedule it has to be: the move for k+1, then the multiply-add of k -- a dependent v_pk_fma_f32 can issue every ~9 cycles,
+// the move fills the slot in between -- and held there by scheduling barriers (left alone inside the kernel, the scheduler
+// hoists all 32 moves in front of the chain: ~130 cycles more per layer).
+template <int K>
+__device__ __forceinline__ float row_bc_k(f32x2 a)
+{
+  return row_bc<(K >> 1)>((K & 1) ? a.y : a.x);
+}
+template <int K>
+__device__ __forceinline__ void row_dot_step(f32x2 &z, float &v, const f32x2 *w, f32x2 a)
+{
+  const float vn = row_bc_k<(K + 1 < 32 ? K + 1 : 31)>(a);
+  z = __builtin_elementwise_fma(w[K], f32x2{v, v}, z);
+  __builtin_amdgcn_sched_barrier(0);
+  v = vn;
+}
+__device__ __forceinline__ f32x2 row_dot_bc(const f32x2 *w, f32x2 a)
 {
   f32x2 z = {0.0f, 0.0f};
-#pragma unroll
-  for (int q = 0; q < N / 4; q++) {
-    z = __builtin_elementwise_fma(w[4 * q + 0], f32x2{v[q].x, v[q].x}, z);
-    z = __builtin_elementwise_fma(w[4 * q + 1], f32x2{v[q].y, v[q].y}, z);
-    z = __builtin_elementwise_fma(w[4 * q + 2], f32x2{v[q].z, v[q].z}, z);
-    z = __builtin_elementwise_fma(w[4 * q + 3], f32x2{v[q].w, v[q].w}, z);
-  }
+  float v = row_bc_k<0>(a);
+  __builtin_amdgcn_sched_barrier(0);
+#define RD4(K) row_dot_step<K>(z, v, w, a); row_dot_step<K + 1>(z, v, w, a); row_dot_step<K + 2>(z, v, w, a); row_dot_step<K + 3>(z, v, w, a);
+  RD4(0) RD4(4) RD4(8) RD4(12) RD4(16) RD4(20) RD4(24) RD4(28)
+#undef RD4
   return z;
-}
-
-// the partner lane's pair (lane p ^ 1 of the same rollout): one DPP move per register, no LDS
-__device__ __forceinline__ f32x2 row_partner(f32x2 v)
-{
-  f32x2 o;
-  o.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-  o.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0xB1, 0xF, 0xF, false));
-  return o;
 }
 
 template <int H>
 __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> &sh, const int w)
 {
+  static_assert(H == 32, "row_dot_bc: 32 activations, two per lane of a 16-lane row");
   const int lane = threadIdx.x & 63;
   const int r = lane >> 4, p = lane & 15;
   const int jr = 4 * w + r;  // rollout of the group
@@ -147,11 +162,13 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
   const lds_float_p p_u = (lds_float_p)&sh.ctl_rec[0][jr][0];  // clamped u0, u1 of this lane's rollout (control wave)
   constexpr int kCtlSlot = kRolloutsPerWave * 4;                // floats per ring slot of ctl_rec
-  float(*act0)[H] = sh.act[w][0];
-  float(*act1)[H] = sh.act[w][1];
+  // The state record of a step is stored by EVERY lane: lanes 0, 1 of a row into the record (ring slot stride below), the
+  // others into a dump row nobody reads -- no exec masking on the recurrence.
+  const uint32_t a_rec0 = (p < 2) ? lds_addr(&sh.rec[0][jr][2 * p]) : lds_addr(&sh.dump[w][lane][0]);
+  const uint32_t rec_stride = (p < 2) ? (uint32_t)(sizeof(float) * kRolloutsPerWave * 4) : 0u;
 
-  // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p -- every lane pair (p, p ^ 1) of a rollout
-  // computes the same output pair, so the whole state is one DPP move away
+  // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p -- every even / odd lane of a rollout computes
+  // the same output pair; layer 0 takes the pairs of lanes 0 and 1 of the row
   f32x2 sp = odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
   if (w == 0) RSTAMP(2);  // weights in registers
@@ -165,11 +182,10 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   for (int t = 0; t < T - 1; t++) {
     const int slot = t & (kGRing - 1);
     const float u0 = u0n, u1 = u1n;
-    const f32x2 so = row_partner(sp);
-    const f32x2 slo = odd ? so : sp, shi = odd ? sp : so;  // (s3, s4), (s5, s6)
+    const f32x2 slo = f32x2{row_bc<0>(sp.x), row_bc<0>(sp.y)}, shi = f32x2{row_bc<1>(sp.x), row_bc<1>(sp.y)};  // (s3, s4), (s5, s6)
     // record for the pose / cost waves: the state BEFORE the update (the ring slot was checked at the end of the
     // previous step); then the publication -- which also says: this wave is done with the control record of step t
-    if (p < 2) *reinterpret_cast<f32x2 *>(&sh.rec[slot][jr][2 * p]) = sp;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)slot * rec_stride), "v"(sp) : "memory");
     lds_publish(a_myseq, t + 1);
     // layer 0: [s3, s4, s5, s6, u0, u1]
     f32x2 z = {0.0f, 0.0f};
@@ -179,39 +195,38 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
     z = __builtin_elementwise_fma(W.w1[3], f32x2{shi.y, shi.y}, z);
     z = __builtin_elementwise_fma(W.w1[4], f32x2{u0, u0}, z);
     z = __builtin_elementwise_fma(W.w1[5], f32x2{u1, u1}, z);
-    *reinterpret_cast<f32x2 *>(&act0[r][2 * p]) = tanh_bias2(z, W.b1s);
-    __builtin_amdgcn_wave_barrier();
-    {
-      float4 v[H / 4];
-#pragma unroll
-      for (int q = 0; q < H / 4; q++) v[q] = *reinterpret_cast<const float4 *>(&act0[r][4 * q]);
-      *reinterpret_cast<f32x2 *>(&act1[r][2 * p]) = tanh_bias2(row_dot<H>(W.w2, v), W.b2s);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // requested now, used at the end of the step (behind the output layer): the control wave's count, then this
-    // rollout's controls of step t+1 (valid if the count read before them is >= t+2), and the cost wave's progress
+    // Requested now, used at the end of the step: the control wave's count, then this rollout's controls of step t+1
+    // (valid if the count read before them is >= t+2), and the cost wave's progress.  In FRONT of layer 1: the chains
+    // below have no LDS wait of their own to hide these reads behind, and a read that is still in flight when a chain
+    // starts stalls it (the packed multiply-adds formally read the odd halves of the move registers, which is where the
+    // register allocator puts pending results: rollout 55.0 -> 52.4 us with the reads moved here).
     const int sn = ((t + 1) & (kGRing - 1)) * kCtlSlot;
     const int cp_v = *p_pub;
     float un0_v = p_u[sn], un1_v = p_u[sn + 1];
     const int cd_v = *p_cd;
-    {
-      float4 v[H / 4];
-#pragma unroll
-      for (int q = 0; q < H / 4; q++) v[q] = *reinterpret_cast<const float4 *>(&act1[r][4 * q]);
-      const f32x2 d = row_dot<H>(W.w3, v) + W.b3;
-      sp = __builtin_elementwise_fma(d, f32x2{a.dt, a.dt}, sp);  // incrementState, neural_net_model.cu:334-344
-    }
+    const f32x2 a0 = tanh_bias2(z, W.b1s);
+    const f32x2 a1 = tanh_bias2(row_dot_bc(W.w2, a0), W.b2s);
     // step t+1 may start when the control wave has published it (it runs ahead) and the ring slot of its state record
     // is free: that slot held step t+1 - kGRing, consumed once cost_done >= t+2 - kGRing
     // (a shorter leash for the riders -- waiting when the cost wave is more than 2 / 3 / 5 steps behind instead of a full
-    // ring -- was measured: 124 / 72.6 / 58.0 us against 55.2 us; the riders need the slack)
+    // ring -- was measured: 124 / 72.6 / 58.0 us against 55.2 us; the riders need the slack).
+    // The scalar side of that test in front of the output layer's chain, the (cold) wait behind it.
     const int want = t + 2, want_cd = t + 2 - kGRing;
-    int cp = __builtin_amdgcn_readfirstlane(cp_v), cd = __builtin_amdgcn_readfirstlane(cd_v);
-    while (((cp < want) | (cd < want_cd)) && --budget > 0) {
-      cp = __builtin_amdgcn_readfirstlane(*p_pub);
-      un0_v = p_u[sn];
-      un1_v = p_u[sn + 1];
-      cd = __builtin_amdgcn_readfirstlane(*p_cd);
+    const int cp_e = __builtin_amdgcn_readfirstlane(cp_v), cd_e = __builtin_amdgcn_readfirstlane(cd_v);
+    const bool need_wait = (cp_e < want) | (cd_e < want_cd);
+    {
+      const f32x2 d = row_dot_bc(W.w3, a1) + W.b3;
+      sp = __builtin_elementwise_fma(d, f32x2{a.dt, a.dt}, sp);  // incrementState, neural_net_model.cu:334-344
+      asm volatile("" : "+v"(sp));  // the chain stays here (otherwise it is sunk below the wait, away from its moves)
+    }
+    if (__builtin_expect(need_wait, 0)) {
+      int cp = cp_e, cd = cd_e;
+      while (((cp < want) | (cd < want_cd)) && --budget > 0) {
+        cp = __builtin_amdgcn_readfirstlane(*p_pub);
+        un0_v = p_u[sn];
+        un1_v = p_u[sn + 1];
+        cd = __builtin_amdgcn_readfirstlane(*p_cd);
+      }
     }
     u0n = un0_v;
     u1n = un1_v;
@@ -219,8 +234,7 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   if (w == 0) RSTAMP(4);  // T loop done
   {  // the record of step T-1
     const int t = T - 1;
-    if (p < 2) *reinterpret_cast<f32x2 *>(&sh.rec[t & (kGRing - 1)][jr][2 * p]) = sp;
-    __builtin_amdgcn_wave_barrier();
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)(t & (kGRing - 1)) * rec_stride), "v"(sp) : "memory");
     lds_publish(a_myseq, t + 1);
   }
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));

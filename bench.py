@@ -229,6 +229,8 @@ def main():
                     help="separate pass after the timed region: steps timed one by one (median solve latency)")
     ap.add_argument("--event-solves", type=int, default=64,
                     help="separate pass after the timed region: solves with HIP events around every stage")
+    ap.add_argument("--sustained-s", type=float, default=2.0,
+                    help="separate pass after the timed region: the step repeated for this many seconds (sustained rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the multi-process driver with gloo and the CPU oracle (no GPU, not a benchmark)")
@@ -320,6 +322,19 @@ def main():
     elapsed = timed_block()
     # the same block repeated (off the headline number): spread of the measurement
     block_s = [elapsed] + [timed_block() for _ in range(max(0, args.repeats - 1))]
+    # separate pass 0: a sustained run (off the headline number): the same step for --sustained-s seconds of wall time --
+    # what a controller that runs for minutes sees, and long enough for a utilisation sampler to catch the GPU at work
+    sustained = None
+    if cuda and args.sustained_s > 0:
+        sync()
+        n_s, t_s = 0, time.perf_counter()
+        while time.perf_counter() - t_s < args.sustained_s:
+            run_steps(500)
+            n_s += 500
+        sync()
+        el_s = time.perf_counter() - t_s
+        sustained = {"seconds": el_s, "solves": n_s, "ms_per_step": 1e3 * el_s / n_s,
+                     "value": cfg["K"] * cfg.get("num_iters", 1) * n_s / el_s, "unit": "rollouts/s (this rank)"}
     # separate pass 1: every step timed on its own (one ctypes call per ABI call): median solve latency
     per_solve_ms = None
     if cuda and rank == 0 and args.latency_solves > 0:
@@ -383,6 +398,7 @@ def main():
             "max_ms_per_step": 1e3 * max(block_s) / args.steps,
             "median_value": K * iters * args.steps * world / float(np.median(block_s)),
             "per_solve_ms": per_solve_ms,
+            "sustained": sustained,
             "instances": instances,
         }
         if cuda:

@@ -8,7 +8,7 @@ mkdir -p gpurun_out/$tag
 for i in $(seq 1 $n); do
   for arm in A B; do
     lib=$A; [ $arm = B ] && lib=$B
-    MPPI_LIB_PATH=$PWD/$lib python3 bench.py --no-cpu-baseline --repeats 3 --latency-solves 0 "$@" > gpurun_out/$tag/$arm$i.json 2> gpurun_out/$tag/$arm$i.err || { echo "arm $arm failed"; tail -3 gpurun_out/$tag/$arm$i.err; exit 1; }
+    MPPI_LIB_PATH=$PWD/$lib python3 bench.py --no-cpu-baseline --repeats 3 --latency-solves 0 --sustained-s 0 "$@" > gpurun_out/$tag/$arm$i.json 2> gpurun_out/$tag/$arm$i.err || { echo "arm $arm failed"; tail -3 gpurun_out/$tag/$arm$i.err; exit 1; }
     python3 - <<PY
 import json
 d=json.load(open("gpurun_out/$tag/$arm$i.json"))

@@ -7,7 +7,7 @@ mkdir -p gpurun_out/$tag
 for i in $(seq 1 $n); do
   for lib in $libs; do
     name=$(basename $lib .so)
-    MPPI_LIB_PATH=$PWD/$lib python3 bench.py --no-cpu-baseline --repeats 3 --latency-solves 0 "$@" > gpurun_out/$tag/$name.$i.json 2> gpurun_out/$tag/$name.$i.err || { echo "$name failed"; tail -3 gpurun_out/$tag/$name.$i.err; continue; }
+    MPPI_LIB_PATH=$PWD/$lib python3 bench.py --no-cpu-baseline --repeats 3 --latency-solves 0 --sustained-s 0 "$@" > gpurun_out/$tag/$name.$i.json 2> gpurun_out/$tag/$name.$i.err || { echo "$name failed"; tail -3 gpurun_out/$tag/$name.$i.err; continue; }
     python3 - <<PY
 import json
 d=json.load(open("gpurun_out/$tag/$name.$i.json"))

@@ -9,7 +9,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/prof/$tag
 rm -rf "$out" && mkdir -p "$out/summary"
-B="python3 bench.py --no-cpu-baseline --repeats 1 --latency-solves 0 --event-solves 0 $*"
+B="python3 bench.py --no-cpu-baseline --repeats 1 --latency-solves 0 --sustained-s 0 --event-solves 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $B --steps 100 --warmup 10 > "$out/bench_trace.json" 2> "$out/trace.err" || { tail -5 "$out/trace.err"; exit 1; }
 python3 tools/prof_summary.py stats "$out/trace" "$out/summary/kernel_stats.csv"
 PM="--steps 20 --warmup 5"
