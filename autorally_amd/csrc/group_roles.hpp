@@ -225,6 +225,80 @@ __device__ __forceinline__ void group_pose_wave(const RolloutArgs &a, SH &sh)
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kPose]));
 }
 
+// ---------------------------------- pose wave, four steps per iteration ----------------------------------
+// lane = 4 j + q works on step t0 + q of rollout j.  The sin/cos pair and the two texel addresses of a step -- nine tenths
+// of the pose wave's instructions -- depend only on that step's pose, so four steps of a rollout run side by side; what is
+// sequential, the three Euler chains x' = fma(sd0, dt, x), y' = .., yaw' = .. (incrementState, neural_net_model.cu:334-344),
+// runs link by link with the link's derivative broadcast inside the quad (one DPP move per link): the same operations in
+// the same order as one step per iteration, hence the same bits.  Why: with the activations of the row form travelling by
+// DPP (rollout_row.hip) the dynamics waves no longer leave the issue slots a one-step-per-iteration pose wave needs --
+// it had become the pace of the group (rollout 52.0 us, 49.5 us with its arithmetic removed).
+template <int Q>
+__device__ __forceinline__ float quad_bc(float v)
+{
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, false));  // quad_perm [Q, Q, Q, Q]
+}
+// the value before each of the four links of v' = fma(d, dt, v) (this lane's: vq) and after the last (v_out)
+__device__ __forceinline__ void quad_chain(float v, float d, float dt, int q, float &vq, float &v_out)
+{
+  const float v1 = fmaf(quad_bc<0>(d), dt, v);
+  const float v2 = fmaf(quad_bc<1>(d), dt, v1);
+  const float v3 = fmaf(quad_bc<2>(d), dt, v2);
+  v_out = fmaf(quad_bc<3>(d), dt, v3);
+  const float lo = (q == 0) ? v : v1, hi = (q == 2) ? v2 : v3;
+  vq = (q < 2) ? lo : hi;
+}
+template <class SH, bool AFFINE>
+__device__ __forceinline__ void group_pose_wave4(const RolloutArgs &a, SH &sh)
+{
+  using R = GroupRoles<SH>;
+  constexpr int NSW = SH::NSW;
+  static_assert(kRolloutsPerWave == 16 && kGRing >= 8, "lane = 4 j + q");
+  const int lane = threadIdx.x & 63;
+  const int j = lane >> 2, q = lane & 3;
+  const int T = a.T;
+  const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]);
+  const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
+  const uint32_t a_mypub = lds_addr(&sh.pose_pub[lane]);
+  float x = a.state[0], y = a.state[1], yaw = a.state[2];  // the pose before step t0, the same in the four lanes of a rollout
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kPose + 1), seen = 0, cdone = 0;
+  for (int t0 = 0; t0 < T; t0 += 4) {
+    const int t = t0 + q;
+    const int tend = min(t0 + 4, T);  // the chunk is steps [t0, tend); lanes of later steps compute on whatever the ring holds
+    // rec(t) is written before wave 0 publishes the first swap of step t (forms whose dynamics waves each write
+    // the records of their own rollouts, SH::kRecByAll: before every one of them has published step t)
+    const int need = (tend - 1) * NSW + 1;
+    while (seen < need && --budget > 0) {
+      seen = SH::kRecByAll ? group_seq_min(sh) : lds_peek(a_seq0);
+      if (seen < need) __builtin_amdgcn_s_sleep(1);
+    }
+    const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kGRing - 1)][j][0]);  // s3 s4 s5 s6
+    // computeKinematics + incrementState for x, y, yaw (neural_net_model.cu:346-355, 334-344)
+    float yaw_q, yaw_n, x_q, x_n, y_q, y_n;
+    quad_chain(yaw, a.negate_yaw_der ? -r0.w : r0.w, a.dt, q, yaw_q, yaw_n);
+    float spsi, cpsi, tf = 0.0f, tb = 0.0f;
+#ifdef MPPI_DIAG_NOPOSE  // diagnostic build: no sin/cos, no texel fetches
+    spsi = 0.0f; cpsi = 1.0f;
+#else
+    sincos_fast(yaw_q, spsi, cpsi);
+#endif
+    quad_chain(x, fmaf(cpsi, r0.y, -(spsi * r0.z)), a.dt, q, x_q, x_n);
+    quad_chain(y, fmaf(spsi, r0.y, cpsi * r0.z), a.dt, q, y_q, y_n);
+#ifdef MPPI_DIAG_NOPOSE
+    tf = x_q; tb = y_q;
+#else
+    const float st[3] = {x_q, y_q, yaw_q};
+    track_fetch<AFFINE>(a.cost, st, cpsi, spsi, tf, tb);
+#endif
+    x = x_n; y = y_n; yaw = yaw_n;
+    // the texels' ring slots held steps t - kGRing, which the cost wave must have consumed
+    while (cdone < tend - kGRing && --budget > 0) cdone = lds_peek(a_cd);
+    if (t < T) *reinterpret_cast<float2 *>(&sh.tex[t & (kGRing - 1)][j][0]) = make_float2(tf, tb);
+    lds_publish(a_mypub, tend);  // steps < tend are out
+  }
+  spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kPose]));
+}
+
 // the end of the cost wave: wait for every other wave's finished word, poison on a raised fail word
 template <class SH>
 __device__ __forceinline__ float group_settle(SH &sh, int budget, float J)
@@ -290,6 +364,74 @@ __device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
   }
   J = group_settle(sh, budget, J);
   a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
+}
+
+// ---------------------------------- cost wave, four steps per iteration ----------------------------------
+// lane = 4 j + q works on step t0 + q of rollout j (the pose wave's layout).  The cost terms of a step depend on that
+// step's records only; what is sequential -- the sticky crash flag (an inclusive OR over the steps) and the running mean
+// (mppi_controller.cu:160-166) -- runs link by link over the quad, the link's operand broadcast by one DPP move: the
+// reference's operations in the reference's order, hence the bits of the one-step-per-iteration wave.
+template <int Q>
+__device__ __forceinline__ int quad_bc_i(int v)
+{
+  return __builtin_amdgcn_mov_dpp(v, Q * 0x55, 0xF, 0xF, false);
+}
+template <class SH, bool CTRL>
+__device__ __forceinline__ void group_cost_wave4(const RolloutArgs &a, SH &sh)
+{
+  using R = GroupRoles<SH>;
+  const int lane = threadIdx.x & 63;
+  const int j = lane >> 2, q = lane & 3;
+  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int T = a.T;
+  const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
+  const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
+  int crash = 0, budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kCost + 1), seen = 0;
+  float J = 0.0f;  // crash, J: the values before step t0, the same in the four lanes of a rollout
+  for (int t0 = 0; t0 < T; t0 += 4) {
+    const int t = t0 + q;
+    const int tend = min(t0 + 4, T);
+    // the pose wave publishes the texels of a step after it has read that step's state record: the records of the chunk
+    // are there (ctl(t) was published before the dynamics waves could start step t)
+    while (seen < tend && --budget > 0) {
+      seen = lds_peek(a_pose);
+      if (seen < tend) __builtin_amdgcn_s_sleep(1);
+    }
+    const float4 r0 = *reinterpret_cast<const float4 *>(&sh.rec[t & (kGRing - 1)][j][0]);      // s3 s4 s5 s6
+    const float4 r1 = *reinterpret_cast<const float4 *>(&sh.ctl_rec[t & (kGRing - 1)][j][0]);  // u0 u1 du0 du1
+    const float2 tx = *reinterpret_cast<const float2 *>(&sh.tex[t & (kGRing - 1)][j][0]);      // front, back texel
+    lds_publish(a_mydone, tend);  // executes after the three reads (the LDS runs a wave's instructions in order)
+    const bool counted = (t > 0) & (t < T);  // the t = 0 evaluation is discarded (Q5); lanes beyond T hold stale records
+    // getCrash of update t-1 (costs.cu:301-305), then the track term's flag (:402 evaluates the track first)
+    int e = (int)(fabsf(r0.x) >= kRollCrash) | (int)(tx.x >= a.cost.boundary_threshold) | (int)(tx.y >= a.cost.boundary_threshold);
+    e = counted ? e : 0;
+    const int c0 = crash | quad_bc_i<0>(e), c1 = c0 | quad_bc_i<1>(e), c2 = c1 | quad_bc_i<2>(e), c3 = c2 | quad_bc_i<3>(e);
+    const int lo = (q == 0) ? c0 : c1, hi = (q == 2) ? c2 : c3;
+    int crash_q = (q < 2) ? lo : hi;  // the flag cost_terms_b sees at step t
+    crash = c3;
+#ifdef MPPI_DIAG_NOCOST  // diagnostic build: no cost arithmetic
+    const float c = r0.y + r1.x + tx.x + (float)crash_q;
+#else
+    CostTerms ct;
+    cost_terms_a<CTRL>(a.cost, a.nu, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, ct);
+    const float c = cost_terms_b(a.cost, ct, tx.x, tx.y, crash_q);  // ORs the track flag in again: no change
+#endif
+    // running mean over 1..T-1 (Q5), one link per step of the chunk
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const int tl = t0 + l;  // wave-uniform
+      const float cl = (l == 0) ? quad_bc<0>(c) : (l == 1) ? quad_bc<1>(c) : (l == 2) ? quad_bc<2>(c) : quad_bc<3>(c);
+      if (tl > 0 && tl < T) {
+#ifdef MPPI_DIAG_NOCOST
+        J = J + cl + (float)a.inv_t[tl];
+#else
+        J = running_mean(J, cl, tl, a.inv_t[tl]);
+#endif
+      }
+    }
+  }
+  J = group_settle(sh, budget, J);
+  if (q == 0) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
 }
 
 }  // namespace mppi

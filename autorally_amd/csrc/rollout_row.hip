@@ -265,9 +265,9 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   if (role >= 4) __builtin_amdgcn_s_setprio(MPPI_ROW_RIDER_PRIO);
 #endif
   if (role < 4) row_dynamics<H>(a, sh, role);
-  else if (role == R::kCost) { group_cost_wave<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
+  else if (role == R::kCost) { group_cost_wave4<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
   else if (role == R::kCtl) { group_control_wave(a, sh); RSTAMP(6); }
-  else if (role == R::kPose) { group_pose_wave<SH, AFFINE>(a, sh); RSTAMP(7); }
+  else if (role == R::kPose) { group_pose_wave4<SH, AFFINE>(a, sh); RSTAMP(7); }
   else { group_rng_wave(a, sh); RSTAMP(8); }
 }
 
@@ -298,9 +298,9 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
   }
   __syncthreads();
   if (role < 4) row_dynamics<H>(a, sh, role);
-  else if (role == R::kCost) group_cost_wave<SH, CTRL>(a, sh);
+  else if (role == R::kCost) group_cost_wave4<SH, CTRL>(a, sh);
   else if (role == R::kCtl) group_control_wave(a, sh);
-  else if (role == R::kPose) group_pose_wave<SH, AFFINE>(a, sh);
+  else if (role == R::kPose) group_pose_wave4<SH, AFFINE>(a, sh);
   else group_rng_wave(a, sh);
 }
 
