@@ -34,7 +34,7 @@ ROLLOUT_BYTES_BUFFERED_NOISE = 16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
 TRAFFIC_PROFILES = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r03_i_*_pmc.json"))) + [os.path.join(ROOT, "profiles", f) for f in (
-    "r03_e_headline_row_pmc.json", "r03_d_headline_pmc.json", "r03_d_cfg4_pmc.json", "r03_c_k32768_multi4_pmc.json", "r02_h_k8192_multi2_pmc.json")]
+    "r03_j_headline_row_pmc.json", "r03_e_headline_row_pmc.json", "r03_d_headline_pmc.json", "r03_d_cfg4_pmc.json", "r03_c_k32768_multi4_pmc.json", "r02_h_k8192_multi2_pmc.json")]
 
 
 def measured_traffic(cfg, variant):
@@ -435,16 +435,18 @@ def main():
                 # The latency form on the vector ALU (rollout_row.hip): no MFMA is issued; the f32 vector peak with packed
                 # multiply-adds equals the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), so the roofline block keeps
                 # that ceiling.  The configuration is latency bound: cycles per step against the recurrence of one dynamics
-                # wavefront alone on a SIMD (tools/ub/row_lds_ub.hip, the kernel's form with the DPP state hand-over: 70
-                # dependent v_pk_fma_f32 at 8 cycles, two tanh, two LDS round trips = 1 090 cycles).
+                # wavefront alone on a SIMD (tools/ub/row_bcast_ub.hip, profiles/r03_j_row_bcast_ub.txt: the activations handed
+                # round by DPP, 70 dependent v_pk_fma_f32 at ~9 cycles + two tanh = 865 cycles; with the per-step bookkeeping of
+                # the product's dynamics wave -- record, sequence word, next controls, progress test -- 1 024).
                 clk_ghz = 2.3
                 cyc = rollout_s / T * clk_ghz * 1e9
                 out["roofline"]["pipe"] = "vector ALU (v_pk_fma_f32), no MFMA issued; f32 vector peak = f32 MFMA peak"
                 out["roofline"]["recurrence"] = {
-                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": 1090.0, "frac_of_floor": 1090.0 / cyc if cyc > 0 else 0.0,
+                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": 865.0, "frac_of_floor": 865.0 / cyc if cyc > 0 else 0.0,
+                    "with_bookkeeping_cycles_per_step": 1024.0,
                     "clock_GHz": clk_ghz,
                     "note": "event-measured kernel time / T (launch, prologue and riders included) against one dynamics wavefront's "
-                            "recurrence measured alone on a SIMD (tools/ub/row_lds_ub.hip)"}
+                            "recurrence measured alone on a SIMD (tools/ub/row_bcast_ub.hip, form A / form Q0)"}
             if "quad" in variant and cfg.get("bf_W") is None:
                 # The configuration is latency bound (one 16-rollout group per CU, T sequential steps), so next
                 # to the throughput roofline: the step time of the recurrence against (a) what its two dynamics
