@@ -58,7 +58,8 @@ struct RowShared {
   int rng_pub[64];
   int fail[4];
   int fin[8];
-  float dump[NW][64][2];                    // where lanes p >= 2 of a dynamics wave put their copy of the state pair (never read)
+  float dump[NW][64 * 2 + (kGRing - 1) * kRolloutsPerWave * 4];  // where lanes p >= 2 of a dynamics wave put their copy of the state
+                                                                 // pair (never read): 8 B per lane, moved along with the ring slot
 };
 
 template <int H>
@@ -157,15 +158,14 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
 
   const uint32_t a_myseq = lds_addr(&sh.xseq[w][lane]);
   typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
-  typedef const volatile float __attribute__((address_space(3))) *lds_float_p;
+  typedef const volatile f32x2 __attribute__((address_space(3))) *lds_f2_p;
   const lds_int_p p_pub = (lds_int_p)&sh.ctl_pub[0];
-  const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
-  const lds_float_p p_u = (lds_float_p)&sh.ctl_rec[0][jr][0];  // clamped u0, u1 of this lane's rollout (control wave)
-  constexpr int kCtlSlot = kRolloutsPerWave * 4;                // floats per ring slot of ctl_rec
-  // The state record of a step is stored by EVERY lane: lanes 0, 1 of a row into the record (ring slot stride below), the
-  // others into a dump row nobody reads -- no exec masking on the recurrence.
-  const uint32_t a_rec0 = (p < 2) ? lds_addr(&sh.rec[0][jr][2 * p]) : lds_addr(&sh.dump[w][lane][0]);
-  const uint32_t rec_stride = (p < 2) ? (uint32_t)(sizeof(float) * kRolloutsPerWave * 4) : 0u;
+  const lds_f2_p p_u = (lds_f2_p)&sh.ctl_rec[0][jr][0];  // clamped (u0, u1) of this lane's rollout (control wave), ring slot 0
+  constexpr int kSlotF2 = kRolloutsPerWave * 2;          // f32x2 per ring slot of ctl_rec (and of rec)
+  // The state record of a step is stored by EVERY lane: lanes 0, 1 of a row into the record, the others into a dump row
+  // nobody reads -- no exec masking on the recurrence; both move along with the ring slot (one address add for all lanes).
+  const uint32_t a_rec0 = (p < 2) ? lds_addr(&sh.rec[0][jr][2 * p]) : lds_addr(&sh.dump[w][2 * lane]);
+  constexpr uint32_t kRecStride = sizeof(float) * kRolloutsPerWave * 4;
 
   // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p -- every even / odd lane of a rollout computes
   // the same output pair; layer 0 takes the pairs of lanes 0 and 1 of the row
@@ -174,18 +174,18 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   if (w == 0) RSTAMP(2);  // weights in registers
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   if (w == 0) RSTAMP(3);  // first controls published: the T loop starts
-  float u0n = p_u[0], u1n = p_u[1];
-  asm volatile("" : "+v"(u0n), "+v"(u1n));  // pinned: the wait for these reads sits here, not inside the loop
+  f32x2 un = p_u[0];
+  asm volatile("" : "+v"(un));  // pinned: the wait for this read sits here, not inside the loop
 
   // Steps 0 .. T-2 in full; of step T-1 only the state record goes out (its update feeds nothing: the cost is the
   // running mean over the states BEFORE the updates of steps 1..T-1, mppi_controller.cu:160-177)
   for (int t = 0; t < T - 1; t++) {
     const int slot = t & (kGRing - 1);
-    const float u0 = u0n, u1 = u1n;
+    const f32x2 u = un;
     const f32x2 slo = f32x2{row_bc<0>(sp.x), row_bc<0>(sp.y)}, shi = f32x2{row_bc<1>(sp.x), row_bc<1>(sp.y)};  // (s3, s4), (s5, s6)
-    // record for the pose / cost waves: the state BEFORE the update (the ring slot was checked at the end of the
-    // previous step); then the publication -- which also says: this wave is done with the control record of step t
-    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)slot * rec_stride), "v"(sp) : "memory");
+    // record for the pose / cost waves: the state BEFORE the update (the ring slot is free: see the end of the step);
+    // then the publication -- which also says: this wave is done with the control record of step t
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)slot * kRecStride), "v"(sp) : "memory");
     lds_publish(a_myseq, t + 1);
     // layer 0: [s3, s4, s5, s6, u0, u1]
     f32x2 z = {0.0f, 0.0f};
@@ -193,48 +193,48 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
     z = __builtin_elementwise_fma(W.w1[1], f32x2{slo.y, slo.y}, z);
     z = __builtin_elementwise_fma(W.w1[2], f32x2{shi.x, shi.x}, z);
     z = __builtin_elementwise_fma(W.w1[3], f32x2{shi.y, shi.y}, z);
-    z = __builtin_elementwise_fma(W.w1[4], f32x2{u0, u0}, z);
-    z = __builtin_elementwise_fma(W.w1[5], f32x2{u1, u1}, z);
-    // Requested now, used at the end of the step: the control wave's count, then this rollout's controls of step t+1
-    // (valid if the count read before them is >= t+2), and the cost wave's progress.  In FRONT of layer 1: the chains
-    // below have no LDS wait of their own to hide these reads behind, and a read that is still in flight when a chain
-    // starts stalls it (the packed multiply-adds formally read the odd halves of the move registers, which is where the
-    // register allocator puts pending results: rollout 55.0 -> 52.4 us with the reads moved here).
-    const int sn = ((t + 1) & (kGRing - 1)) * kCtlSlot;
+    z = __builtin_elementwise_fma(W.w1[4], f32x2{u.x, u.x}, z);
+    z = __builtin_elementwise_fma(W.w1[5], f32x2{u.y, u.y}, z);
+    // Requested now, used at the end of the step: the control wave's count, then this rollout's controls of step t+1 as
+    // ONE 8-B read into the pair the packed multiply-adds of layer 0 take them from (valid if the count read before them
+    // is >= t+2).  In FRONT of layer 1: the chains below have no LDS wait of their own to hide these reads behind, and a
+    // read that is still in flight when a chain starts stalls it (the packed multiply-adds formally read the odd halves of
+    // the move registers, which is where the register allocator puts pending results: rollout 55.0 -> 52.4 us with the
+    // reads moved here).
+    const int sn = ((t + 1) & (kGRing - 1)) * kSlotF2;
     const int cp_v = *p_pub;
-    float un0_v = p_u[sn], un1_v = p_u[sn + 1];
-    const int cd_v = *p_cd;
+    un = p_u[sn];
     const f32x2 a0 = tanh_bias2(z, W.b1s);
     const f32x2 a1 = tanh_bias2(row_dot_bc(W.w2, a0), W.b2s);
-    // step t+1 may start when the control wave has published it (it runs ahead) and the ring slot of its state record
-    // is free: that slot held step t+1 - kGRing, consumed once cost_done >= t+2 - kGRing
-    // (a shorter leash for the riders -- waiting when the cost wave is more than 2 / 3 / 5 steps behind instead of a full
-    // ring -- was measured: 124 / 72.6 / 58.0 us against 55.2 us; the riders need the slack).
-    // The scalar side of that test in front of the output layer's chain, the (cold) wait behind it.
-    const int want = t + 2, want_cd = t + 2 - kGRing;
-    const int cp_e = __builtin_amdgcn_readfirstlane(cp_v), cd_e = __builtin_amdgcn_readfirstlane(cd_v);
-    const bool need_wait = (cp_e < want) | (cd_e < want_cd);
+    // Step t+1 may start when the control wave has published it (it runs ahead).  That also says that the ring slot of
+    // the state record of step t+1 is free -- it held step t+1 - kGRing, consumed once cost_done >= t+2 - kGRing: the
+    // control wave publishes a chunk that ends with step tm >= t+1 only after it has seen cost_done >= tm+1 - kGRing
+    // (group_control_wave: need_c; the control record of a step shares the slot index of its state record), so this wave
+    // does not look at the cost wave's word itself.
+    // (A shorter leash for the riders -- waiting when the cost wave is more than 2 / 3 / 5 steps behind instead of a full
+    // ring -- was measured: 124 / 72.6 / 58.0 us against 55.2 us; the riders need the slack.)
+    // The scalar side of the test in front of the output layer's chain, the (cold) wait behind it.
+    const int want = t + 2;
+    const int cp_e = __builtin_amdgcn_readfirstlane(cp_v);
+    asm volatile("" : "+v"(un));  // the wait for the two reads sits HERE (long arrived), not behind the next step's LDS stores
     {
       const f32x2 d = row_dot_bc(W.w3, a1) + W.b3;
       sp = __builtin_elementwise_fma(d, f32x2{a.dt, a.dt}, sp);  // incrementState, neural_net_model.cu:334-344
       asm volatile("" : "+v"(sp));  // the chain stays here (otherwise it is sunk below the wait, away from its moves)
     }
-    if (__builtin_expect(need_wait, 0)) {
-      int cp = cp_e, cd = cd_e;
-      while (((cp < want) | (cd < want_cd)) && --budget > 0) {
+    if (__builtin_expect(cp_e < want, 0)) {
+      int cp = cp_e;
+      while (cp < want && --budget > 0) {
         cp = __builtin_amdgcn_readfirstlane(*p_pub);
-        un0_v = p_u[sn];
-        un1_v = p_u[sn + 1];
-        cd = __builtin_amdgcn_readfirstlane(*p_cd);
+        un = p_u[sn];
       }
+      asm volatile("" : "+v"(un));  // (its wait too: otherwise the merge of the two paths puts one behind the next step's stores)
     }
-    u0n = un0_v;
-    u1n = un1_v;
   }
   if (w == 0) RSTAMP(4);  // T loop done
   {  // the record of step T-1
     const int t = T - 1;
-    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)(t & (kGRing - 1)) * rec_stride), "v"(sp) : "memory");
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)(t & (kGRing - 1)) * kRecStride), "v"(sp) : "memory");
     lds_publish(a_myseq, t + 1);
   }
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
