@@ -62,12 +62,13 @@ SYMBOLS = [
     "mppi_set_bf_params", "mppi_set_ddp_weights", "mppi_debug_cost_raster", "mppi_compute_feedback_gains", "mppi_get_feedback_gains",
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
-    "mppi_debug_inject_handover_fault",
+    "mppi_debug_inject_handover_fault", "mppi_compute_feedback_gains_pair", "mppi_set_host_threads",
 ]
 
 ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
                 "mppi_compute_control_batch", "mppi_compute_control_batch_async", "mppi_control_ticks_batch",
                 "mppi_nominal_traj_pair")
+ABI3_SYMBOLS = ("mppi_compute_feedback_gains_pair", "mppi_set_host_threads")
 
 _lib = None
 
@@ -142,8 +143,12 @@ def lib():
             L.mppi_compute_control_batch.argtypes = [C.POINTER(hp), fp, C.c_int]
             L.mppi_control_ticks_batch.argtypes = [C.POINTER(hp), fp, C.c_int, C.c_int, C.c_int]
             L.mppi_nominal_traj_pair.argtypes = [hp, fp, fp, fp, hp, fp, fp, fp]
+        v3 = L.mppi_abi_version() >= 3
+        if v3:
+            L.mppi_compute_feedback_gains_pair.argtypes = [hp, fp, fp, fp, hp, fp, fp, fp]
+            L.mppi_set_host_threads.argtypes = [C.c_int]
         for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
-            if v2 or s not in ABI2_SYMBOLS:
+            if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS):
                 getattr(L, s)
         _lib = L
     return _lib
@@ -353,6 +358,10 @@ class Solver:
         tx = _fp(_f32(target_x, (self.T, 7))) if target_x is not None else None
         tu = _fp(_f32(target_u, (self.T, 2))) if target_u is not None else None
         self._ck(self.L.mppi_compute_feedback_gains(self.h, _fp(_f32(state, (7,))), tx, tu))
+        return self.feedback_gains()
+
+    def feedback_gains(self):
+        """getFeedbackGains of the last successful computeFeedbackGains."""
         fb = np.zeros((self.T, 2, 7), dtype=np.float32)
         ff = np.zeros((self.T, 2), dtype=np.float32)
         x = np.zeros((self.T, 7), dtype=np.float32)
@@ -418,6 +427,27 @@ def control_ticks_batch(solvers, states, n_ticks, stride=1):
     rc = solvers[0].L.mppi_control_ticks_batch(hs, _fp(st), n, int(n_ticks), int(stride))
     if rc != OK:
         raise MppiError(rc, "; ".join(s.L.mppi_last_error(s.h).decode() for s in solvers))
+
+
+def set_host_threads(n):
+    """mppi_set_host_threads: 1 = the caller's thread only, 2 = one helper thread for the paired host work of a tick."""
+    rc = lib().mppi_set_host_threads(int(n))
+    if rc != OK:
+        raise MppiError(rc, "mppi_set_host_threads(%d)" % n)
+
+
+def compute_feedback_gains_pair(sol_a, state_a, sol_b, state_b, targets_a=None, targets_b=None):
+    """mppi_compute_feedback_gains_pair; targets_x = (state_seq [T][7], control_seq [T][2]) or None (the handle's own
+    nominal replay from state_x)."""
+    def tp(t):
+        if t is None:
+            return None, None
+        return _fp(_f32(t[0], (sol_a.T, 7))), _fp(_f32(t[1], (sol_a.T, 2)))
+    ta, tb = tp(targets_a), tp(targets_b)
+    rc = sol_a.L.mppi_compute_feedback_gains_pair(sol_a.h, _fp(_f32(state_a, (7,))), ta[0], ta[1],
+                                                  sol_b.h, _fp(_f32(state_b, (7,))), tb[0], tb[1])
+    if rc != OK:
+        raise MppiError(rc, sol_a.L.mppi_last_error(sol_a.h).decode() + " | " + sol_b.L.mppi_last_error(sol_b.h).decode())
 
 
 def nominal_traj_pair(sol_a, state_a, sol_b, state_b):

@@ -15,8 +15,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -179,6 +183,96 @@ int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess)
     hipError_t e__ = (call);                                             \
     if (e__ != hipSuccess) return fail((h), MPPI_ERR_HIP, #call, e__);   \
   } while (0)
+
+// One helper thread for the host-side halves of a control tick that come in pairs (the two controllers' nominal replays,
+// their two DDP passes: run_control_loop.cuh:218-225 -- independent work on two handles): the caller's thread does one, the
+// helper the other.  Off unless mppi_set_host_threads(2) was called.  The helper sleeps on a condition variable; arm() wakes it
+// (mppi_compute_control_batch_async does, a solve's length before the replays are due) and it then polls for work for 1 ms
+// after the last job, so that the hand-over costs a cache line, not a futex wake.
+class HostHelper {
+ public:
+  ~HostHelper()
+  {
+    if (!th_.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+      wake_ = true;
+    }
+    cv_.notify_one();
+    th_.join();
+  }
+  void arm()
+  {
+    std::call_once(started_, [this] { th_ = std::thread([this] { loop(); }); });
+    if (spinning_.load()) return;  // (seq_cst, with the stores in run_pair / loop: a job is never posted to a helper going to sleep unseen)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      wake_ = true;
+    }
+    cv_.notify_one();
+  }
+  // runs `other` on the helper and `mine` on the caller's thread; returns when both are done.  One pair at a time: a second
+  // caller (another control loop of the process) runs both halves itself.
+  void run_pair(const std::function<void()> &other, const std::function<void()> &mine)
+  {
+    std::unique_lock<std::mutex> busy(pair_mu_, std::try_to_lock);
+    if (!busy.owns_lock()) {
+      mine();
+      other();
+      return;
+    }
+    job_ = &other;
+    done_.store(false);
+    posted_.store(true);
+    arm();
+    mine();
+    while (!done_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+
+ private:
+  void loop()
+  {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return wake_; });
+        wake_ = false;
+        if (quit_) return;
+      }
+      do {
+        spinning_.store(true);
+        auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
+        unsigned spins = 0;
+        for (;;) {
+          if (posted_.load(std::memory_order_acquire)) {
+            posted_.store(false);
+            (*job_)();
+            done_.store(true, std::memory_order_release);
+            until = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
+          } else {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFF) == 0 && std::chrono::steady_clock::now() > until) break;
+          }
+        }
+        spinning_.store(false);
+      } while (posted_.load());  // posted while this thread was on its way to sleep: its poster saw `spinning_` and sent no wake
+    }
+  }
+  std::once_flag started_;
+  std::thread th_;
+  std::mutex mu_, pair_mu_;
+  std::condition_variable cv_;
+  bool wake_ = false, quit_ = false;
+  std::atomic<bool> spinning_{false}, posted_{false}, done_{false};
+  const std::function<void()> *job_ = nullptr;
+};
+std::atomic<int> g_host_threads{1};
+HostHelper &host_helper()
+{
+  static HostHelper hh;
+  return hh;
+}
 
 // Batched solves of several handles go to ONE stream per device, shared by all handles and never destroyed, so
 // that the instances' kernels are one launch and a handle never holds another handle's stream.
@@ -1373,6 +1467,8 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     for (int q = 0; q < i; q++)
       if (hs[q] == hs[i]) return fail(hs[i], MPPI_ERR_INVALID, "the same handle twice in one batch");
   }
+  // the host-side halves of this tick (nominal replays, DDP passes) are a solve's length away: the helper thread wakes now
+  if (n == 2 && g_host_threads.load(std::memory_order_relaxed) >= 2) host_helper().arm();
   // One launch for all instances where the quad form serves them together (every wave of every group still gets a
   // SIMD of its own: the sum of the groups fits the CUs); otherwise every solve on its own handle's stream, as
   // n calls of mppi_compute_control_async would do.
@@ -1629,6 +1725,12 @@ int mppi_nominal_traj_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM],
       const int rc = mppi_synchronize(h);
       if (rc) return rc;
     }
+  if (g_host_threads.load(std::memory_order_relaxed) >= 2) {  // one replay per thread (mppi_set_host_threads)
+    int rca = MPPI_OK, rcb = MPPI_OK;
+    host_helper().run_pair([&] { rcb = mppi_nominal_traj(hb, state_b, state_seq_b, control_seq_b); },
+                           [&] { rca = mppi_nominal_traj(ha, state_a, state_seq_a, control_seq_a); });
+    return rca ? rca : rcb;
+  }
   mppi_handle *hs[2] = {ha, hb};
   float *sseq[2] = {state_seq_a, state_seq_b}, *cseq[2] = {control_seq_a, control_seq_b};
   float s[2][kStateDim], sd[2][kStateDim], in6[2][6];
@@ -1703,6 +1805,35 @@ int mppi_compute_feedback_gains(mppi_handle *h, const float state[MPPI_STATE_DIM
   if (ddp_feedback_gains(net, p, state, xs.data(), us.data(), h->ddp) != 0)
     return fail(h, MPPI_ERR_STATE, "DDP: control Hessian could not be factorised");
   h->have_ddp = true;
+  return MPPI_OK;
+}
+
+int mppi_compute_feedback_gains_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM], const float *target_state_seq_a,
+                                     const float *target_control_seq_a, mppi_handle *hb, const float state_b[MPPI_STATE_DIM],
+                                     const float *target_state_seq_b, const float *target_control_seq_b)
+{
+  if (!ha || !hb || ha == hb) return MPPI_ERR_INVALID;
+  if (g_host_threads.load(std::memory_order_relaxed) >= 2) {
+    // the nominal replays inside (no targets given) synchronise their handle: do that on this thread, which has the device
+    for (mppi_handle *h : {ha, hb})
+      if (h->pending) {
+        const int rc = mppi_synchronize(h);
+        if (rc) return rc;
+      }
+    int rca = MPPI_OK, rcb = MPPI_OK;
+    host_helper().run_pair([&] { rcb = mppi_compute_feedback_gains(hb, state_b, target_state_seq_b, target_control_seq_b); },
+                           [&] { rca = mppi_compute_feedback_gains(ha, state_a, target_state_seq_a, target_control_seq_a); });
+    return rca ? rca : rcb;
+  }
+  const int rc = mppi_compute_feedback_gains(ha, state_a, target_state_seq_a, target_control_seq_a);
+  return rc ? rc : mppi_compute_feedback_gains(hb, state_b, target_state_seq_b, target_control_seq_b);
+}
+
+int mppi_set_host_threads(int n)
+{
+  if (n < 1 || n > 2) return MPPI_ERR_INVALID;
+  g_host_threads.store(n, std::memory_order_relaxed);
+  if (n >= 2) host_helper().arm();  // starts the helper now, not inside the first tick
   return MPPI_OK;
 }
 

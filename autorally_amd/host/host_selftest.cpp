@@ -58,6 +58,7 @@ struct FakeController {
   void startControl() { float s[7]; for (int i = 0; i < 7; i++) s[i] = state_seq[i]; startControl(s); }
   static void startControlPair(FakeController *a, const float *s, FakeController *p) { a->startControl(s); p->startControl(); }
   static void finishControlPair(FakeController *a, FakeController *p) { a->finishControl(); p->finishControl(); }
+  static void computeFeedbackGainsPair(FakeController *a, FakeController *p, const float *s) { a->computeFeedbackGains(s); p->computeFeedbackGains(s); }
   void finishControl() {}
   float getComputedTrajectoryCost() const { return cost; }
   std::vector<float> getControlSeq() const { return control_seq; }

@@ -574,6 +574,10 @@ class MPPIControllerT {
   {
     syncParams(false);  // the host copy of the network / control ranges the Jacobians are taken of
     ck(mppi_compute_feedback_gains(h_, state, state_solution_.data(), control_solution_.data()));
+    fetchFeedbackGains();
+  }
+  void fetchFeedbackGains()
+  {
     const size_t T = (size_t)numTimesteps_;
     result_.feedback_gain.resize(T * CONTROL_DIM * STATE_DIM);
     result_.feedforward_gain.resize(T * CONTROL_DIM);
@@ -581,6 +585,17 @@ class MPPIControllerT {
     result_.control_trajectory.resize(T * CONTROL_DIM);
     ck(mppi_get_feedback_gains(h_, result_.feedback_gain.data(), result_.feedforward_gain.data(),
                                result_.state_trajectory.data(), result_.control_trajectory.data(), &result_.total_cost));
+  }
+  // computeFeedbackGains(state) of both controllers of a tick (run_control_loop.cuh:220-225) in one call: with
+  // mppi_set_host_threads(2) the two DDP passes run side by side; the results are those of the two single calls
+  static void computeFeedbackGainsPair(MPPIControllerT *actual, MPPIControllerT *predicted, const float *state)
+  {
+    actual->syncParams(false);
+    predicted->syncParams(false);
+    actual->ck(mppi_compute_feedback_gains_pair(actual->h_, state, actual->state_solution_.data(), actual->control_solution_.data(),
+                                                predicted->h_, state, predicted->state_solution_.data(),
+                                                predicted->control_solution_.data()));
+    for (MPPIControllerT *c : {actual, predicted}) c->fetchFeedbackGains();
   }
   const FeedbackResult &getFeedbackGains() const { return result_; }  // :443-446
 

@@ -36,7 +36,7 @@ template <class DYNAMICS_T, class MAKE_MODEL>
 int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL make_model)
 {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s <launch.xml> [--rollouts K] [--layers 6-32-32-4] [--max-iter N] [--no-sleep] "
+    fprintf(stderr, "usage: %s <launch.xml> [--rollouts K] [--layers 6-32-32-4] [--max-iter N] [--no-sleep] [--host-threads 1|2] "
                     "[--device D] [--trace file] [--set key=value]\n", argv[0]);
     return 2;
   }
@@ -55,6 +55,9 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
   // costs.params_.desired_speed / model.control_rngs_[1].y (no setter, no version bump), as code written against
   // the reference does (e.g. cutThrottle, mppi_controller.cu:460-466); the next solve must see it
   double poke_speed = -1.0, poke_throttle = -1.0;
+  // --host-threads 1|2: mppi_set_host_threads -- 2 (default here): the two controllers' nominal replays and DDP passes of
+  // a tick side by side, on the optimizer thread and one helper (the reference runs them one after the other)
+  int host_threads = 2;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--rollouts") && i + 1 < argc) rollouts = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--layers") && i + 1 < argc) layers = parse_layers(argv[++i]);
@@ -63,6 +66,7 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     else if (!strcmp(argv[i], "--trace") && i + 1 < argc) trace_path = argv[++i];
     else if (!strcmp(argv[i], "--set") && i + 1 < argc) overrides.push_back(argv[++i]);
     else if (!strcmp(argv[i], "--no-sleep")) sleep_to_rate = false;
+    else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--dcfg-desired-speed") && i + 1 < argc) { dcfg_speed = atof(argv[++i]); have_dcfg = true; }
     else if (!strcmp(argv[i], "--debug-image")) debug_image = true;
     else if (!strcmp(argv[i], "--pose-script") && i + 1 < argc) pose_script = argv[++i];
@@ -71,6 +75,7 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
+    if (mppi_set_host_threads(host_threads) != MPPI_OK) throw std::runtime_error("--host-threads must be 1 or 2");
     ParamMap params;
     loadParams(&params, argv[1]);
     for (const std::string &kv : overrides) {  // e.g. --set x_pos=0.0 (double), typed like the existing key

@@ -256,10 +256,8 @@ LoopStats runControlLoop(CONTROLLER_T *predicted_state_controller, CONTROLLER_T 
     CONTROLLER_T::startControlPair(actual_state_controller, state, predicted_state_controller);
     CONTROLLER_T::finishControlPair(actual_state_controller, predicted_state_controller);
     const auto t_solve1 = std::chrono::steady_clock::now();
-    if (use_feedback_gains) {  // :220-225: both controllers, from the measured state
-      actual_state_controller->computeFeedbackGains(state);
-      predicted_state_controller->computeFeedbackGains(state);
-    }
+    if (use_feedback_gains)  // :220-225: both controllers, from the measured state
+      CONTROLLER_T::computeFeedbackGainsPair(actual_state_controller, predicted_state_controller, state);
     const auto t_gains1 = std::chrono::steady_clock::now();
     feedback_gain = predicted_state_controller->getFeedbackGains().feedback_gain;  // :229
 

@@ -31,7 +31,8 @@ extern "C" {
 /* 2: + mppi_set_costmap_transform, mppi_savitsky_golay, mppi_compute_control_batch[_async], mppi_control_ticks_batch, mppi_nominal_traj_pair,
  *    mppi_debug_inject_handover_fault; mppi_slide_control_seq(h, 0) is MPPI_OK (was MPPI_ERR_INVALID); "fused" =
  *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w", "valu_row8w_*"; variants "row", "multi4u". */
-#define MPPI_ABI_VERSION 2
+/* 3: + mppi_set_host_threads, mppi_compute_feedback_gains_pair. */
+#define MPPI_ABI_VERSION 3
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
 #define MPPI_MAX_LAYERS 8
@@ -218,6 +219,19 @@ int mppi_compute_feedback_gains(mppi_handle *h, const float state[MPPI_STATE_DIM
  * zero), feedforward [T][2], state_traj [T][7], control_traj [T][2], total_cost; any may be NULL. */
 int mppi_get_feedback_gains(mppi_handle *h, float *feedback, float *feedforward, float *state_traj,
                             float *control_traj, float *total_cost);
+
+/* computeFeedbackGains of the two controllers of a control tick (run_control_loop.cuh:220-225: both, one after the other, on
+ * the optimizer thread) in one call; results bit for bit those of two mppi_compute_feedback_gains calls.  With
+ * mppi_set_host_threads(2) the two DDP passes run side by side. */
+int mppi_compute_feedback_gains_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM], const float *target_state_seq_a,
+                                     const float *target_control_seq_a, mppi_handle *hb, const float state_b[MPPI_STATE_DIM],
+                                     const float *target_state_seq_b, const float *target_control_seq_b);
+
+/* Host threads the library may use for the host-side work of a tick that comes in pairs (mppi_nominal_traj_pair,
+ * mppi_compute_feedback_gains_pair): 1 (default) = the caller's thread only (the reference's optimizer thread does everything,
+ * path_integral_main.cu:136-138); 2 = one helper thread, process-wide, which sleeps between ticks and is woken by
+ * mppi_compute_control_batch_async.  Results do not depend on the setting. */
+int mppi_set_host_threads(int n);
 
 /* MPPICosts::getDebugDisplay without the OpenCV display (costs.cu:272-285 -> debugCostKernel,
  * PI/debug_kernels.cuh:39-88): the costmap around (x, y), width_m x height_m metres at ppm pixels per

@@ -168,6 +168,53 @@ def test_nominal_trajectories_of_a_pair_in_lockstep_equal_the_single_replays(gol
         s.close()
 
 
+def test_paired_host_work_on_a_helper_thread_equals_the_single_calls():
+    """mppi_set_host_threads(2): the two nominal replays / the two DDP passes of a tick run side by side (the caller's thread
+    and one helper thread); results bit for bit those of the single calls and of the one-thread setting, tick after tick
+    (the helper sleeps between ticks, is woken by the batched solve, and is found asleep again after a pause)."""
+    import time
+    cfg = S.make_config(512, 100, track="oval")
+    a, b = capi.Solver(cfg), capi.Solver(dict(cfg, seed=9))
+    sa, sb = cfg["start_state"].copy(), cfg["start_state"].copy()
+    sb[0] += 0.4
+    sb[4] -= 1.0
+
+    def bits(x):
+        return np.ascontiguousarray(x).view(np.uint32)
+    try:
+        for tick in range(6):
+            capi.set_host_threads(2 if tick % 3 else 1)
+            capi.compute_control_batch([a, b], [sa, sb])
+            (xa, ua), (xb, ub) = capi.nominal_traj_pair(a, sa, b, sb)
+            ra, rb = a.nominal_traj(sa), b.nominal_traj(sb)
+            for got, ref in ((xa, ra[0]), (ua, ra[1]), (xb, rb[0]), (ub, rb[1])):
+                np.testing.assert_array_equal(bits(got), bits(ref))
+            capi.compute_feedback_gains_pair(a, sa, b, sa, (xa, ua), (xb, ub))
+            ga, gb = a.feedback_gains(), b.feedback_gains()
+            ha, hb = a.compute_feedback_gains(sa, xa, ua), b.compute_feedback_gains(sa, xb, ub)
+            for g, h in ((ga, ha), (gb, hb)):
+                for key in ("feedback", "feedforward", "x", "u"):
+                    np.testing.assert_array_equal(bits(g[key]), bits(h[key]))
+                assert g["total_cost"] == h["total_cost"]
+            assert np.max(np.abs(ga["feedback"] - gb["feedback"])) > 0
+            # without targets: each pass replays its own handle's sequence from the given state
+            capi.compute_feedback_gains_pair(a, sa, b, sb)
+            np.testing.assert_array_equal(bits(a.feedback_gains()["feedback"]), bits(a.compute_feedback_gains(sa)["feedback"]))
+            np.testing.assert_array_equal(bits(b.feedback_gains()["feedback"]), bits(b.compute_feedback_gains(sb)["feedback"]))
+            for s in (a, b):
+                s.slide_control_seq(1)
+            if tick == 3:
+                time.sleep(0.05)  # the helper goes back to sleep (1 ms after its last job)
+        with pytest.raises(capi.MppiError):
+            capi.set_host_threads(3)
+        with pytest.raises(capi.MppiError):
+            capi.compute_feedback_gains_pair(a, sa, a, sa)
+    finally:
+        capi.set_host_threads(1)
+        for s in (a, b):
+            s.close()
+
+
 def test_batch_then_single_then_batch_and_two_iterations():
     """Transitions between the batch stream and a handle's own stream (single solve, result vectors, applied
     controls, set_noise, seed) keep every handle's sequence of results; num_iters = 2 batches both iterations."""
