@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256) void k_lds(const float *theta, float *out, uns
 }
 
 // ---- form A: every layer as mov_dpp + pk_fma; state pair as in the product (lane pair (p, p^1) holds the whole state) ----
+// SC: the two tanh of a lane's pair as two scalar chains (fma, exp, add, rcp, fma each) instead of the packed form: the first
+// activation of the next layer's chain is ready one transcendental issue earlier
+template <bool SC>
+__device__ __forceinline__ f32x2 tanh2(f32x2 z, f32x2 b)
+{
+  if (SC) return f32x2{tanh_bias(z.x, b.x), tanh_bias(z.y, b.y)};
+  return tanh_bias2(z, b);
+}
+template <bool SC>
 __global__ __launch_bounds__(256) void k_bc_a(const float *theta, float *out, unsigned long long *cyc, int iters, float dt)
 {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -154,8 +163,8 @@ __global__ __launch_bounds__(256) void k_bc_a(const float *theta, float *out, un
     z = __builtin_elementwise_fma(W.w1[3], f32x2{s6, s6}, z);
     z = __builtin_elementwise_fma(W.w1[4], f32x2{0.1f, 0.1f}, z);
     z = __builtin_elementwise_fma(W.w1[5], f32x2{0.1f, 0.1f}, z);
-    const f32x2 a0 = tanh_bias2(z, W.b1s);
-    const f32x2 a1 = tanh_bias2(row_dot_bc(W.w2, a0), W.b2s);
+    const f32x2 a0 = tanh2<SC>(z, W.b1s);
+    const f32x2 a1 = tanh2<SC>(row_dot_bc(W.w2, a0), W.b2s);
     z = row_dot_bc(W.w3, a1);
     sp = __builtin_elementwise_fma(z + W.b3, f32x2{dt, dt}, sp);
   }
@@ -477,7 +486,8 @@ int main(int argc, char **argv)
     printf("\n");
   };
   run("LDS form (product)", k_lds, true);
-  run("form A: mov_dpp + pk_fma, all layers", k_bc_a, false);
+  run("form A: mov_dpp + pk_fma, all layers", k_bc_a<false>, false);
+  run("form A, the pair's two tanh as scalar chains", k_bc_a<true>, false);
   run("form P0: A in the product's loop shape (partner move, u from regs)", k_bc_p<0>, false);
   run("form P1: + state record and sequence word to LDS", k_bc_p<1>, false);
   run("form P2: + next controls and progress words from LDS", k_bc_p<2>, false);
