@@ -188,6 +188,60 @@ def test_large_cost_draws_stay_inside_the_first_order_bound_of_their_cost_differ
         assert dU < 1e-3, (v, dU)  # and it is small in absolute terms
 
 
+@pytest.mark.parametrize("seed", [36115, 43822])
+def test_multi_iteration_draws_of_the_row_form_sweep(golden_dir, seed):
+    """Draws 36115 and 43822 of the generator above -- the two of 2 999 draws of a sweep over the vector-ALU row form alone
+    (tools/fuzz_sweep.py 30000 50000 row, profiles/r03_j_fuzz_sweep_row_2999_draws.txt) that missed the criterion of the
+    committed sweep.  Both are MULTI-iteration draws with gamma = 0.5: iteration i+1 perturbs the U that iteration i produced,
+    so a last-digit difference of U after the first iteration moves every rollout of the next, and the comparison of the last
+    iteration's costs is no longer a comparison on identical inputs.  36115 (K=4096, three iterations): 4.5 % of the last
+    iteration's rollouts differ by more than 1e-4 relative (limit of the sweep: 3 %), |dU| = 5.4e-4; 43822 (K=512, two
+    iterations, eta = 1.4): no such rollout, |dU| = 3.2e-4 against the oracle with fmaf and 1.4e-4 against the one without --
+    the oracle's own two modes are 1.8e-4 apart.  What is asserted: the first iteration ALONE (identical inputs) meets the
+    clean criterion; every kernel form gives the same bits (the draw says nothing about one form); and the multi-iteration
+    result stays within 1e-3, for 43822 also within max(2e-4, the oracle's own spread) of the nearer oracle mode."""
+    cfg, _, hist = _draw(golden_dir, seed)
+    iters = cfg["num_iters"]
+    assert iters > 1 and list(cfg["layers"]) == [6, 32, 32, 4] and cfg["K"] <= 4096
+    eps = noise_for(cfg)
+    U0 = warm_U(cfg, seed=seed)
+    r1 = O.Oracle(cfg, fma_mode=1, nthreads=16).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
+    r0 = O.Oracle(cfg, fma_mode=0, nthreads=16).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
+    spread = float(np.max(np.abs(r1["U"] - r0["U"])))
+
+    def solve(c, v, e):
+        sol = capi.Solver(c)
+        sol.set_rollout_variant(v)
+        sol.set_control_seq(U0)
+        sol.set_control_hist(hist)
+        sol.set_noise(e)
+        sol.compute_control(c["start_state"])
+        out = sol.get_results(), sol.get_applied_controls(), sol.rollout_variant()
+        sol.close()
+        return out
+    # the first iteration alone
+    c1 = dict(cfg, num_iters=1)
+    f1 = O.Oracle(c1, fma_mode=1, nthreads=16).compute_control(c1["start_state"], U0, hist, eps[:1], num_iters=1)
+    g1, V1, name = solve(c1, "row", eps[:1])
+    assert "row8w" in name
+    np.testing.assert_array_equal(V1.view(np.uint32), f1["V"][-1].view(np.uint32))
+    fl = rel_err(g1["costs"], f1["costs"]) > 1e-4
+    mass = float(np.sum(np.maximum(f1["w"] / f1["w"].sum(), g1["w"] / g1["w"].sum())[fl]))
+    assert float(np.mean(fl)) <= 0.03 and float(np.max(np.abs(g1["U"] - f1["U"]))) <= 2e-4 + 4.0 * mass
+    # all iterations: every form the same bits, the result close to the oracle in absolute terms
+    base = None
+    for v in ("row", "quad", "fused", "valu"):
+        got, V, _ = solve(cfg, v, eps)
+        if base is None:
+            base = got
+        for key in ("costs", "U", "w"):
+            np.testing.assert_array_equal(got[key].view(np.uint32), base[key].view(np.uint32), err_msg="%s %s" % (v, key))
+    d1, d0 = float(np.max(np.abs(base["U"] - r1["U"]))), float(np.max(np.abs(base["U"] - r0["U"])))
+    assert min(d1, d0) < 1e-3 and float(np.mean(rel_err(base["costs"], r1["costs"]) > 1e-4)) < 0.08
+    if seed == 43822:
+        assert spread > 1e-4 and min(d1, d0) <= max(2e-4, spread), (d1, d0, spread)
+
+
 def _update_model_layout(layers, theta):
     """packed [W1|b1|W2|b2|..] -> updateModel's [W1|W2|..|b1|b2|..] (neural_net_model.cu:152-180)"""
     Ws, bs, o = [], [], 0

@@ -15,9 +15,15 @@ import test_fuzz_gpu as F  # noqa: E402
 
 gd = os.path.join(ROOT, "tests", "golden")
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+# a third argument "row": only the draws the vector-ALU row form serves (6-32-32-4, at most one group per CU), on that form
+only_row = len(sys.argv) > 3 and sys.argv[3] == "row"
 bad, explained, conditioned, illcond, worst_clean, forms = 0, 0, 0, 0, 0.0, {}
 for seed in range(lo, hi):
     cfg, variant, hist = F._draw(gd, seed)
+    if only_row:
+        if cfg.get("bf_W") is not None or list(cfg["layers"]) != [6, 32, 32, 4] or cfg["K"] > 4096:
+            continue
+        variant = "row"
     iters = cfg["num_iters"]
     eps = F.noise_for(cfg)
     U0 = F.warm_U(cfg, seed=seed)
@@ -105,6 +111,6 @@ for seed in range(lo, hi):
 print("seeds %d..%d: %d draws, %d failed, %d multi-iteration draws explained by a weight-bearing flip in their first iteration, "
       "%d single-iteration draws inside the first-order bound of their own cost differences, %d draws on which the oracle's own two "
       "modes differ by more than the HIP path does, worst |dU| of a draw without flipped weight %.3e" % (
-          lo, hi - 1, hi - lo, bad, explained, conditioned, illcond, worst_clean))
+          lo, hi - 1, sum(forms.values()), bad, explained, conditioned, illcond, worst_clean))
 print("kernel forms drawn:", ", ".join("%s x%d" % kv for kv in sorted(forms.items())))
 sys.exit(1 if bad else 0)
