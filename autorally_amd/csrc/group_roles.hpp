@@ -48,32 +48,60 @@ __device__ __forceinline__ int group_seq_min(SH &sh)
 }
 
 // ---------------------------------- noise wave ----------------------------------
-// The handle's MRG32k3a streams, one lane per rollout: the two uniform draws of every step into a ring for the
-// control wave, which does Box-Muller (the generator's 64-bit multiply chains on quarter-rate v_mul_hi_u32 are
-// work enough for one rider).
+// The handle's MRG32k3a streams: the two uniform draws of every step into a ring for the control wave, which does
+// Box-Muller.  The generator's two components are independent third-order recurrences that meet only in the output
+// z = (p1 - p2) mod m1, so a rollout takes TWO lanes -- lane 2 j + c runs component c of rollout j with its own multipliers,
+// modulus and fold constant in registers -- and the partner's p2 comes by one DPP move: one component's instructions per
+// draw instead of two (the 64-bit products are quarter rate, and a rider only gets the issue slots its SIMD's dynamics
+// wave leaves).  Integer arithmetic throughout: the same words as mrg_next_z (noise_device.hpp).
+struct MrgHalf {
+  uint32_t s0, s1, s2;  // component c's three words, oldest first
+};
+// x < 2^63 -> x mod m, m = 2^32 - C (C = 209: two rounds suffice and the third changes nothing; C = 22853: three)
+__device__ __forceinline__ uint32_t fold_m(uint64_t x, uint32_t C, uint32_t m)
+{
+  x = (x >> 32) * C + (x & 0xffffffffULL);
+  x = (x >> 32) * C + (x & 0xffffffffULL);
+  x = (x >> 32) * C + (x & 0xffffffffULL);
+  if (x >= m) x -= m;
+  return (uint32_t)x;
+}
 template <class SH>
 __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
 {
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
-  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + (lane & 15);
+  const int j = (lane >> 1) & 15, c = lane & 1;
+  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
-  const bool active = lane < kRolloutsPerWave;
+  const bool active = lane < 2 * kRolloutsPerWave;
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kRng + 1);
   if (a.inline_noise != 0) {
-    Mrg gsta{0, 0, 0, 0, 0, 0};
+    // p = (A sX - Bn s0) mod m: component 1 = (a12 s11 - a13n s10) mod m1, component 2 = (a21 s22 - a23n s20) mod m2
+    const uint32_t m = c ? (uint32_t)kM2 : (uint32_t)kM1, C = c ? kC2 : kC1;
+    const uint32_t A = c ? (uint32_t)kA21 : (uint32_t)kA12, Bn = c ? (uint32_t)kA23N : (uint32_t)kA13N;
+    MrgHalf g{0, 0, 0};
     if (active) {
-      gsta.s10 = a.rng_in[k]; gsta.s11 = a.rng_in[K + k]; gsta.s12 = a.rng_in[2 * K + k];
-      gsta.s20 = a.rng_in[3 * K + k]; gsta.s21 = a.rng_in[4 * K + k]; gsta.s22 = a.rng_in[5 * K + k];
+      g.s0 = a.rng_in[(3 * c) * K + k]; g.s1 = a.rng_in[(3 * c + 1) * K + k]; g.s2 = a.rng_in[(3 * c + 2) * K + k];
     }
     const uint32_t a_ctl = lds_addr(&sh.ctl_pub[0]);
     const uint32_t a_mypub = lds_addr(&sh.rng_pub[lane]);
     int seen = 0;
     for (int t = 0; t < T; t++) {
+      float2 e = make_float2(0.5f, 0.5f);
 #ifdef MPPI_DIAG_NORNG  // diagnostic build: the hand-overs without the generator steps (which rider paces the group?)
-      const float2 e = make_float2(0.25f + 0.001f * (float)t, 0.5f);
+      e = make_float2(0.25f + 0.001f * (float)t, 0.5f);
 #else
-      const float2 e = active ? uniform_pair(gsta) : make_float2(0.5f, 0.5f);
+#pragma unroll
+      for (int d = 0; d < 2; d++) {  // one timestep's pair of uniforms: two generator steps (uniform_pair)
+        const uint32_t p = fold_m((uint64_t)A * (c ? g.s2 : g.s1) + (uint64_t)Bn * (m - g.s0), C, m);
+        g.s0 = g.s1; g.s1 = g.s2; g.s2 = p;
+        const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]: lane ^ 1
+        uint32_t z = (p >= p2) ? p - p2 : p + (uint32_t)kM1 - p2;  // (even lanes: p = p1)
+        if (z == 0) z = (uint32_t)kM1;
+        const float u = (float)z * 0x1p-32f;
+        if (d == 0) e.x = u; else e.y = u;
+      }
 #endif
       // slot t % kGRing held step t - kGRing, consumed once the control wave has published that step
       const int need = t - kGRing + 1;
@@ -81,12 +109,11 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
         seen = lds_peek(a_ctl);
         if (seen < need) __builtin_amdgcn_s_sleep(2);
       }
-      if (active) *reinterpret_cast<float2 *>(&sh.eps[t & (kGRing - 1)][lane][0]) = e;
+      if (active && c == 0) *reinterpret_cast<float2 *>(&sh.eps[t & (kGRing - 1)][j][0]) = e;
       lds_publish(a_mypub, t + 1);
     }
     if (active) {
-      a.rng_out[k] = gsta.s10; a.rng_out[K + k] = gsta.s11; a.rng_out[2 * K + k] = gsta.s12;
-      a.rng_out[3 * K + k] = gsta.s20; a.rng_out[4 * K + k] = gsta.s21; a.rng_out[5 * K + k] = gsta.s22;
+      a.rng_out[(3 * c) * K + k] = g.s0; a.rng_out[(3 * c + 1) * K + k] = g.s1; a.rng_out[(3 * c + 2) * K + k] = g.s2;
     }
   }
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kRng]));
