@@ -324,7 +324,28 @@ def main():
     elapsed = timed_block()
     # the same block repeated (off the headline number): spread of the measurement
     block_s = [elapsed] + [timed_block() for _ in range(max(0, args.repeats - 1))]
-    # separate pass 0: a sustained run (off the headline number): the same step for --sustained-s seconds of wall time --
+    # separate pass 1, directly behind the timed blocks (the GPU in the state they ran in: behind the 2 s sustained pass the
+    # same kernel measures ~12 % longer): HIP events around the stages of every solve (they lengthen the launch gaps, so
+    # they stay out of the timed region); the rollout kernel's duration feeds the roofline block
+    if cuda:
+        sol.enable_stage_timing(1)
+        sol.reset_stage_times()
+        run_steps(args.event_solves)
+        sync()
+        stage_times = sol.get_stage_times()
+        sol.enable_stage_timing(0)
+    # separate pass 2: every step timed on its own (one ctypes call per ABI call): median solve latency
+    per_solve_ms = None
+    if cuda and rank == 0 and args.latency_solves > 0:
+        lat = []
+        for _ in range(args.latency_solves):
+            t1 = time.perf_counter()
+            step()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        lat = np.sort(np.asarray(lat))
+        per_solve_ms = {"n": int(lat.size), "median": float(np.median(lat)), "p10": float(lat[int(0.1 * lat.size)]),
+                        "p90": float(lat[int(0.9 * lat.size)]), "min": float(lat[0]), "max": float(lat[-1])}
+    # separate pass 3: a sustained run (off the headline number): the same step for --sustained-s seconds of wall time --
     # what a controller that runs for minutes sees, and long enough for a utilisation sampler to catch the GPU at work
     sustained = None
     if cuda and args.sustained_s > 0:
@@ -337,26 +358,6 @@ def main():
         el_s = time.perf_counter() - t_s
         sustained = {"seconds": el_s, "solves": n_s, "ms_per_step": 1e3 * el_s / n_s,
                      "value": cfg["K"] * cfg.get("num_iters", 1) * n_s / el_s, "unit": "rollouts/s (this rank)"}
-    # separate pass 1: every step timed on its own (one ctypes call per ABI call): median solve latency
-    per_solve_ms = None
-    if cuda and rank == 0 and args.latency_solves > 0:
-        lat = []
-        for _ in range(args.latency_solves):
-            t1 = time.perf_counter()
-            step()
-            lat.append(1e3 * (time.perf_counter() - t1))
-        lat = np.sort(np.asarray(lat))
-        per_solve_ms = {"n": int(lat.size), "median": float(np.median(lat)), "p10": float(lat[int(0.1 * lat.size)]),
-                        "p90": float(lat[int(0.9 * lat.size)]), "min": float(lat[0]), "max": float(lat[-1])}
-    # separate pass 2: HIP events around the stages of every solve (they lengthen the launch gaps, so
-    # they stay out of the timed region); the rollout kernel's duration feeds the roofline block
-    if cuda:
-        sol.enable_stage_timing(1)
-        sol.reset_stage_times()
-        run_steps(args.event_solves)
-        sync()
-        stage_times = sol.get_stage_times()
-        sol.enable_stage_timing(0)
     if dist is not None:
         dist.barrier()
 
