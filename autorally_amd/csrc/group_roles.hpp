@@ -66,8 +66,25 @@ __device__ __forceinline__ uint32_t fold_m(uint64_t x, uint32_t C, uint32_t m)
   if (x >= m) x -= m;
   return (uint32_t)x;
 }
-template <class SH>
-__device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
+// this lane's three generator words (lane 2 j + c: component c of rollout j), requested by a kernel in FRONT of its start
+// barrier: they are the head of a launch's critical path (words -> first draws -> Box-Muller -> first controls -> the dynamics
+// waves start), and the barrier is a wait for the workgroup's last wave to arrive (row form: first controls 6 070 -> 5 170
+// cycles after the first instruction, rollout 47.4 -> 45.6 us)
+__device__ __forceinline__ MrgHalf group_rng_load(const RolloutArgs &a)
+{
+  const int lane = threadIdx.x & 63;
+  const int j = (lane >> 1) & 15, c = lane & 1;
+  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int K = a.K;
+  MrgHalf g{0, 0, 0};
+  if (a.inline_noise != 0 && lane < 2 * kRolloutsPerWave) {
+    g.s0 = a.rng_in[(3 * c) * K + k]; g.s1 = a.rng_in[(3 * c + 1) * K + k]; g.s2 = a.rng_in[(3 * c + 2) * K + k];
+  }
+  return g;
+}
+// PRE: the words were requested by group_rng_load (pre); otherwise they are loaded here
+template <class SH, bool PRE = false>
+__device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh, const MrgHalf pre = MrgHalf{0, 0, 0})
 {
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
@@ -81,7 +98,9 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh)
     const uint32_t m = c ? (uint32_t)kM2 : (uint32_t)kM1, C = c ? kC2 : kC1;
     const uint32_t A = c ? (uint32_t)kA21 : (uint32_t)kA12, Bn = c ? (uint32_t)kA23N : (uint32_t)kA13N;
     MrgHalf g{0, 0, 0};
-    if (active) {
+    if constexpr (PRE) {
+      g = pre;
+    } else if (active) {
       g.s0 = a.rng_in[(3 * c) * K + k]; g.s1 = a.rng_in[(3 * c + 1) * K + k]; g.s2 = a.rng_in[(3 * c + 2) * K + k];
     }
     const uint32_t a_ctl = lds_addr(&sh.ctl_pub[0]);

@@ -249,6 +249,8 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (role == 0) RSTAMP(0);  // first instruction
+  MrgHalf g0{0, 0, 0};
+  if (role == R::kRng) g0 = group_rng_load(a);  // in front of the barrier: the head of the launch's critical path
   if (role == 0) {  // sequence words start at 0; the only barrier
 #pragma unroll
     for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   else if (role == R::kCost) { group_cost_wave4<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
   else if (role == R::kCtl) { group_control_wave(a, sh); RSTAMP(6); }
   else if (role == R::kPose) { group_pose_wave4<SH, AFFINE>(a, sh); RSTAMP(7); }
-  else { group_rng_wave(a, sh); RSTAMP(8); }
+  else { group_rng_wave<SH, true>(a, sh, g0); RSTAMP(8); }
 }
 
 // several instances in one launch (mppi_compute_control_batch): workgroups [first[i], first[i+1]) run instance i, whose
