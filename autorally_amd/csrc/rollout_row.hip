@@ -41,6 +41,7 @@ __device__ unsigned long long g_row_stamps[16];
 #else
 #define RSTAMP(i) do { } while (0)
 #endif
+
 template <int H>
 struct RowShared {
   static constexpr int NW = 4;            // dynamics waves per group, four rollouts each
