@@ -23,6 +23,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
          "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma"]
 
 
+# per-file additions: the row form's T loop is one wave's dependent chains with their operand moves in the shadow of the
+# multiply-adds; the scheduler's max-ILP strategy orders the bookkeeping around them better than the default
+# (same-box A/B: 0.0577 -> 0.0569 ms per step, the batched kernel unchanged; the other kernels keep the default)
+EXTRA_FLAGS = {"rollout_row.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -49,7 +55,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([cc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
