@@ -34,7 +34,7 @@ ROLLOUT_BYTES_BUFFERED_NOISE = 16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
 TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", f) for f in (  # newest first: the first match is taken
-    "r03_m_headline_row_pmc.json", "r03_l_headline_row_pmc.json", "r03_k_headline_row_pmc.json", "r03_k_cfg2_pmc.json", "r03_k_cfg1_pmc.json", "r03_j_headline_row_pmc.json", "r03_e_headline_row_pmc.json",
+    "r03_n_headline_row_pmc.json", "r03_m_headline_row_pmc.json", "r03_l_headline_row_pmc.json", "r03_k_headline_row_pmc.json", "r03_k_cfg2_pmc.json", "r03_k_cfg1_pmc.json", "r03_j_headline_row_pmc.json", "r03_e_headline_row_pmc.json",
     "r03_d_headline_pmc.json", "r03_d_cfg4_pmc.json", "r03_c_k32768_multi4_pmc.json", "r02_h_k8192_multi2_pmc.json")] + \
     sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r03_i_*_pmc.json")))
 
