@@ -59,8 +59,9 @@ struct RolloutArgs {
   CostArgs cost;
 };
 
-// Argument block of the batched quad kernel (rollout_quad_batch_kernel): instance i owns the workgroups
-// [first[i], first[i + 1]).
+// Argument block of the batched rollout kernels: grid (groups of the largest instance, instances), workgroup (x, y) runs
+// group x of inst[y].  first[] -- the instances' first workgroups in a one-dimensional numbering -- is host-side bookkeeping
+// (the kernels looked their instance up in it until the lookup's second trip to the argument segment was measured).
 constexpr int kMaxBatch = 4;
 struct QuadBatchArgs {
   int n;

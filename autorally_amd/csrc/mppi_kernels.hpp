@@ -46,7 +46,7 @@ hipError_t launch_rollout_oct(int hidden, int n_hidden, const RolloutArgs &a, hi
 bool row_variant_supported(int hidden, int n_hidden);
 int row_pack_floats();
 hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
-hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream);  // inst[i].group0 = first[i]
+hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream);  // grid (groups, instances)
 
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {
@@ -66,7 +66,7 @@ hipError_t launch_dynamics_valu(const NetDesc &net, const float *theta, const fl
 
 // rollout_bf.hip (GeneralizedLinear basis-function dynamics, W[4][25] in a.wpack)
 hipError_t launch_rollout_bf(const RolloutArgs &a, int waves, hipStream_t stream);  // waves per 64 rollouts: 1, 2, 3
-// several instances of the three-wave form in one launch (first[] in workgroups of 64 rollouts)
+// several instances of the three-wave form in one launch (grid: groups of 64 rollouts x instances)
 hipError_t launch_rollout_bf_batch(const QuadBatchArgs &b, hipStream_t stream);
 hipError_t launch_dynamics_bf(const float *W, const float *states, const float *controls, float *ders, int n,
                               hipStream_t stream);

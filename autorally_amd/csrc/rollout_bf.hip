@@ -447,14 +447,12 @@ __device__ __forceinline__ void bf3_group(const RolloutArgs &a, const int group)
 __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const RolloutArgs a) { bf3_group(a, (int)blockIdx.x); }
 
 // several instances in one launch (mppi_compute_control_batch: the two controllers of path_integral_bf's control
-// loop): workgroups [first[i], first[i+1]) run instance i
+// loop): workgroup (x, y) runs group x of instance y
 __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const QuadBatchArgs b)
 {
-  int i = 0;  // workgroup-uniform
-#pragma unroll
-  for (int q = 1; q < kMaxBatch; q++)
-    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
-  bf3_group(b.inst[i], (int)blockIdx.x - b.first[i]);
+  const RolloutArgs &a = b.inst[blockIdx.y];  // (the instance from the workgroup's own index: rollout_row.hip, rollout_row_batch_kernel)
+  if ((int)blockIdx.x >= a.K / kBfLanes) return;
+  bf3_group(a, (int)blockIdx.x);
 }
 
 // test entry (mppi_debug_dynamics): state derivative of n independent (state, control) pairs
@@ -491,7 +489,9 @@ hipError_t launch_rollout_bf(const RolloutArgs &a, int waves, hipStream_t stream
 hipError_t launch_rollout_bf_batch(const QuadBatchArgs &b, hipStream_t stream)
 {
   if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rollout_bf3_batch_kernel, dim3(b.first[b.n]), dim3(3 * kBfLanes), 0, stream, b);
+  int gmax = 0;
+  for (int i = 0; i < b.n; i++) gmax = b.inst[i].K / kBfLanes > gmax ? b.inst[i].K / kBfLanes : gmax;
+  hipLaunchKernelGGL(rollout_bf3_batch_kernel, dim3(gmax, b.n), dim3(3 * kBfLanes), 0, stream, b);
   return hipGetLastError();
 }
 

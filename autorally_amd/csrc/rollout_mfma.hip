@@ -454,8 +454,8 @@ __device__ __forceinline__ void quad_dynamics(const RolloutArgs &a, QuadShared<H
 }
 
 // One group of 16 rollouts of problem instance `a`: the body of the quad kernel.  `group` is the group's index
-// INSIDE its instance (the stand-alone kernel: blockIdx.x; the batched kernel below: blockIdx.x minus the
-// instance's first workgroup).
+// INSIDE its instance (blockIdx.x in the stand-alone kernel and in the batched kernel below, whose blockIdx.y is
+// the instance).
 template <int H, int NHID, bool AFFINE, bool CTRL>
 __device__ __forceinline__ void quad_group(const RolloutArgs &a, QuadShared<H, NHID> &sh, const int group)
 {
@@ -617,18 +617,18 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
 
 // Several independent MPPI instances in ONE launch (mppi_compute_control_batch: the actual-state and the
 // predicted-state controller of runControlLoop, run_control_loop.cuh:218-219, K = 1920 each -- 120 + 120 groups on
-// 256 CUs): workgroups [first[i], first[i+1]) run instance i with that instance's own argument block (state, U,
+// 256 CUs): workgroup (x, y) runs group x of instance y with that instance's own argument block (state, U,
 // noise / generator states, costmap, cost parameters).  The per-group code is quad_group, so every instance's
 // results equal a stand-alone launch bit for bit.
 template <int H, int NHID, bool AFFINE, bool CTRL>
 __global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatchArgs b)
 {
   __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
-  int i = 0;  // wave-uniform
-#pragma unroll
-  for (int q = 1; q < kMaxBatch; q++)
-    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
-  quad_group<H, NHID, AFFINE, CTRL>(b.inst[i], sh, (int)blockIdx.x - b.first[i]);
+  // grid (groups of the largest instance, instances): the instance from the workgroup's own index -- one round trip to the
+  // argument segment instead of two dependent ones (rollout_row.hip: rollout_row_batch_kernel)
+  const RolloutArgs &a = b.inst[blockIdx.y];
+  if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;
+  quad_group<H, NHID, AFFINE, CTRL>(a, sh, (int)blockIdx.x);
 }
 
 // Debug/test entry: state derivative of n independent (state, control) pairs through the
@@ -688,7 +688,9 @@ static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipS
 template <int H, int NHID>
 static hipError_t launch_quad_batch_t(const QuadBatchArgs &b, bool affine, bool ctrl, hipStream_t stream)
 {
-  const dim3 grid(b.first[b.n]), block(256);
+  int gmax = 0;
+  for (int i = 0; i < b.n; i++) gmax = b.inst[i].K / kRolloutsPerWave > gmax ? b.inst[i].K / kRolloutsPerWave : gmax;
+  const dim3 grid(gmax, b.n), block(256);
   if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, false>), grid, block, 0, stream, b);
   else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, true>), grid, block, 0, stream, b);
   else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, false>), grid, block, 0, stream, b);

@@ -274,8 +274,10 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   else { group_rng_wave<SH, true>(a, sh, g0); RSTAMP(8); }
 }
 
-// several instances in one launch (mppi_compute_control_batch): workgroups [first[i], first[i+1]) run instance i, whose
-// argument block carries group0 = first[i]
+// several instances in one launch (mppi_compute_control_batch): grid (groups of the largest instance, instances) -- workgroup
+// (x, y) runs group x of instance y, whose argument block sits at a position the workgroup knows from its own index: ONE
+// round trip to the argument segment, as in the single-instance kernel (a search of the instance in a table of first
+// workgroups made it two dependent ones, ~1 us of every launch -- the argument segment is not close memory)
 template <int H, bool AFFINE, bool CTRL>
 __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchArgs b)
 {
@@ -284,11 +286,9 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
   __shared__ __attribute__((aligned(16))) SH sh;
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int i = 0;  // workgroup-uniform
-#pragma unroll
-  for (int q = 1; q < kMaxBatch; q++)
-    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
+  const int i = (int)blockIdx.y;  // workgroup-uniform
   const RolloutArgs &a = b.inst[i];
+  if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;  // a smaller instance than the largest of the batch
   if (role == 0) {
 #pragma unroll
     for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
@@ -318,11 +318,17 @@ hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream)
     affine = affine && b.inst[i].cost.affine != 0;
     ctrl = ctrl || b.inst[i].cost.need_control_cost != 0;
   }
-  const dim3 grid(b.first[b.n]), block(512);
-  if (affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, false>), grid, block, 0, stream, b);
-  else if (affine && ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, true>), grid, block, 0, stream, b);
-  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, false>), grid, block, 0, stream, b);
-  else hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, true>), grid, block, 0, stream, b);
+  QuadBatchArgs c = b;  // the kernel indexes an instance's rollouts by blockIdx.x alone
+  int gmax = 0;
+  for (int i = 0; i < b.n; i++) {
+    c.inst[i].group0 = 0;
+    gmax = c.inst[i].K / kRolloutsPerWave > gmax ? c.inst[i].K / kRolloutsPerWave : gmax;
+  }
+  const dim3 grid(gmax, b.n), block(512);
+  if (affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, false>), grid, block, 0, stream, c);
+  else if (affine && ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, true>), grid, block, 0, stream, c);
+  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, false>), grid, block, 0, stream, c);
+  else hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, true>), grid, block, 0, stream, c);
   return hipGetLastError();
 }
 

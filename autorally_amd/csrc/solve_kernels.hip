@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs
 }
 
 // The tails of several instances (K <= kRedChunk each: T + 1 workgroups per instance) in one launch, behind
-// rollout_quad_batch_kernel: workgroups [first[i], first[i + 1]) are instance i's.
+// rollout_quad_batch_kernel: grid (T + 1 of the longest instance, instances), workgroup (x, y) is row x of instance y.
 struct TailBatchArgs {
   int n;
   int first[kMaxBatch + 1];
@@ -467,11 +467,11 @@ struct TailBatchArgs {
 };
 __global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const TailBatchArgs b)
 {
-  int i = 0;  // workgroup-uniform
-#pragma unroll
-  for (int q = 1; q < kMaxBatch; q++)
-    if (q < b.n && (int)blockIdx.x >= b.first[q]) i = q;
-  solve_tail_body(b.inst[i], (int)blockIdx.x - b.first[i]);
+  // grid (T + 1 of the longest instance, instances): the instance from the workgroup's own index, one round trip to the
+  // argument segment (rollout_row.hip: rollout_row_batch_kernel)
+  const TailArgs &a = b.inst[blockIdx.y];
+  if ((int)blockIdx.x > a.T) return;
+  solve_tail_body(a, (int)blockIdx.x);
 }
 
 // slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
@@ -621,7 +621,9 @@ hipError_t launch_solve_tail_batch(const TailLaunch *l, int n, hipStream_t strea
     b.inst[i] = b.inst[0];
     b.first[i + 1] = b.first[n];
   }
-  hipLaunchKernelGGL(solve_tail_batch_kernel, dim3(b.first[n]), dim3(kTailThreads), dyn, stream, b);
+  int tmax = 0;
+  for (int i = 0; i < n; i++) tmax = l[i].T > tmax ? l[i].T : tmax;
+  hipLaunchKernelGGL(solve_tail_batch_kernel, dim3(tmax + 1, n), dim3(kTailThreads), dyn, stream, b);
   return hipGetLastError();
 }
 
