@@ -450,7 +450,7 @@ __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const Rollout
 // loop): workgroup (x, y) runs group x of instance y
 __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const QuadBatchArgs b)
 {
-  const RolloutArgs &a = b.inst[blockIdx.y];  // (the instance from the workgroup's own index: rollout_row.hip, rollout_row_batch_kernel)
+  const RolloutArgs a = b.inst[blockIdx.y];  // (a copy, the instance from the workgroup's own index: rollout_row.hip, rollout_row_batch_kernel)
   if ((int)blockIdx.x >= a.K / kBfLanes) return;
   bf3_group(a, (int)blockIdx.x);
 }

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatch
   __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
   // grid (groups of the largest instance, instances): the instance from the workgroup's own index -- one round trip to the
   // argument segment instead of two dependent ones (rollout_row.hip: rollout_row_batch_kernel)
-  const RolloutArgs &a = b.inst[blockIdx.y];
+  const RolloutArgs a = b.inst[blockIdx.y];  // a copy: through a reference the waves re-read parameters from the segment in their loops
   if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;
   quad_group<H, NHID, AFFINE, CTRL>(a, sh, (int)blockIdx.x);
 }

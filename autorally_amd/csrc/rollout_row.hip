@@ -287,8 +287,13 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = (int)blockIdx.y;  // workgroup-uniform
-  const RolloutArgs &a = b.inst[i];
+  // A COPY of the instance's block, not a reference into the argument segment: through the reference the riders re-read
+  // their parameters from the segment inside their loops (38 scalar loads in the kernel, 30 of them in loops; 12 and 1 with
+  // the copy, as in the single-instance kernel): 48.3 -> 47.4 us by rocprofv3
+  const RolloutArgs a = b.inst[i];
   if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;  // a smaller instance than the largest of the batch
+  MrgHalf g0{0, 0, 0};
+  if (role == R::kRng) g0 = group_rng_load(a);  // in front of the barrier (with the copy above: 47.7 -> 46.3 us)
   if (role == 0) {
 #pragma unroll
     for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
   else if (role == R::kCost) group_cost_wave4<SH, CTRL>(a, sh);
   else if (role == R::kCtl) group_control_wave(a, sh);
   else if (role == R::kPose) group_pose_wave4<SH, AFFINE>(a, sh);
-  else group_rng_wave(a, sh);
+  else group_rng_wave<SH, true>(a, sh, g0);
 }
 
 bool row_variant_supported(int hidden, int n_hidden) { return hidden == 32 && n_hidden == 2; }

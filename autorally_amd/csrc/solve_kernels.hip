@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const Ta
 {
   // grid (T + 1 of the longest instance, instances): the instance from the workgroup's own index, one round trip to the
   // argument segment (rollout_row.hip: rollout_row_batch_kernel)
-  const TailArgs &a = b.inst[blockIdx.y];
+  const TailArgs a = b.inst[blockIdx.y];  // a copy (a reference makes the body re-read its parameters from the segment)
   if ((int)blockIdx.x > a.T) return;
   solve_tail_body(a, (int)blockIdx.x);
 }
