@@ -74,7 +74,7 @@ __device__ __forceinline__ MrgHalf group_rng_load(const RolloutArgs &a)
 {
   const int lane = threadIdx.x & 63;
   const int j = (lane >> 1) & 15, c = lane & 1;
-  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
   const int K = a.K;
   MrgHalf g{0, 0, 0};
   if (a.inline_noise != 0 && lane < 2 * kRolloutsPerWave) {
@@ -89,7 +89,7 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh, con
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
   const int j = (lane >> 1) & 15, c = lane & 1;
-  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
   const bool active = lane < 2 * kRolloutsPerWave;
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kRng + 1);
@@ -152,7 +152,7 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
   static_assert(kGCtlChunk == 4 && kGRing >= 2 * kGCtlChunk, "four steps per iteration, lanes 16 q + j");
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, q = lane >> 4;
-  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
   const int K = a.K, T = a.T;
   const bool inl = a.inline_noise != 0;
   float2 *const noise = reinterpret_cast<float2 *>(a.noise);
@@ -373,7 +373,7 @@ __device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
-  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
   const int T = a.T;
   const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
   const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
@@ -428,7 +428,7 @@ __device__ __forceinline__ void group_cost_wave4(const RolloutArgs &a, SH &sh)
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
   const int j = lane >> 2, q = lane & 3;
-  const int k = ((int)blockIdx.x - a.group0) * kRolloutsPerWave + j;
+  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
   const int T = a.T;
   const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
   const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);

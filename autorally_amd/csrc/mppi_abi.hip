@@ -392,6 +392,12 @@ std::vector<float> pack_row_weights(const std::vector<float> &theta)
     float *b = entry(35), *c = entry(36);
     b[0] = B1[j0] * kTanhScale; b[1] = B1[j1] * kTanhScale; b[2] = B2[j0] * kTanhScale; b[3] = B2[j1] * kTanhScale;
     c[0] = B3[o0]; c[1] = B3[o1];
+    // tree form (row_out_tree): this lane's own two activations into the four outputs, output (p >> 2) ^ i at position i
+    const int o = p >> 2;
+    float *t0 = entry(37), *t1 = entry(38), *t2 = entry(39);
+    t0[0] = W3[o * H + j0]; t0[1] = W3[(o ^ 1) * H + j0]; t0[2] = W3[o * H + j1]; t0[3] = W3[(o ^ 1) * H + j1];
+    t1[0] = W3[(o ^ 2) * H + j0]; t1[1] = W3[(o ^ 3) * H + j0]; t1[2] = W3[(o ^ 2) * H + j1]; t1[3] = W3[(o ^ 3) * H + j1];
+    t2[0] = B3[o];
   }
   return out;
 }
@@ -426,6 +432,7 @@ bool use_valu_reg(const mppi_handle *h) { return !h->basis && !use_mfma(h) && h-
 // whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD on paper (K = 16384) --
 // sometimes two on one SIMD and none on its neighbour, which doubles the kernel time
 // (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us).
+inline bool is_row(int b) { return b == 900 || b == 901; }  // 901: the tree form of the output layer (rollout_row.hip)
 int effective_block(const mppi_handle *h)
 {
   if (h->block_threads != 0) return h->block_threads;
@@ -474,7 +481,7 @@ bool has_noise_wave(const mppi_handle *h)
   if (h->basis) return bf_waves(h) == 3;
   if (!use_mfma(h)) return false;
   const int b = effective_block(h);
-  return b == 512 || b == 900 || ((b == 800 || b > 1000) && !multi_gen(h));
+  return b == 512 || is_row(b) || ((b == 800 || b > 1000) && !multi_gen(h));
 }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
@@ -513,7 +520,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.U = h->d_in;
   a.noise = noise;
   a.costs = h->d_costs;
-  a.wpack = use_mfma(h) ? (effective_block(h) == 900 ? h->d_rowpack : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
+  a.wpack = use_mfma(h) ? (is_row(effective_block(h)) ? h->d_rowpack : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
   a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
@@ -531,7 +538,6 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.inline_noise = 0;
   a.spin_budget = h->spin_budget;
   a.fault_wave = h->fault_wave;
-  a.group0 = 0;
   fill_cost_args(h, a.cost);
 }
 
@@ -542,7 +548,7 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
                  : (use_mfma(h) && effective_block(h) > 1000)
                      ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
                  : (use_mfma(h) && effective_block(h) == 800) ? launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream)
-                 : (use_mfma(h) && effective_block(h) == 900) ? launch_rollout_row(h->hidden, h->n_hidden, a, h->stream)
+                 : (use_mfma(h) && is_row(effective_block(h))) ? launch_rollout_row(h->hidden, h->n_hidden, a, effective_block(h) == 901, h->stream)
                  : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
                                    : launch_rollout_valu(h->net, a, h->stream);
@@ -1480,7 +1486,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     // network model: the four-wavefront form; basis-function model: its three-wavefront form (in-kernel generator)
     const bool form_ok = h->basis ? (h0->basis && bf_waves(h) == 3)
                                   : (!h0->basis && use_mfma(h) && use_mfma(h0) &&
-                                     (effective_block(h) == 512 || effective_block(h) == 900) &&
+                                     (effective_block(h) == 512 || is_row(effective_block(h))) &&
                                      effective_block(h) == effective_block(h0) &&
                                      h->hidden == h0->hidden && h->n_hidden == h0->n_hidden);
     together = form_ok && h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
@@ -1519,7 +1525,6 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     QuadBatchArgs qb;
     TailLaunch tl[kMaxBatch];
     qb.n = n;
-    qb.first[0] = 0;
     const bool last = (it == iters - 1);
     for (int i = 0; i < n; i++) {
       mppi_handle *h = hs[i];
@@ -1535,17 +1540,12 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
         a.rng_out = h->d_rng[1 - h->rng_cur];
         h->rng_cur = 1 - h->rng_cur;
       }
-      a.group0 = qb.first[i];
-      qb.first[i + 1] = qb.first[i] + (h->basis ? h->K / 64 : h->K / kRolloutsPerWave);
       tl[i] = tail_launch(h, noise, last);
       if (last) h->slid_valid = wants_slid_copy(h);
     }
-    for (int i = n; i < kMaxBatch; i++) {
-      qb.inst[i] = qb.inst[0];
-      qb.first[i + 1] = qb.first[n];
-    }
+    for (int i = n; i < kMaxBatch; i++) qb.inst[i] = qb.inst[0];
     hipError_t e = h0->basis ? launch_rollout_bf_batch(qb, S)
-                   : effective_block(h0) == 900 ? launch_rollout_row_batch(qb, S)
+                   : is_row(effective_block(h0)) ? launch_rollout_row_batch(qb, effective_block(h0) == 901, S)
                                                 : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
     if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
     if (e != hipSuccess) return fail(h0, MPPI_ERR_HIP, "batched launch", e);
@@ -1912,8 +1912,8 @@ const char *mppi_rollout_variant(const mppi_handle *h)
   else if (b > 1000)
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi%d%s", h->hidden, h->n_hidden, b - 1000,
              multi_gen(h) ? "_gen" : "");
-  else if (b == 900)
-    snprintf(buf, sizeof(buf), "valu_row8w_h%d_l%d", h->hidden, h->n_hidden);
+  else if (is_row(b))
+    snprintf(buf, sizeof(buf), "valu_row8w%s_h%d_l%d", b == 901 ? "_tree" : "", h->hidden, h->n_hidden);
   else
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
              b == 512 ? "quad4w" : b == 800 ? (multi_gen(h) ? "oct8w_gen" : "oct8w") : (b == 256 ? "fused_b256" : "fused_b64"));
@@ -1937,10 +1937,10 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     if (!h->basis) return fail(h, MPPI_ERR_UNSUPPORTED, "bf3 is a form of the basis-function model");
     h->block_threads = 768;
   }
-  else if (strcmp(name, "row") == 0) {
+  else if (strcmp(name, "row") == 0 || strcmp(name, "row_exact") == 0 || strcmp(name, "row_tree") == 0) {
     if (!h->mfma_ok || !row_variant_supported(h->hidden, h->n_hidden))
       return fail(h, MPPI_ERR_UNSUPPORTED, "row form exists for 6-32x2-4");
-    h->block_threads = 900;
+    h->block_threads = strcmp(name, "row_tree") == 0 ? 901 : 900;
   }
   else if (strcmp(name, "oct") == 0 || strcmp(name, "oct_gen") == 0) {
     if (!h->mfma_ok || !oct_variant_supported(h->hidden, h->n_hidden))

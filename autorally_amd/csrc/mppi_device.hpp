@@ -53,19 +53,14 @@ struct RolloutArgs {
   // and -- tests only -- the wavefront role (1-based, 0 = none) that starts with that budget exhausted
   // (mppi_debug_inject_handover_fault)
   int spin_budget, fault_wave;
-  // first workgroup of this instance inside a batched launch (kernels built on group_roles.hpp index their rollouts
-  // by blockIdx.x - group0); 0 in a stand-alone launch
-  int group0;
   CostArgs cost;
 };
 
 // Argument block of the batched rollout kernels: grid (groups of the largest instance, instances), workgroup (x, y) runs
-// group x of inst[y].  first[] -- the instances' first workgroups in a one-dimensional numbering -- is host-side bookkeeping
-// (the kernels looked their instance up in it until the lookup's second trip to the argument segment was measured).
+// group x of inst[y]: every kernel indexes an instance's rollouts by blockIdx.x alone.
 constexpr int kMaxBatch = 4;
 struct QuadBatchArgs {
   int n;
-  int first[kMaxBatch + 1];
   RolloutArgs inst[kMaxBatch];
 };
 

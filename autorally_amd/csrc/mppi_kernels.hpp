@@ -45,8 +45,9 @@ hipError_t launch_rollout_oct(int hidden, int n_hidden, const RolloutArgs &a, hi
 // control and noise wave per 16 rollouts; a.wpack = the weights in register order (pack_row_weights, mppi_abi.hip)
 bool row_variant_supported(int hidden, int n_hidden);
 int row_pack_floats();
-hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
-hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream);  // grid (groups, instances)
+// tree: the output layer as own-activation partials + a DPP butterfly (NOT the reference's summation order: opt-in by tolerance)
+hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, bool tree, hipStream_t stream);
+hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, bool tree, hipStream_t stream);  // grid (groups, instances)
 
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {

@@ -63,19 +63,23 @@ struct RowShared {
                                                                  // pair (never read): 8 B per lane, moved along with the ring slot
 };
 
-template <int H>
+// TREE (the "row_tree" form): the output layer as own-activation partials + a butterfly over the row instead of the
+// k-ascending chain -- see row_out_tree below; w3 then holds this lane's 2 x 4 output weights instead of all 32 x 2.
+template <int H, bool TREE>
 struct RowWeights {
-  f32x2 w1[kNetIn], w2[H], w3[H];
+  f32x2 w1[kNetIn], w2[H], w3[TREE ? 4 : H];
   f32x2 b1s, b2s, b3;  // hidden biases pre-scaled for tanh_bias2 (theta_s of the register VALU kernel)
 };
 
 // rowpack: the weights in REGISTER order, written by the host (pack_row_weights, mppi_abi.hip): 16-B entry i of lane p at
 // float4 index i * 16 + p -- a load instruction of a wave reads 256 contiguous bytes (the four rollouts of a wave share
 // them).  Entries: 0..2 = w1[0..5], 3..18 = w2[0..31], 19..34 = w3[0..31] (pairs, two per entry), 35 = (b1s, b2s), 36 = b3.
+// Tree form: 37 = (W3[o][2p], W3[o^1][2p], W3[o][2p+1], W3[o^1][2p+1]), 38 = the same of outputs o^2, o^3, 39 = (b3[o], -, -, -),
+// o = p >> 2 the output this lane's quad ends up with.
 // (Loading the rows straight from the packed theta -- 44 scattered 16-B loads per lane -- cost 2.1 us per launch.)
-constexpr int kRowPackEntries = 37;
-template <int H>
-__device__ __forceinline__ void row_load(const float *rowpack, int p, RowWeights<H> &W)
+constexpr int kRowPackEntries = 40;
+template <int H, bool TREE>
+__device__ __forceinline__ void row_load(const float *rowpack, int p, RowWeights<H, TREE> &W)
 {
   static_assert(H == 32, "entry layout of pack_row_weights");
   const float4 *pk = reinterpret_cast<const float4 *>(rowpack) + p;
@@ -87,16 +91,29 @@ __device__ __forceinline__ void row_load(const float *rowpack, int p, RowWeights
   }
 #pragma unroll
   for (int i = 0; i < H / 2; i++) {
-    const float4 v = pk[(3 + i) * 16], u = pk[(3 + H / 2 + i) * 16];
+    const float4 v = pk[(3 + i) * 16];
     W.w2[2 * i] = f32x2{v.x, v.y};
     W.w2[2 * i + 1] = f32x2{v.z, v.w};
-    W.w3[2 * i] = f32x2{u.x, u.y};
-    W.w3[2 * i + 1] = f32x2{u.z, u.w};
+    if constexpr (!TREE) {
+      const float4 u = pk[(3 + H / 2 + i) * 16];
+      W.w3[2 * i] = f32x2{u.x, u.y};
+      W.w3[2 * i + 1] = f32x2{u.z, u.w};
+    }
   }
-  const float4 b = pk[35 * 16], c = pk[36 * 16];
+  const float4 b = pk[35 * 16];
   W.b1s = f32x2{b.x, b.y};
   W.b2s = f32x2{b.z, b.w};
-  W.b3 = f32x2{c.x, c.y};
+  if constexpr (TREE) {
+    const float4 u = pk[37 * 16], v = pk[38 * 16], c = pk[39 * 16];
+    W.w3[0] = f32x2{u.x, u.y};
+    W.w3[1] = f32x2{u.z, u.w};
+    W.w3[2] = f32x2{v.x, v.y};
+    W.w3[3] = f32x2{v.z, v.w};
+    W.b3 = f32x2{c.x, c.y};
+  } else {
+    const float4 c = pk[36 * 16];
+    W.b3 = f32x2{c.x, c.y};
+  }
 }
 
 // The activation of neuron k of this lane's rollout, from the registers of the lane that computed it: a rollout is one
@@ -136,7 +153,39 @@ __device__ __forceinline__ f32x2 row_dot_bc(const f32x2 *w, f32x2 a)
   return z;
 }
 
-template <int H>
+// The output layer of the TREE form ("row_tree").  In the exact form every lane of a rollout runs the whole 32-long chain
+// for two of the four outputs -- 32 dependent packed multiply-adds and 32 moves per lane and step, ~290 of the step's ~930
+// cycles and 30 % of the kernel's vector instructions, for 4 useful numbers.  Here lane p multiplies only ITS OWN two
+// activations (a[2p], a[2p+1]) into the four outputs (a product and a fused multiply-add each, packed: 4 instructions) and
+// the 16 partials of an output are summed by a butterfly of DPP adds that halves the number of live values per level:
+//   level 1 (row_ror:8):        v0 += v2(p^8), v1 += v3(p^8)    lanes p < 8 keep outputs {0,1}, lanes p >= 8 outputs {2,3}
+//   level 2 (row_half_mirror):  v0 += v1(p^7)                   quad q = p >> 2 keeps output q
+//   level 3, 4 (quad_perm):     v0 += v0(p^1); v0 += v0(p^2)
+// -- 5 adds on a 4-deep chain; which output a lane keeps is wired into the ORDER of its weights (v_i = partial of output
+// (p >> 2) ^ i, pack_row_weights), so no select is needed.  Every lane of quad q ends with output q = state component
+// s[3 + q]: layer 0 of the next step takes the state from lanes 0, 4, 8, 12 of the row.  This is NOT the reference's
+// summation order (neural_net_model.cu:379-394 sums k ascending; the hidden layers keep that order): the form is opt-in by
+// tolerance -- checked bit for bit against the oracle's mode 2 (oracle/mppi_oracle.c: out_tree_dot), and against the
+// nominal oracle at the north-star criteria (controls 1e-4).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float acc, float src)
+{
+  return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_out_tree(const f32x2 *w3, f32x2 a)
+{
+  const f32x2 ax = {a.x, a.x}, ay = {a.y, a.y};
+  const f32x2 v01 = __builtin_elementwise_fma(w3[1], ay, w3[0] * ax);
+  const f32x2 v23 = __builtin_elementwise_fma(w3[3], ay, w3[2] * ax);
+  float v0 = dpp_add<0x128>(v01.x, v23.x);  // row_ror:8
+  const float v1 = dpp_add<0x128>(v01.y, v23.y);
+  v0 = dpp_add<0x141>(v0, v1);              // row_half_mirror: lane p <- lane p ^ 7
+  v0 = dpp_add<0xB1>(v0, v0);               // quad_perm [1,0,3,2]
+  v0 = dpp_add<0x4E>(v0, v0);               // quad_perm [2,3,0,1]
+  return v0;
+}
+
+template <int H, bool TREE>
 __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> &sh, const int w)
 {
   static_assert(H == 32, "row_dot_bc: 32 activations, two per lane of a 16-lane row");
@@ -145,17 +194,13 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   const int jr = 4 * w + r;  // rollout of the group
   const bool odd = (p & 1) != 0;
   const int T = a.T;
-  RowWeights<H> W;
-#ifdef MPPI_DIAG_NOWLOAD  // diagnostic build: what do the weight loads cost at the start of a launch?
-  for (int k = 0; k < kNetIn; k++) W.w1[k] = f32x2{0.01f * k, 0.02f};
-  for (int k = 0; k < H; k++) { W.w2[k] = f32x2{0.001f * k, 0.002f * p}; W.w3[k] = f32x2{0.003f, 0.001f * k}; }
-  W.b1s = W.b2s = W.b3 = f32x2{0.01f, 0.02f};
-#else
-  row_load<H>(a.wpack, p, W);
-#endif
+  RowWeights<H, TREE> W;
+  row_load<H, TREE>(a.wpack, p, W);
   // pinned: the waits for the weight loads sit here, not at their first use inside the T loop
 #pragma unroll
-  for (int k = 0; k < H; k++) { asm volatile("" : "+v"(W.w2[k])); asm volatile("" : "+v"(W.w3[k])); }
+  for (int k = 0; k < H; k++) asm volatile("" : "+v"(W.w2[k]));
+#pragma unroll
+  for (int k = 0; k < (TREE ? 4 : H); k++) asm volatile("" : "+v"(W.w3[k]));
 
   const uint32_t a_myseq = lds_addr(&sh.xseq[w][lane]);
   typedef const volatile int __attribute__((address_space(3))) *lds_int_p;
@@ -165,12 +210,15 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   constexpr int kSlotF2 = kRolloutsPerWave * 2;          // f32x2 per ring slot of ctl_rec (and of rec)
   // The state record of a step is stored by EVERY lane: lanes 0, 1 of a row into the record, the others into a dump row
   // nobody reads -- no exec masking on the recurrence; both move along with the ring slot (one address add for all lanes).
-  const uint32_t a_rec0 = (p < 2) ? lds_addr(&sh.rec[0][jr][2 * p]) : lds_addr(&sh.dump[w][2 * lane]);
+  // (tree form: one component per lane -- quad q of the row holds s[3 + q], lanes 0, 4, 8, 12 write the record)
+  const uint32_t a_rec0 = TREE ? (((p & 3) == 0) ? lds_addr(&sh.rec[0][jr][p >> 2]) : lds_addr(&sh.dump[w][2 * lane]))
+                               : ((p < 2) ? lds_addr(&sh.rec[0][jr][2 * p]) : lds_addr(&sh.dump[w][2 * lane]));
   constexpr uint32_t kRecStride = sizeof(float) * kRolloutsPerWave * 4;
 
   // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p -- every even / odd lane of a rollout computes
   // the same output pair; layer 0 takes the pairs of lanes 0 and 1 of the row
-  f32x2 sp = odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
+  // (tree form: sp.x = s[3 + (p >> 2)], sp.y unused)
+  f32x2 sp = TREE ? f32x2{a.state[3 + (p >> 2)], 0.0f} : odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
   if (w == 0) RSTAMP(2);  // weights in registers
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
@@ -183,10 +231,12 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   for (int t = 0; t < T - 1; t++) {
     const int slot = t & (kGRing - 1);
     const f32x2 u = un;
-    const f32x2 slo = f32x2{row_bc<0>(sp.x), row_bc<0>(sp.y)}, shi = f32x2{row_bc<1>(sp.x), row_bc<1>(sp.y)};  // (s3, s4), (s5, s6)
+    const f32x2 slo = TREE ? f32x2{row_bc<0>(sp.x), row_bc<4>(sp.x)} : f32x2{row_bc<0>(sp.x), row_bc<0>(sp.y)};    // (s3, s4)
+    const f32x2 shi = TREE ? f32x2{row_bc<8>(sp.x), row_bc<12>(sp.x)} : f32x2{row_bc<1>(sp.x), row_bc<1>(sp.y)};  // (s5, s6)
     // record for the pose / cost waves: the state BEFORE the update (the ring slot is free: see the end of the step);
     // then the publication -- which also says: this wave is done with the control record of step t
-    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)slot * kRecStride), "v"(sp) : "memory");
+    if constexpr (TREE) asm volatile("ds_write_b32 %0, %1" ::"v"(a_rec0 + (uint32_t)slot * kRecStride), "v"(sp.x) : "memory");
+    else asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)slot * kRecStride), "v"(sp) : "memory");
     lds_publish(a_myseq, t + 1);
     // layer 0: [s3, s4, s5, s6, u0, u1]
     f32x2 z = {0.0f, 0.0f};
@@ -218,7 +268,11 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
     const int want = t + 2;
     const int cp_e = __builtin_amdgcn_readfirstlane(cp_v);
     asm volatile("" : "+v"(un));  // the wait for the two reads sits HERE (long arrived), not behind the next step's LDS stores
-    {
+    if constexpr (TREE) {
+      const float d = row_out_tree(W.w3, a1) + W.b3.x;
+      sp.x = fmaf(d, a.dt, sp.x);  // incrementState, neural_net_model.cu:334-344
+      asm volatile("" : "+v"(sp.x));
+    } else {
       const f32x2 d = row_dot_bc(W.w3, a1) + W.b3;
       sp = __builtin_elementwise_fma(d, f32x2{a.dt, a.dt}, sp);  // incrementState, neural_net_model.cu:334-344
       asm volatile("" : "+v"(sp));  // the chain stays here (otherwise it is sunk below the wait, away from its moves)
@@ -235,13 +289,14 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   if (w == 0) RSTAMP(4);  // T loop done
   {  // the record of step T-1
     const int t = T - 1;
-    asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)(t & (kGRing - 1)) * kRecStride), "v"(sp) : "memory");
+    if constexpr (TREE) asm volatile("ds_write_b32 %0, %1" ::"v"(a_rec0 + (uint32_t)(t & (kGRing - 1)) * kRecStride), "v"(sp.x) : "memory");
+    else asm volatile("ds_write_b64 %0, %1" ::"v"(a_rec0 + (uint32_t)(t & (kGRing - 1)) * kRecStride), "v"(sp) : "memory");
     lds_publish(a_myseq, t + 1);
   }
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
-template <int H, bool AFFINE, bool CTRL>
+template <int H, bool AFFINE, bool CTRL, bool TREE>
 __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
 {
   using SH = RowShared<H>;
@@ -267,7 +322,7 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
 #ifdef MPPI_ROW_RIDER_PRIO
   if (role >= 4) __builtin_amdgcn_s_setprio(MPPI_ROW_RIDER_PRIO);
 #endif
-  if (role < 4) row_dynamics<H>(a, sh, role);
+  if (role < 4) row_dynamics<H, TREE>(a, sh, role);
   else if (role == R::kCost) { group_cost_wave4<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
   else if (role == R::kCtl) { group_control_wave(a, sh); RSTAMP(6); }
   else if (role == R::kPose) { group_pose_wave4<SH, AFFINE>(a, sh); RSTAMP(7); }
@@ -278,7 +333,7 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
 // (x, y) runs group x of instance y, whose argument block sits at a position the workgroup knows from its own index: ONE
 // round trip to the argument segment, as in the single-instance kernel (a search of the instance in a table of first
 // workgroups made it two dependent ones, ~1 us of every launch -- the argument segment is not close memory)
-template <int H, bool AFFINE, bool CTRL>
+template <int H, bool AFFINE, bool CTRL, bool TREE>
 __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchArgs b)
 {
   using SH = RowShared<H>;
@@ -305,7 +360,7 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
     sh.fin[lane & 7] = 0;
   }
   __syncthreads();
-  if (role < 4) row_dynamics<H>(a, sh, role);
+  if (role < 4) row_dynamics<H, TREE>(a, sh, role);
   else if (role == R::kCost) group_cost_wave4<SH, CTRL>(a, sh);
   else if (role == R::kCtl) group_control_wave(a, sh);
   else if (role == R::kPose) group_pose_wave4<SH, AFFINE>(a, sh);
@@ -315,39 +370,41 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
 bool row_variant_supported(int hidden, int n_hidden) { return hidden == 32 && n_hidden == 2; }
 int row_pack_floats() { return kRowPackEntries * 16 * 4; }
 
-hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, hipStream_t stream)
+// The four (AFFINE, CTRL) instances of a kernel template, tree or exact
+#define MPPI_ROW_DISPATCH(LAUNCH, KERN, TREE, ...)                                                            \
+  do {                                                                                                        \
+    if (affine && !ctrl) LAUNCH((KERN<32, true, false, TREE>), __VA_ARGS__);                                  \
+    else if (affine && ctrl) LAUNCH((KERN<32, true, true, TREE>), __VA_ARGS__);                               \
+    else if (!affine && !ctrl) LAUNCH((KERN<32, false, false, TREE>), __VA_ARGS__);                           \
+    else LAUNCH((KERN<32, false, true, TREE>), __VA_ARGS__);                                                  \
+  } while (0)
+
+hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, bool tree, hipStream_t stream)
 {
   if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;
   bool affine = true, ctrl = false;  // the general forms are exact supersets (rollout_mfma.hip)
+  int gmax = 0;
   for (int i = 0; i < b.n; i++) {
     affine = affine && b.inst[i].cost.affine != 0;
     ctrl = ctrl || b.inst[i].cost.need_control_cost != 0;
-  }
-  QuadBatchArgs c = b;  // the kernel indexes an instance's rollouts by blockIdx.x alone
-  int gmax = 0;
-  for (int i = 0; i < b.n; i++) {
-    c.inst[i].group0 = 0;
-    gmax = c.inst[i].K / kRolloutsPerWave > gmax ? c.inst[i].K / kRolloutsPerWave : gmax;
+    gmax = b.inst[i].K / kRolloutsPerWave > gmax ? b.inst[i].K / kRolloutsPerWave : gmax;
   }
   const dim3 grid(gmax, b.n), block(512);
-  if (affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, false>), grid, block, 0, stream, c);
-  else if (affine && ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, true>), grid, block, 0, stream, c);
-  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, false>), grid, block, 0, stream, c);
-  else hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, true>), grid, block, 0, stream, c);
+  if (tree) MPPI_ROW_DISPATCH(hipLaunchKernelGGL, rollout_row_batch_kernel, true, grid, block, 0, stream, b);
+  else MPPI_ROW_DISPATCH(hipLaunchKernelGGL, rollout_row_batch_kernel, false, grid, block, 0, stream, b);
   return hipGetLastError();
 }
 
-hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream)
+hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, bool tree, hipStream_t stream)
 {
   if (!row_variant_supported(hidden, n_hidden) || a.K % kRolloutsPerWave != 0) return hipErrorInvalidValue;
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   const dim3 grid(a.K / kRolloutsPerWave), block(512);
-  if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, true, false>), grid, block, 0, stream, a);
-  else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, true, true>), grid, block, 0, stream, a);
-  else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, false, false>), grid, block, 0, stream, a);
-  else MPPI_LAUNCH_ROLLOUT((rollout_row_kernel<32, false, true>), grid, block, 0, stream, a);
+  if (tree) MPPI_ROW_DISPATCH(MPPI_LAUNCH_ROLLOUT, rollout_row_kernel, true, grid, block, 0, stream, a);
+  else MPPI_ROW_DISPATCH(MPPI_LAUNCH_ROLLOUT, rollout_row_kernel, false, grid, block, 0, stream, a);
   return hipGetLastError();
 }
+#undef MPPI_ROW_DISPATCH
 
 }  // namespace mppi
 

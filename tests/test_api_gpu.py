@@ -318,7 +318,7 @@ def test_control_ticks_equals_the_call_by_call_loop():
 
 
 @pytest.mark.parametrize("family,wave", [("nn", 1), ("nn", 2), ("nn", 3), ("nn", 4), ("nn64", 2),
-                                         ("row", 1), ("row", 2), ("row", 3), ("row", 4), ("row", 5), ("row", 6), ("row", 7), ("row", 8), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
+                                         ("row", 1), ("row", 2), ("row", 3), ("row", 4), ("row", 5), ("row", 6), ("row", 7), ("row", 8), ("row_tree", 1), ("row_tree", 4), ("row_tree", 6), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
                                          ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7), ("multi4", 8),
                                          ("multi2", 2), ("multi2", 3), ("multi2", 4),
                                          ("multi4u", 3), ("multi4u", 5), ("multi4u", 6),

@@ -86,6 +86,56 @@ def test_fma_and_nofma_variants_agree(golden_dir):
         np.testing.assert_allclose(a.state_deriv(s, u), b.state_deriv(s, u), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("name", [m for m in MODELS if "wider" not in m and "writer" not in m])
+def test_tree_mode_of_the_output_layer(golden_dir, name):
+    """fma_mode 2 -- the output layer in the summation order of the row-tree kernel (mppi_oracle.c: out_tree_dot) -- is a
+    re-association of 32 products: pinned by the same reference-Python vectors at the same 1e-5, within the spread the
+    FMA / no-FMA modes already have between themselves, and equal to a numpy statement of the butterfly."""
+    g = load_nn_golden(golden_dir)
+    o0, o1, o2 = (_oracle_for(golden_dir, name, g, m) for m in (0, 1, 2))
+    states, ctrls, ders = g[name + "/states"], g[name + "/controls"], g[name + "/state_ders"]
+    layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", name + ".npz"))
+    assert list(layers) == [6, 32, 32, 4]
+    W3 = theta[-(4 * 32 + 4):-4].reshape(4, 32).astype(np.float32)
+    b3 = theta[-4:].astype(np.float32)
+    W1 = theta[:192].reshape(32, 6); b1 = theta[192:224]; W2 = theta[224:224 + 1024].reshape(32, 32); b2 = theta[1248:1280]
+    worst21 = worst01 = 0.0
+    differs = 0
+    for s, u, d in zip(states, ctrls, ders):
+        sd2, sd1, sd0 = o2.state_deriv(s, u), o1.state_deriv(s, u), o0.state_deriv(s, u)
+        assert float(np.max(np.abs(sd2 - d) / np.maximum(1.0, np.abs(d)))) < 1e-5
+        np.testing.assert_array_equal(sd2[:3], sd1[:3])  # kinematics untouched
+        worst21 = max(worst21, float(np.max(np.abs(sd2 - sd1))))
+        worst01 = max(worst01, float(np.max(np.abs(sd0 - sd1))))
+        differs += int(np.any(sd2 != sd1))
+        # numpy statement of the tree on the mode-1 hidden activations (float32 products are exact in float64, one rounding
+        # per operation): lane p owns activations 2p, 2p+1
+        a = np.array([s[3], s[4], s[5], s[6], u[0], u[1]], np.float32)
+        h = a
+        for W, b in ((W1, b1), (W2, b2)):
+            z = np.zeros(W.shape[0], np.float32)
+            for k in range(W.shape[1]):
+                z = (W[:, k].astype(np.float64) * np.float64(h[k]) + z.astype(np.float64)).astype(np.float32)  # fmaf
+            h = np.tanh((z + b.astype(np.float32)).astype(np.float32)).astype(np.float32)
+        out = np.zeros(4, np.float32)
+        for j in range(4):
+            Pp = np.zeros(16, np.float32)
+            for q in range(16):
+                m = np.float32(W3[j, 2 * q] * h[2 * q])
+                Pp[q] = np.float32(np.float64(W3[j, 2 * q + 1]) * np.float64(h[2 * q + 1]) + np.float64(m))
+            L1 = np.array([Pp[q] + Pp[q ^ 8] for q in range(16)], np.float32)
+            L2 = np.array([L1[q] + L1[q ^ 7] for q in range(16)], np.float32)
+            L3 = np.array([L2[q] + L2[q ^ 1] for q in range(16)], np.float32)
+            out[j] = np.float32(np.float32(L3[0] + L3[2]) + b3[j])
+            # every lane of the kernel's row holds the same bits
+            assert all(np.float32(L3[q] + L3[q ^ 2]) == np.float32(L3[0] + L3[2]) for q in range(16))
+        # (numpy's tanh and libm's tanhf may differ in the last bit of an activation: compare at 2e-6, the order itself
+        # is pinned bit for bit on the GPU, tests/test_row_tree_gpu.py)
+        np.testing.assert_allclose(out, sd2[3:], atol=2e-6, rtol=1e-6)
+    assert differs > 0          # the mode does change bits ...
+    assert worst21 <= max(2 * worst01, 4e-6), (worst21, worst01)  # ... by no more than FMA contraction does
+
+
 # ---------------- MRG32k3a known answers ----------------
 # L'Ecuyer, Simard, Chen, Kelton, "An object-oriented random-number package with many long
 # streams and substreams" (RngStreams): A1p76, A2p76, A1p127, A2p127.
