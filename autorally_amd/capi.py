@@ -63,12 +63,14 @@ SYMBOLS = [
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
     "mppi_debug_inject_handover_fault", "mppi_compute_feedback_gains_pair", "mppi_set_host_threads",
+    "mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout",
 ]
 
 ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
                 "mppi_compute_control_batch", "mppi_compute_control_batch_async", "mppi_control_ticks_batch",
                 "mppi_nominal_traj_pair")
 ABI3_SYMBOLS = ("mppi_compute_feedback_gains_pair", "mppi_set_host_threads")
+ABI4_SYMBOLS = ("mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout")
 
 _lib = None
 
@@ -147,8 +149,13 @@ def lib():
         if v3:
             L.mppi_compute_feedback_gains_pair.argtypes = [hp, fp, fp, fp, hp, fp, fp, fp]
             L.mppi_set_host_threads.argtypes = [C.c_int]
+        v4 = L.mppi_abi_version() >= 4
+        if v4:
+            L.mppi_debug_capture_iterations.argtypes = [hp, C.c_int]
+            L.mppi_debug_get_iterations.argtypes = [hp, fp, fp, fp]
+            L.mppi_set_wait_timeout.argtypes = [hp, C.c_double]
         for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
-            if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS):
+            if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS) and (v4 or s not in ABI4_SYMBOLS):
                 getattr(L, s)
         _lib = L
     return _lib
@@ -381,6 +388,24 @@ class Solver:
         out = np.zeros_like(states)
         self._ck(self.L.mppi_debug_dynamics(self.h, states.shape[0], _fp(states), _fp(controls), _fp(out)))
         return out
+
+    def debug_capture_iterations(self, on=1):
+        self._ck(self.L.mppi_debug_capture_iterations(self.h, int(on)))
+
+    def debug_get_iterations(self, with_V=False):
+        """{"U_raw": [iters][T][2], "costs": [iters][K], "V": [iters][K][T][2] (explicit-noise solves, with_V)}"""
+        it, K, T = int(self.cfg.get("num_iters", 1)), self.cfg["K"], self.cfg["T"]
+        U = np.zeros((it, T, 2), np.float32)
+        c = np.zeros((it, K), np.float32)
+        V = np.zeros((it, K, T, 2), np.float32) if with_V else None
+        self._ck(self.L.mppi_debug_get_iterations(self.h, _fp(U), _fp(c), _fp(V) if with_V else None))
+        out = {"U_raw": U, "costs": c}
+        if with_V:
+            out["V"] = V
+        return out
+
+    def set_wait_timeout(self, seconds):
+        self._ck(self.L.mppi_set_wait_timeout(self.h, float(seconds)))
 
     def debug_inject_handover_fault(self, wave, spin_budget):
         self._ck(self.L.mppi_debug_inject_handover_fault(self.h, int(wave), int(spin_budget)))

@@ -156,6 +156,10 @@ struct mppi_handle {
   float traj_cost = 0.0f, baseline = 0.0f, eta = 0.0f;
 
   int spin_budget = 0, fault_wave = 0;  // mppi_debug_inject_handover_fault (0, 0: kSpinBudget, no fault)
+  // mppi_debug_capture_iterations: [num_iters][2T + K] -- the raw weighted mean U and the costs after every iteration
+  float *d_cap = nullptr;
+  bool capture = false, cap_valid = false, cap_explicit = false;
+  double wait_timeout_s = 30.0;  // mppi_set_wait_timeout
   bool timing = false;
   int timing_every = 1;      // record stage events on every Nth solve only (events add launch gaps)
   unsigned timing_count = 0;
@@ -764,7 +768,7 @@ int wait_pending(mppi_handle *h)
       if (hipStreamQuery(work_stream(h)) == hipSuccess && (__atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) != h->seq ||
                                                       __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq))
         return fail(h, MPPI_ERR_HIP, "solve finished without publishing its result block");
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > h->wait_timeout_s)
         return fail(h, MPPI_ERR_HIP, "timed out waiting for the solve");
     }
   }
@@ -893,6 +897,11 @@ int enqueue_solve(mppi_handle *h, const float *state)
     const bool want_slid = last && wants_slid_copy(h);
     HIPCHK(h, launch_solve_tail(tail_launch(h, noise, last), h->stream));
     if (last) h->slid_valid = want_slid;
+    if (h->capture) {  // test hook: what this iteration left (the last iteration's raw U is in the result block)
+      float *c = h->d_cap + (size_t)it * (2 * (size_t)T + K);
+      if (!last) HIPCHK(h, hipMemcpyAsync(c, h->d_in, sizeof(float) * 2 * (size_t)T, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(c + 2 * (size_t)T, h->d_costs, sizeof(float) * (size_t)K, hipMemcpyDeviceToDevice, h->stream));
+    }
     if (prefetch) {
       h->gen_time_now = timed;  // only the prefetch launch: a generator the stream waits for sits between e[0] and e[1]
       rc = prefetch_noise(h);
@@ -911,6 +920,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
   h->explicit_iters = 0;
   h->pending = true;
   h->pending_timed = timed;
+  h->cap_valid = h->capture;
+  h->cap_explicit = explicit_noise;
   return MPPI_OK;
 }
 
@@ -918,7 +929,7 @@ void free_all(mppi_handle *h)
 {
   if (!h) return;
   float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_scal, h->d_noise, h->d_stage, h->d_costs,
-                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part, h->d_rowpack};
+                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part, h->d_rowpack, h->d_cap};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
@@ -1490,7 +1501,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
                                      effective_block(h) == effective_block(h0) &&
                                      h->hidden == h0->hidden && h->n_hidden == h0->n_hidden);
     together = form_ok && h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
-               h->K <= 4096 && !h->timing && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
+               h->K <= 4096 && !h->timing && !h->capture && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
     // waves of a group that need a SIMD each: quad 4, row 4 dynamics waves (its riders ride), basis functions 3
     waves += h->basis ? 3 * (h->K / 64) : 4 * (h->K / kRolloutsPerWave);
   }
@@ -1968,6 +1979,63 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   else if (strcmp(name, "fused") == 0 || strcmp(name, "block256") == 0) h->block_threads = 256;
   else if (strcmp(name, "block64") == 0) h->block_threads = 64;
   else return fail(h, MPPI_ERR_INVALID, "unknown variant");
+  return MPPI_OK;
+}
+
+/* Debug/test entries (not part of the drop-in surface): what every iteration of a multi-iteration solve left, so that
+ * a test can hold iteration i against the oracle started from the SAME U (mppi_controller.cu:609-667: the loop re-uses
+ * U_ without smoothing in between).  Capturing adds two small device copies per iteration and keeps the handle out of
+ * batched launches. */
+int mppi_debug_capture_iterations(mppi_handle *h, int on)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  if (on && !h->d_cap) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMalloc(&h->d_cap, sizeof(float) * (size_t)h->cfg.num_iters * (2 * (size_t)h->T + h->K)));
+  }
+  h->capture = on != 0;
+  h->cap_valid = false;
+  return MPPI_OK;
+}
+
+int mppi_debug_get_iterations(mppi_handle *h, float *U_raw, float *costs, float *V)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  if (!h->cap_valid) return fail(h, MPPI_ERR_STATE, "no captured solve (mppi_debug_capture_iterations, then a solve on this handle alone)");
+  if (V && !h->cap_explicit) return fail(h, MPPI_ERR_STATE, "applied controls of every iteration exist for explicit-noise solves only");
+  const int iters = h->cfg.num_iters, T = h->T, K = h->K;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  OWN(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t rec = 2 * (size_t)T + K;
+  std::vector<float> buf((size_t)iters * rec);
+  HIPCHK(h, hipMemcpy(buf.data(), h->d_cap, sizeof(float) * buf.size(), hipMemcpyDeviceToHost));
+  for (int it = 0; it < iters; it++) {
+    if (U_raw) {
+      float *u = U_raw + (size_t)it * 2 * T;
+      if (it < iters - 1) memcpy(u, buf.data() + (size_t)it * rec, sizeof(float) * 2 * (size_t)T);
+      else for (int t = 0; t < T; t++) { u[2 * t] = h->h_res[4 * t]; u[2 * t + 1] = h->h_res[4 * t + 2]; }  // rows [u0, seq, u1, seq]
+    }
+    if (costs) memcpy(costs + (size_t)it * K, buf.data() + (size_t)it * rec + 2 * (size_t)T, sizeof(float) * (size_t)K);
+    if (V) {
+      const size_t slot = (size_t)K * T * 2;
+      HIPCHK(h, launch_tk_to_kt(h->d_noise + (size_t)it * slot, h->d_stage, K, T, h->stream));
+      HIPCHK(h, hipMemcpyAsync(V + (size_t)it * slot, h->d_stage, slot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  return MPPI_OK;
+}
+
+/* How long a blocking call polls for a solve's result block before it reports MPPI_ERR_HIP (default 30 s). */
+int mppi_set_wait_timeout(mppi_handle *h, double seconds)
+{
+  if (!h || !(seconds > 0.0)) return MPPI_ERR_INVALID;
+  h->wait_timeout_s = seconds;
   return MPPI_OK;
 }
 

@@ -165,7 +165,7 @@ __device__ __forceinline__ f32x2 row_dot_bc(const f32x2 *w, f32x2 a)
 // (p >> 2) ^ i, pack_row_weights), so no select is needed.  Every lane of quad q ends with output q = state component
 // s[3 + q]: layer 0 of the next step takes the state from lanes 0, 4, 8, 12 of the row.  This is NOT the reference's
 // summation order (neural_net_model.cu:379-394 sums k ascending; the hidden layers keep that order): the form is opt-in by
-// tolerance -- checked bit for bit against the oracle's mode 2 (oracle/mppi_oracle.c: out_tree_dot), and against the
+// tolerance -- checked bit for bit against the test oracle's mode 2 (its out_tree_dot), and against the
 // nominal oracle at the north-star criteria (controls 1e-4).
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float acc, float src)

@@ -32,7 +32,8 @@ extern "C" {
  *    mppi_debug_inject_handover_fault; mppi_slide_control_seq(h, 0) is MPPI_OK (was MPPI_ERR_INVALID); "fused" =
  *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w", "valu_row8w_*"; variants "row", "multi4u". */
 /* 3: + mppi_set_host_threads, mppi_compute_feedback_gains_pair. */
-#define MPPI_ABI_VERSION 3
+/* 4: + mppi_debug_capture_iterations, mppi_debug_get_iterations, mppi_set_wait_timeout; variants "row_tree", "row_exact". */
+#define MPPI_ABI_VERSION 4
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
 #define MPPI_MAX_LAYERS 8
@@ -255,7 +256,9 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
 const char *mppi_rollout_variant(const mppi_handle *h);
 /* Force a variant (A/B of SURVEY cfg 4 and of the kernel forms): "auto"; "mfma" | "valu" | "valu_lds"
  * (arithmetic unit: "mfma" keeps the matrix-instruction forms at every K, "valu" / "valu_lds" are the throughput-style
- * vector kernels); "row" (the vector-ALU latency form, 6-32-32-4 only); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
+ * vector kernels); "row" = "row_exact" (the vector-ALU latency form, 6-32-32-4 only) | "row_tree" (the same with the OUTPUT layer summed as
+ * per-lane partials + a butterfly instead of the reference's k-ascending chain: not bit-identical to the other forms, held to
+ * the 1e-4 tolerance on the controls; tests/test_row_tree_gpu.py); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
  * wavefront per 16 rollouts) | "multi4" | "multi2" | "multi1" (ND dynamics wavefronts of 16 rollouts + one
  * cost + one control wavefront; "_gen" appended: eps from the stand-alone generator kernel) | "oct" | "oct_gen"
  * (64-wide nets: four dynamics wavefronts, one M tile each, + pose, cost, control, noise wavefront per 16
@@ -280,6 +283,23 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
  * Roles of the multi form: 1 .. ND = dynamics waves, then the cost wave and the control wave (ND = 4: the pose
  * wave, the cost wave, the control wave). */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
+
+/* Test hooks (not part of the drop-in surface): what EVERY iteration of a solve with num_iters > 1 left behind.  The
+ * reference's iteration loop (PI/mppi_controller.cu:609-667) re-uses U_ -- the raw weighted mean, unsmoothed -- as the
+ * nominal sequence of the next iteration, so from iteration 2 on a comparison with another implementation is a
+ * comparison on identical inputs only if that implementation is started from THIS one's U of the iteration before.
+ * mppi_debug_capture_iterations(h, 1): from the next solve on, keep them (two small device copies per iteration; such a
+ * handle is solved on its own, never inside a batched launch); 0: off.
+ * mppi_debug_get_iterations: U_raw [num_iters][T][2] = the weighted mean after iteration i before any smoothing
+ * (weightedReductionKernel's output, :219-267), costs [num_iters][K], V [num_iters][K][T][2] = the applied controls
+ * (explicit-noise solves only: MPPI_ERR_STATE otherwise); each may be NULL. */
+int mppi_debug_capture_iterations(mppi_handle *h, int on);
+int mppi_debug_get_iterations(mppi_handle *h, float *U_raw, float *costs, float *V);
+
+/* How long a blocking call (mppi_compute_control, mppi_synchronize, mppi_get_results ...) polls for a solve's result block
+ * before it gives up with MPPI_ERR_HIP; default 30 s.  (The reference blocks in cudaStreamSynchronize without a limit,
+ * PI/mppi_controller.cu:667; at 50 Hz a controller may want a limit of a few periods.) */
+int mppi_set_wait_timeout(mppi_handle *h, double seconds);
 
 #ifdef __cplusplus
 }

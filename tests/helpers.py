@@ -44,3 +44,76 @@ def load_nn_golden(golden_dir):
         z = np.load(os.path.join(golden_dir, f))
         g.update({k: z[k] for k in z.files})
     return g
+
+
+COST_RTOL = 3e-6  # a-priori relative tolerance of a rollout cost away from the discontinuities (tanh / sincos / atan forms)
+
+
+def first_order_bound(gamma, w_norm, dJ, costs_ref, flipped, V_ref, U_ref):
+    """|dU| a softmax-weighted mean can move, to first order, when the costs move by dJ: dw_k / w_k = -gamma (dJ_k - sum_j w_j
+    dJ_j), hence |dU| <= 2 gamma sum_k w_k |dJ_k| max_k |V_k - U|.  Large costs x gamma make this exceed the 2e-4 of a clean
+    draw although every cost agrees to the last digits.  |dJ_k| is the MEASURED difference but never more than COST_RTOL |J_k|:
+    the bound does not widen with the device's error beyond the a-priori tolerance (rollouts beyond 1e-4 are accounted for by
+    their weight mass instead)."""
+    keep = ~flipped
+    d = np.minimum(np.abs(dJ), COST_RTOL * np.maximum(np.abs(costs_ref.astype(np.float64)), 1.0))
+    return 2.0 * float(gamma) * float(np.sum(w_norm[keep] * d[keep])) * float(np.max(np.abs(V_ref - U_ref[None])))
+
+
+def solve_with_iterations(cfg, variant, U0, hist, eps):
+    """One HIP solve with every iteration captured (mppi_debug_capture_iterations): (results, iterations, variant name)."""
+    from autorally_amd import capi
+    sol = capi.Solver(cfg)
+    try:
+        sol.set_rollout_variant(variant)
+    except capi.MppiError:
+        pass  # a form this layer list does not have: the automatic choice stays
+    sol.debug_capture_iterations(1)
+    sol.set_control_seq(U0)
+    sol.set_control_hist(hist)
+    sol.set_noise(eps)
+    sol.compute_control(cfg["start_state"])
+    got = sol.get_results()
+    its = sol.debug_get_iterations(with_V=True)
+    name = sol.rollout_variant()
+    sol.close()
+    return got, its, name
+
+
+def teacher_forced_iterations(cfg, got, its, U0, hist, eps, fma_mode=1, nthreads=16):
+    """Per-iteration comparison on IDENTICAL inputs (mppi_controller.cu:609-667 re-uses the raw weighted mean U_ as the next
+    iteration's nominal sequence): iteration i of the HIP solve started from ITS OWN U after iteration i-1, so the oracle's
+    iteration i is started from that same U.  Returns one dict per iteration: V_equal, flipped (fraction of rollouts beyond
+    1e-4 relative), mass (weight they carry), dU (raw weighted mean, L-inf), first_order (2 gamma sum w|dJ| max|V - U| over the
+    rollouts that did not flip), eta, and for the last iteration dU_smoothed / d_traj_cost."""
+    iters = int(cfg.get("num_iters", 1))
+    c1 = dict(cfg, num_iters=1)
+    orc = O.Oracle(c1, fma_mode=fma_mode, nthreads=nthreads)
+    out = []
+    for i in range(iters):
+        U_in = np.asarray(U0, np.float32) if i == 0 else its["U_raw"][i - 1]
+        costs_o, V_o, _ = orc.rollouts(cfg["start_state"], U_in, eps[i])
+        w_o, _, eta, tc = orc.weights(costs_o)
+        U_o = orc.weighted_reduction(w_o, eta, V_o)
+        w_g, _, eta_g, tc_g = orc.weights(its["costs"][i])
+        err = rel_err(its["costs"][i], costs_o)
+        fl = err > 1e-4
+        wn, wgn = w_o / w_o.sum(), w_g / w_g.sum()
+        dJ = np.abs(its["costs"][i].astype(np.float64) - costs_o.astype(np.float64))
+        m = {"V_equal": bool(np.array_equal(its["V"][i].view(np.uint32), V_o.view(np.uint32))),
+             "flipped": float(np.mean(fl)), "n_flipped": int(fl.sum()),
+             "mass": float(np.sum(np.maximum(wn, wgn)[fl])),
+             "dU": float(np.max(np.abs(its["U_raw"][i] - U_o))),
+             "first_order": first_order_bound(cfg["gamma"], wn, dJ, costs_o, fl, V_o, U_o),
+             "eta": float(eta), "p99": float(np.percentile(err, 99)), "median_cost": float(np.median(costs_o))}
+        if i == iters - 1:
+            m["dU_smoothed"] = float(np.max(np.abs(got["U"] - orc.savgol(U_o, hist))))
+            m["d_traj_cost"] = abs(got["traj_cost"] - tc) / max(abs(tc), 1e-3)
+        out.append(m)
+    return out
+
+
+def iteration_ok(m, with_first_order=True):
+    """The single-iteration criterion of tests/test_fuzz_gpu.py on one teacher-forced iteration."""
+    bound = 2e-4 + 4.0 * m["mass"] + (m["first_order"] if with_first_order else 0.0)
+    return m["V_equal"] and m["flipped"] <= 0.03 and m["dU"] <= bound and m.get("dU_smoothed", 0.0) <= bound
