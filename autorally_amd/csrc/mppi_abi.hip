@@ -447,7 +447,10 @@ int effective_block(const mppi_handle *h)
     // 6-32-32-4 at one group per CU: the vector-ALU ROW form (rollout_row.hip) -- the shortest recurrence of all
     // (K=4096, T=100: 56.8 us; quad 68.2 us)
     // ("mfma" asked for explicitly -- the A/B arm of SURVEY cfg 4 -- keeps the matrix-instruction forms)
-    if (groups <= cus && row_variant_supported(h->hidden, h->n_hidden) && h->variant_pref != 1) return 900;
+    // -- in its TREE form (901: the output layer as per-lane partials + a butterfly, rollout 45.8 -> 36.7 us; inside the
+    // north-star tolerance of the reference's summation order, tests/test_row_tree_gpu.py); "row_exact" keeps the
+    // k-ascending output chain (900), bit-identical to every other form
+    if (groups <= cus && row_variant_supported(h->hidden, h->n_hidden) && h->variant_pref != 1) return 901;
     if (groups <= cus) return 512;
     if (groups <= 2 * cus) return 1002;
     // (64-wide nets beyond one group per SIMD: the eight-wave form needs 172 VGPRs = one workgroup per CU, so K = 32768

@@ -33,18 +33,29 @@ ROLLOUT_BYTES_INLINE_NOISE = 8
 ROLLOUT_BYTES_BUFFERED_NOISE = 16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (= f32 vector) peak
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", f) for f in (  # newest first: the first match is taken
-    "r03_n_headline_row_pmc.json", "r03_m_headline_row_pmc.json", "r03_l_headline_row_pmc.json", "r03_k_headline_row_pmc.json", "r03_k_cfg2_pmc.json", "r03_k_cfg1_pmc.json", "r03_j_headline_row_pmc.json", "r03_e_headline_row_pmc.json",
-    "r03_d_headline_pmc.json", "r03_d_cfg4_pmc.json", "r03_c_k32768_multi4_pmc.json", "r02_h_k8192_multi2_pmc.json")] + \
-    sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r03_i_*_pmc.json")))
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources a rollout launch is compiled from: tools/prof_summary.py stamps a
+    PMC summary with it, and a summary taken on other sources no longer describes the code that is running."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "autorally_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "autorally_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(cfg, variant):
-    """(HBM bytes per rollout launch, file) from the committed rocprofv3 PMC passes (tools/prof_run.sh:
-    FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, separate passes), if one of them was taken on
-    this exact workload and kernel form; else (None, None).  PMC counters cannot be read from inside this
-    process, so this is the profiled constant."""
-    for path in TRAFFIC_PROFILES:
+    """(HBM bytes per rollout launch or None, note) from the committed rocprofv3 PMC passes (tools/prof_run.sh:
+    FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, separate passes).  PMC counters cannot be read from inside this
+    process, so this is a profiled constant: taken from the newest profiles/r*_pmc.json of this exact workload and kernel
+    form, and only if that summary was stamped with the kernel sources this run was built from -- otherwise None, with
+    the stale figure named in the note."""
+    import glob
+    sha = kernel_sources_sha16()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):  # newest round / letter first
         try:
             with open(path) as f:
                 p = json.load(f)
@@ -52,11 +63,16 @@ def measured_traffic(cfg, variant):
             if (w["K"], w["T"], w["layers"], w["rollout_variant"]) != (cfg["K"], cfg["T"], list(cfg["layers"]), variant):
                 continue
             for name, e in p["kernels"].items():
-                if "rollout" in name:
-                    return e["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+                if "rollout" in name and "traffic_bytes_per_launch" in e:
+                    rel = os.path.relpath(path, ROOT)
+                    if p.get("kernel_sources_sha16") == sha:
+                        return e["traffic_bytes_per_launch"], "HBM bytes per launch (rocprofv3 PMC passes, %s, same kernel sources %s)" % (rel, sha)
+                    if stale is None:
+                        stale = "null: the newest PMC pass of this workload and form (%s: %.0f bytes per launch) was taken on other kernel sources (%s, now %s)" % (
+                            rel, e["traffic_bytes_per_launch"], p.get("kernel_sources_sha16", "unstamped"), sha)
         except (OSError, KeyError, ValueError):
             pass
-    return None, None
+    return None, stale or "null: no committed PMC pass (tools/prof_run.sh -> profiles/) for this workload and kernel form"
 
 
 BASIS_FLOPS_PER_UPDATE = 270  # 100 MACs of W phi + ~70 multiply/divide/add of the 25 basis functions, no transcendentals
@@ -67,7 +83,7 @@ def flops_per_update(layers):
     return sum(2 * a * b + b for a, b in zip(layers[:-1], layers[1:]))
 
 
-def init_dist(backend, devices=None):
+def init_dist(backend, devices=None, force=False):
     """(rank, device, world, dist-or-None); one process per GPU, env from torch.distributed.run.
     `devices` (--devices "0,0"): rank -> device map for rehearsing the N > 1 path on fewer GPUs than ranks
     (then with --dist-backend gloo: RCCL refuses two ranks on one device); default device = LOCAL_RANK."""
@@ -79,7 +95,7 @@ def init_dist(backend, devices=None):
         if len(devices) != world:
             raise SystemExit("--devices names %d devices for WORLD_SIZE=%d" % (len(devices), world))
         device = devices[rank]
-    if world == 1:
+    if world == 1 and not force:
         return rank, device, world, None
     import torch
     import torch.distributed as dist
@@ -239,6 +255,9 @@ def main():
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="process group for barrier / max / gather (never on the data path); nccl = RCCL (default), "
                          "gloo for rehearsing N > 1 with several ranks on one GPU")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise the process group at world size 1 too (smoke of the RCCL path on a one-GPU box: "
+                         "barrier and max-over-ranks on a CUDA tensor; nothing of the data path changes)")
     ap.add_argument("--devices", type=str, default="",
                     help="rank -> device map, e.g. '0,0' (default: device = LOCAL_RANK)")
     args = ap.parse_args()
@@ -246,7 +265,7 @@ def main():
     selftest = args.selftest_cpu
     backend = "gloo" if selftest else args.dist_backend
     devices = [int(x) for x in args.devices.split(",")] if args.devices else None
-    rank, local_rank, world, dist = init_dist(backend, devices)  # local_rank: this rank's DEVICE from here on
+    rank, local_rank, world, dist = init_dist(backend, devices, args.force_process_group)  # local_rank: this rank's DEVICE from here on
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
@@ -314,6 +333,13 @@ def main():
     # that code objects are loaded, allocations are settled and the GPU has left its idle clock state (a
     # fresh process starts at the idle shader clock and the W = 5 steps the driver asks for last 0.4 ms).
     # A controller runs for minutes at 50 Hz; the steady state is the quantity of interest.  Reported below.
+    # Before any of that, the contract read literally: W warm-up steps on the fresh process, then the K timed steps --
+    # reported as the extra key "cold" beside the primed figure (the first solves of a process run at the idle shader clock).
+    cold_s = None
+    if cuda and args.prime_ms > 0:
+        run_steps(args.warmup)
+        cold_s = timed_block()
+        local_s.clear()
     t_prime, n_prime = time.perf_counter(), 0
     while cuda and 1e3 * (time.perf_counter() - t_prime) < args.prime_ms:
         run_steps(20)
@@ -393,13 +419,17 @@ def main():
                        "host_affinity": affinity if cuda else "unchanged",
                        "priming": "%d untimed solves (%.0f ms) before the %d warm-up steps" % (n_prime, args.prime_ms, args.warmup),
                        "parallelism": "replicas x%d (no collective)" % world,
-                       "process_group": backend if world > 1 else "none"},
+                       "process_group": backend if dist is not None else "none"},
             "state_updates_per_s": value * T,
             "repeats": len(block_s),
             "median_ms_per_step": 1e3 * float(np.median(block_s)) / args.steps,
             "min_ms_per_step": 1e3 * min(block_s) / args.steps,
             "max_ms_per_step": 1e3 * max(block_s) / args.steps,
             "median_value": K * iters * args.steps * world / float(np.median(block_s)),
+            "cold": None if cold_s is None else {
+                "ms_per_step": 1e3 * cold_s / args.steps, "value": K * iters * args.steps * world / cold_s,
+                "note": "the same %d timed steps straight after %d warm-up steps on the fresh process, before the priming pass "
+                        "(barrier + synchronize on both sides, max over ranks): the contract read literally" % (args.steps, args.warmup)},
             "per_solve_ms": per_solve_ms,
             "sustained": sustained,
             "instances": instances,
@@ -422,12 +452,15 @@ def main():
                 out["stage_ms"]["note"] += ("; noise_ms = the stand-alone generator kernel's launch (its own begin / end events): in the "
                                             "prefetching forms it runs on a second stream BESIDE the rollout or the tail of the same "
                                             "solve, so noise + rollout + tail is more than the step")
-            traffic, traffic_file = measured_traffic(cfg, variant)
+            traffic, traffic_note = measured_traffic(cfg, variant)
+            # which ceiling: the matrix-instruction forms against the dense f32 MFMA peak; the row forms issue no MFMA and are
+            # bound by the LATENCY of one wave's dependent vector multiply-add chain (peak kept: f32 vector = f32 MFMA peak);
+            # the throughput-style vector kernels and the basis-function model against the f32 vector peak
+            bound = "valu-latency" if "row8w" in variant else ("mfma" if variant.startswith("mfma") else "valu")
             out["roofline"] = {
-                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "bound": bound, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_unit": ("HBM bytes per launch (rocprofv3 PMC passes, %s)" % traffic_file) if traffic_file else
-                                "null: no committed PMC pass (tools/prof_run.sh -> profiles/) for this workload and kernel form",
+                "traffic_unit": traffic_note,
                 "kernel": "rollout (%s)" % variant, "kernel_ms": rollout_s * 1e3,
                 "flop_per_state_update": fl, "state_updates_per_launch": K * T,
                 "algorithmic_bytes_per_launch": bpu * K * T,
@@ -441,15 +474,21 @@ def main():
                 # wavefront alone on a SIMD (tools/ub/row_bcast_ub.hip, profiles/r03_j_row_bcast_ub.txt: the activations handed
                 # round by DPP, 70 dependent v_pk_fma_f32 at ~9 cycles + two tanh = 865 cycles; with the per-step bookkeeping of
                 # the product's dynamics wave -- record, sequence word, next controls, progress test -- 1 024).
-                clk_ghz = 2.3
+                clk_ghz = 2.3  # ASSUMED: the clock the chip held under this kernel when the stamps were taken (in-kernel
+                # s_memtime cycles x T against the rocprofv3 duration); not measured in this run
                 cyc = rollout_s / T * clk_ghz * 1e9
+                tree = "tree" in variant
+                # the k-ascending chain of the exact form: 70 dependent v_pk_fma_f32 + two tanh = 865 cycles alone on a SIMD; the
+                # tree form replaces the output layer's 32 links by 2 packed products + a 4-deep butterfly: 6 + 32 links, two
+                # tanh, the butterfly (profiles/r03_j_row_bcast_ub.txt and DESIGN.md 4.2c)
+                floor = 865.0 - 32 * 9.0 + 60.0 if tree else 865.0
                 out["roofline"]["pipe"] = "vector ALU (v_pk_fma_f32), no MFMA issued; f32 vector peak = f32 MFMA peak"
                 out["roofline"]["recurrence"] = {
-                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": 865.0, "frac_of_floor": 865.0 / cyc if cyc > 0 else 0.0,
-                    "with_bookkeeping_cycles_per_step": 1024.0,
-                    "clock_GHz": clk_ghz,
+                    "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": floor, "frac_of_floor": floor / cyc if cyc > 0 else 0.0,
+                    "clock_GHz_assumed": clk_ghz,
                     "note": "event-measured kernel time / T (launch, prologue and riders included) against one dynamics wavefront's "
-                            "recurrence measured alone on a SIMD (tools/ub/row_bcast_ub.hip, form A / form Q0)"}
+                            "recurrence alone on a SIMD (tools/ub/row_bcast_ub.hip: 865 cycles for the exact chain; tree form: that "
+                            "minus 32 links of ~9 cycles plus ~60 for two packed products and the butterfly)"}
             if "quad" in variant and cfg.get("bf_W") is None:
                 # The configuration is latency bound (one 16-rollout group per CU, T sequential steps), so next
                 # to the throughput roofline: the step time of the recurrence against (a) what its two dynamics

@@ -46,18 +46,28 @@ def load_nn_golden(golden_dir):
     return g
 
 
-COST_RTOL = 3e-6  # a-priori relative tolerance of a rollout cost away from the discontinuities (tanh / sincos / atan forms)
+COST_RTOL = 3e-6   # a-priori relative tolerance of a rollout cost away from the discontinuities (tanh / sincos / atan forms)
+GRAY_RTOL = 1e-5   # beyond this (and up to the 1e-4 "flipped" mark) a cost difference is a threshold flip of SMALL effect
 
 
 def first_order_bound(gamma, w_norm, dJ, costs_ref, flipped, V_ref, U_ref):
     """|dU| a softmax-weighted mean can move, to first order, when the costs move by dJ: dw_k / w_k = -gamma (dJ_k - sum_j w_j
     dJ_j), hence |dU| <= 2 gamma sum_k w_k |dJ_k| max_k |V_k - U|.  Large costs x gamma make this exceed the 2e-4 of a clean
-    draw although every cost agrees to the last digits.  |dJ_k| is the MEASURED difference but never more than COST_RTOL |J_k|:
-    the bound does not widen with the device's error beyond the a-priori tolerance (rollouts beyond 1e-4 are accounted for by
-    their weight mass instead)."""
+    draw although every cost agrees to the last digits.  Three classes of rollouts:
+      * relative difference <= GRAY_RTOL: smooth arithmetic -- |dJ_k| is the MEASURED difference but never more than
+        COST_RTOL |J_k|, so the bound does not widen with the device's error beyond the a-priori tolerance;
+      * GRAY_RTOL < relative difference <= 1e-4 ("gray"): a nearest-texel / crash / slip threshold flipped on ONE or a few
+        steps of a rollout whose cost is large (crashed rollouts: ~1e3), so the flip stays under the 1e-4 mark of a "flipped"
+        rollout although it is one (sweep seeds 201853: 1.5e-5 of 2 262 on a rollout with 1.8 % of the weight; 209729: 5e-5 of
+        240 on the rollout with 38 %) -- entered with its measured |dJ_k|; callers limit how many there may be;
+      * beyond 1e-4: accounted for by their weight mass (not here).
+    Returns (bound, number of gray rollouts)."""
     keep = ~flipped
-    d = np.minimum(np.abs(dJ), COST_RTOL * np.maximum(np.abs(costs_ref.astype(np.float64)), 1.0))
-    return 2.0 * float(gamma) * float(np.sum(w_norm[keep] * d[keep])) * float(np.max(np.abs(V_ref - U_ref[None])))
+    ref = np.maximum(np.abs(costs_ref.astype(np.float64)), 1.0)
+    a = np.abs(dJ)
+    gray = keep & (a > GRAY_RTOL * ref)
+    d = np.where(gray, a, np.minimum(a, COST_RTOL * ref))
+    return 2.0 * float(gamma) * float(np.sum(w_norm[keep] * d[keep])) * float(np.max(np.abs(V_ref - U_ref[None]))), int(gray.sum())
 
 
 def solve_with_iterations(cfg, variant, U0, hist, eps):
@@ -100,12 +110,13 @@ def teacher_forced_iterations(cfg, got, its, U0, hist, eps, fma_mode=1, nthreads
         fl = err > 1e-4
         wn, wgn = w_o / w_o.sum(), w_g / w_g.sum()
         dJ = np.abs(its["costs"][i].astype(np.float64) - costs_o.astype(np.float64))
+        fo, n_gray = first_order_bound(cfg["gamma"], wn, dJ, costs_o, fl, V_o, U_o)
         m = {"V_equal": bool(np.array_equal(its["V"][i].view(np.uint32), V_o.view(np.uint32))),
              "flipped": float(np.mean(fl)), "n_flipped": int(fl.sum()),
              "mass": float(np.sum(np.maximum(wn, wgn)[fl])),
              "dU": float(np.max(np.abs(its["U_raw"][i] - U_o))),
-             "first_order": first_order_bound(cfg["gamma"], wn, dJ, costs_o, fl, V_o, U_o),
-             "eta": float(eta), "p99": float(np.percentile(err, 99)), "median_cost": float(np.median(costs_o))}
+             "first_order": fo, "n_gray": n_gray,
+             "K": int(cfg["K"]), "eta": float(eta), "p99": float(np.percentile(err, 99)), "median_cost": float(np.median(costs_o))}
         if i == iters - 1:
             m["dU_smoothed"] = float(np.max(np.abs(got["U"] - orc.savgol(U_o, hist))))
             m["d_traj_cost"] = abs(got["traj_cost"] - tc) / max(abs(tc), 1e-3)
@@ -116,4 +127,5 @@ def teacher_forced_iterations(cfg, got, its, U0, hist, eps, fma_mode=1, nthreads
 def iteration_ok(m, with_first_order=True):
     """The single-iteration criterion of tests/test_fuzz_gpu.py on one teacher-forced iteration."""
     bound = 2e-4 + 4.0 * m["mass"] + (m["first_order"] if with_first_order else 0.0)
-    return m["V_equal"] and m["flipped"] <= 0.03 and m["dU"] <= bound and m.get("dU_smoothed", 0.0) <= bound
+    return m["V_equal"] and m["flipped"] <= 0.03 and m["dU"] <= bound and m.get("dU_smoothed", 0.0) <= bound and \
+        (not with_first_order or m["n_gray"] <= max(2, int(m["K"]) // 200))

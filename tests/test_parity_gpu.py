@@ -32,11 +32,13 @@ def _built():
 
 
 def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
+    """HIP solve and the oracle on the same inputs.  The oracle runs in the arithmetic mode of the kernel form that served
+    the solve: mode 1 (the reference's summation order) for every form but the row-tree form, whose output layer is summed as
+    a butterfly (mode 2) -- for that form the NOMINAL oracle's U / trajectory cost / costs come along as ref["nominal"] and
+    every caller's north-star criteria are checked against them here."""
     eps = noise_for(cfg, seed)
-    orc = O.Oracle(cfg, fma_mode=1, nthreads=8)
     U0 = np.zeros((cfg["T"], 2), np.float32) if U0 is None else U0
     hist = np.zeros(4, np.float32) if hist is None else hist
-    ref = orc.compute_control(cfg["start_state"], U0, hist, eps, num_iters=cfg.get("num_iters", 1))
     sol = capi.Solver(cfg)
     if variant:
         sol.set_rollout_variant(variant)
@@ -48,6 +50,16 @@ def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
     got["V"] = sol.get_applied_controls()
     got["variant"] = sol.rollout_variant()
     sol.close()
+    tree = "_tree" in got["variant"]
+    iters = cfg.get("num_iters", 1)
+    ref = O.Oracle(cfg, fma_mode=2 if tree else 1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
+    if tree:
+        nom = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
+        ref["nominal"] = nom
+        if iters == 1:  # north star: controls and trajectory cost within 1e-4 of the reference's own summation order
+            assert np.max(np.abs(got["U"] - nom["U"])) <= 1e-4
+            assert abs(got["traj_cost"] - nom["traj_cost"]) <= 1e-4 * abs(nom["traj_cost"])
+            assert int(np.sum(rel_err(got["costs"], nom["costs"]) > 1e-4)) <= max(cfg["K"] // 200, 1)
     return ref, got
 
 

@@ -5,8 +5,9 @@ ITERATION, teacher-forced: the oracle's iteration i is started from the HIP path
 (mppi_debug_capture_iterations; tests/helpers.py), so every iteration is a comparison on identical inputs:
 applied controls bit-exact, flipped rollouts <= 3 %, |dU| <= 2e-4 + 4 x (weight mass of the flipped rollouts).
 An iteration outside that is then classified, in this order:
-  conditioned      inside the first-order bound of its own cost differences, each capped at the a-priori 3e-6 relative
-                   (large costs x gamma: last-digit cost differences move the softmax);
+  conditioned      inside the first-order bound of its own cost differences (tests/helpers.py: first_order_bound): each capped
+                   at the a-priori 3e-6 relative (large costs x gamma: last-digit cost differences move the softmax), except
+                   at most max(2, K/200) "gray-zone" rollouts -- threshold flips of small effect, 1e-5 < relative <= 1e-4;
   granularity      more than 3 % flipped but no more than 4 rollouts (K = 64, 128), controls inside the bound;
   ill-conditioned  the oracle's own two arithmetic modes (fmaf where nvcc contracts / none), teacher-forced the same way,
                    differ from each other by more than the HIP path differs from the nearer one;
@@ -34,6 +35,12 @@ worst_clean, worst_any, forms = 0.0, 0.0, {}
 for seed in range(lo, hi):
     if seed % 500 == 0:
         print("# at seed %d: %d draws, %d BAD" % (seed, n_draws, bad), file=sys.stderr, flush=True)
+    if only_row:  # the first three draws of F._draw decide whether the row form serves this seed: skip the rest cheaply
+        r = np.random.RandomState(seed)
+        K_ = 64 * int(r.choice([1, 2, 3, 5, 8, 16, 17, 32, 64, 65, 100]))
+        r.choice([2, 3, 5, 9, 16, 20, 33, 47, 60, 100])
+        if F.LAYERS[r.randint(len(F.LAYERS))] is not None or K_ > 4096:
+            continue
     cfg, variant, hist = F._draw(gd, seed)
     if only_row:
         if cfg.get("bf_W") is not None or list(cfg["layers"]) != [6, 32, 32, 4] or cfg["K"] > 4096:
@@ -58,11 +65,13 @@ for seed in range(lo, hi):
             continue
         head = "seed %d K=%d T=%d %s iteration %d of %d (gamma %g, eta %.3f, median cost %.0f)" % (
             seed, cfg["K"], cfg["T"], name, i + 1, iters, cfg["gamma"], m["eta"], m["median_cost"])
-        if m["V_equal"] and m["flipped"] <= 0.03 and dU <= bound + m["first_order"]:
+        few_gray = m["n_gray"] <= max(2, cfg["K"] // 200)
+        if m["V_equal"] and m["flipped"] <= 0.03 and few_gray and dU <= bound + m["first_order"]:
             conditioned += 1
-            print("conditioned %s: dU=%.3e <= %.3e = 2e-4 + 4 x %.2e + first-order %.3e" % (head, dU, bound + m["first_order"], m["mass"], m["first_order"]), flush=True)
+            print("conditioned %s: dU=%.3e <= %.3e = 2e-4 + 4 x %.2e + first-order %.3e (%d gray-zone rollout(s))" % (
+                head, dU, bound + m["first_order"], m["mass"], m["first_order"], m["n_gray"]), flush=True)
             continue
-        if m["V_equal"] and m["n_flipped"] <= 4 and dU <= bound + m["first_order"]:
+        if m["V_equal"] and m["n_flipped"] <= 4 and few_gray and dU <= bound + m["first_order"]:
             granular += 1
             print("granularity %s: %d flipped rollouts = %.1f %% of K, dU=%.3e <= %.3e" % (head, m["n_flipped"], 100 * m["flipped"], dU, bound + m["first_order"]), flush=True)
             continue

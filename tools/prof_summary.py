@@ -64,6 +64,12 @@ def pmc(out, note, dirs):
         if "read_bytes_corrected" in e and "write_bytes" in e:
             e["traffic_bytes_per_launch"] = e["read_bytes_corrected"] + e["write_bytes"]
         res["kernels"][k] = e
+    try:  # the kernel sources this profile was taken on (bench.py refuses a traffic figure of other sources)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        res["kernel_sources_sha16"] = bench.kernel_sources_sha16()
+    except Exception as e:  # noqa: BLE001
+        res["kernel_sources_sha16"] = "unknown (%s)" % type(e).__name__
     bj = os.environ.get("PROF_BENCH_JSON")
     if bj and os.path.exists(bj):  # the bench line of the --stats pass of the same command: names the workload
         try:
