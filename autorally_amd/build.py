@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmppi_hip.so")
-SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_multi.hip", "rollout_oct.hip", "rollout_row.hip", "rollout_valu.hip", "solve_kernels.hip",
+SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_multi.hip", "rollout_oct.hip", "rollout_row.hip", "rollout_row64.hip", "rollout_valu.hip", "solve_kernels.hip",
            "noise_mrg32k3a.hip", "rollout_bf.hip", "ddp_feedback.cpp"]
 HEADERS = ["mppi_device.hpp", "mfma_net.hpp", "group_roles.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", "basis_funcs.hpp", "host_net.hpp", "tanhf_vec.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
@@ -26,7 +26,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # per-file additions: the row form's T loop is one wave's dependent chains with their operand moves in the shadow of the
 # multiply-adds; the scheduler's max-ILP strategy orders the bookkeeping around them better than the default
 # (same-box A/B: 0.0577 -> 0.0569 ms per step, the batched kernel unchanged; the other kernels keep the default)
-EXTRA_FLAGS = {"rollout_row.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+EXTRA_FLAGS = {"rollout_row.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               "rollout_row64.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def hipcc():

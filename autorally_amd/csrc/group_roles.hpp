@@ -6,6 +6,9 @@
 //
 // SH (the __shared__ struct of the kernel) provides
 //   static constexpr int NW, NSW;           dynamics waves of the group; swaps they publish per step
+//   static constexpr int kR;                rollouts of the group: 16, or 8 (rollout_row64.hip at K <= 8 x #CUs) -- the riders keep
+//                                           their 16-rollout lane layouts; slots j >= kR repeat rollout j - kR (the same values
+//                                           to the same LDS addresses) and are masked where a wave touches global memory
 //   int   xseq[NW][64];                     swaps published by dynamics wave w (word 0 is read)
 //   float rec[kGRing][16][4];               s3..s6 before the update of step t (written by dynamics wave 0
 //                                           BEFORE it publishes the first swap of step t)
@@ -35,8 +38,14 @@ template <class SH>
 struct GroupRoles {
   static constexpr int kPose = SH::NW, kCost = SH::NW + 1, kCtl = SH::NW + 2, kRng = SH::NW + 3;
   static constexpr int kWaves = SH::NW + 4;
-  static_assert(kWaves <= 8, "fin[8]");
+  static_assert(kWaves <= (int)(sizeof(SH::fin) / sizeof(int)), "fin[]");
+  static_assert(SH::kR == 16 || SH::kR == 8, "rollouts per group");
 };
+// rollout slot s of a rider's lane layout -> (rollout of the group, first rollout of the launch's numbering, is it real)
+template <class SH>
+__device__ __forceinline__ int group_j(int slot) { return slot & (SH::kR - 1); }
+template <class SH>
+__device__ __forceinline__ bool group_real(int slot) { return slot < SH::kR; }
 
 template <class SH>
 __device__ __forceinline__ int group_seq_min(SH &sh)
@@ -70,11 +79,12 @@ __device__ __forceinline__ uint32_t fold_m(uint64_t x, uint32_t C, uint32_t m)
 // barrier: they are the head of a launch's critical path (words -> first draws -> Box-Muller -> first controls -> the dynamics
 // waves start), and the barrier is a wait for the workgroup's last wave to arrive (row form: first controls 6 070 -> 5 170
 // cycles after the first instruction, rollout 47.4 -> 45.6 us)
+template <class SH>
 __device__ __forceinline__ MrgHalf group_rng_load(const RolloutArgs &a)
 {
   const int lane = threadIdx.x & 63;
-  const int j = (lane >> 1) & 15, c = lane & 1;
-  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
+  const int j = group_j<SH>((lane >> 1) & 15), c = lane & 1;
+  const int k = (int)blockIdx.x * SH::kR + j;
   const int K = a.K;
   MrgHalf g{0, 0, 0};
   if (a.inline_noise != 0 && lane < 2 * kRolloutsPerWave) {
@@ -88,10 +98,11 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh, con
 {
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
-  const int j = (lane >> 1) & 15, c = lane & 1;
-  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
+  const int j = group_j<SH>((lane >> 1) & 15), c = lane & 1;
+  const int k = (int)blockIdx.x * SH::kR + j;
   const int K = a.K, T = a.T;
   const bool active = lane < 2 * kRolloutsPerWave;
+  const bool real = lane < 2 * SH::kR;
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kRng + 1);
   if (a.inline_noise != 0) {
     // p = (A sX - Bn s0) mod m: component 1 = (a12 s11 - a13n s10) mod m1, component 2 = (a21 s22 - a23n s20) mod m2
@@ -131,7 +142,7 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh, con
       if (active && c == 0) *reinterpret_cast<float2 *>(&sh.eps[t & (kGRing - 1)][j][0]) = e;
       lds_publish(a_mypub, t + 1);
     }
-    if (active) {
+    if (real) {
       a.rng_out[(3 * c) * K + k] = g.s0; a.rng_out[(3 * c + 1) * K + k] = g.s1; a.rng_out[(3 * c + 2) * K + k] = g.s2;
     }
   }
@@ -151,8 +162,9 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
   constexpr int NSW = SH::NSW;
   static_assert(kGCtlChunk == 4 && kGRing >= 2 * kGCtlChunk, "four steps per iteration, lanes 16 q + j");
   const int lane = threadIdx.x & 63;
-  const int j = lane & 15, q = lane >> 4;
-  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
+  const int j = group_j<SH>(lane & 15), q = lane >> 4;
+  const bool real = group_real<SH>(lane & 15);
+  const int k = (int)blockIdx.x * SH::kR + j;
   const int K = a.K, T = a.T;
   const bool inl = a.inline_noise != 0;
   float2 *const noise = reinterpret_cast<float2 *>(a.noise);
@@ -201,7 +213,7 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
       const float du0 = nf ? 0.0f : n0, du1 = nf ? 0.0f : n1;
       float u0 = nf ? Ut.x : (pure_noise_k ? n0 : Ut.x + n0);
       float u1 = nf ? Ut.y : (pure_noise_k ? n1 : Ut.y + n1);
-      noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
+      if (real) noise[(size_t)t * K + k] = make_float2(u0, u1);  // before the clamp (Q3)
       u0 = clampf(u0, a.u_lo[0], a.u_hi[0]);
       u1 = clampf(u1, a.u_lo[1], a.u_hi[1]);
       const int slot = t & (kGRing - 1);
@@ -224,6 +236,7 @@ __device__ __forceinline__ void group_pose_wave(const RolloutArgs &a, SH &sh)
 {
   using R = GroupRoles<SH>;
   constexpr int NSW = SH::NSW;
+  static_assert(SH::kR == 16, "one step per iteration: 16-rollout groups only");
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
   const int T = a.T;
@@ -301,7 +314,7 @@ __device__ __forceinline__ void group_pose_wave4(const RolloutArgs &a, SH &sh)
   constexpr int NSW = SH::NSW;
   static_assert(kRolloutsPerWave == 16 && kGRing >= 8, "lane = 4 j + q");
   const int lane = threadIdx.x & 63;
-  const int j = lane >> 2, q = lane & 3;
+  const int j = group_j<SH>(lane >> 2), q = lane & 3;
   const int T = a.T;
   const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]);
   const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
@@ -372,6 +385,7 @@ __device__ __forceinline__ void group_cost_wave(const RolloutArgs &a, SH &sh)
 {
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
+  static_assert(SH::kR == 16, "one step per iteration: 16-rollout groups only");
   const int j = lane & 15;
   const int k = (int)blockIdx.x * kRolloutsPerWave + j;
   const int T = a.T;
@@ -427,8 +441,8 @@ __device__ __forceinline__ void group_cost_wave4(const RolloutArgs &a, SH &sh)
 {
   using R = GroupRoles<SH>;
   const int lane = threadIdx.x & 63;
-  const int j = lane >> 2, q = lane & 3;
-  const int k = (int)blockIdx.x * kRolloutsPerWave + j;
+  const int j = group_j<SH>(lane >> 2), q = lane & 3;
+  const int k = (int)blockIdx.x * SH::kR + j;
   const int T = a.T;
   const uint32_t a_mydone = lds_addr(&sh.cost_done[lane]);
   const uint32_t a_pose = lds_addr(&sh.pose_pub[0]);
@@ -477,7 +491,7 @@ __device__ __forceinline__ void group_cost_wave4(const RolloutArgs &a, SH &sh)
     }
   }
   J = group_settle(sh, budget, J);
-  if (q == 0) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
+  if (q == 0 && group_real<SH>(lane >> 2)) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
 }
 
 }  // namespace mppi

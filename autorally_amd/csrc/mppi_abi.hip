@@ -143,6 +143,7 @@ struct mppi_handle {
   float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
   float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
   float *d_rowpack = nullptr;  // 6-32-32-4: the weights in the register order of the row form (rollout_row.hip)
+  float *d_row64pack = nullptr;  // 64-wide nets: register + LDS image of rollout_row64.hip
   bool valu_reg_ok = false;
   double *d_invt = nullptr;
   uint32_t *d_rng[2] = {nullptr, nullptr};
@@ -406,6 +407,57 @@ std::vector<float> pack_row_weights(const std::vector<float> &theta)
   return out;
 }
 
+// Image of the 64-wide row form (rollout_row64.hip: row64_load + the LDS part): lane g of a 32-lane rollout owns neurons
+// 2g, 2g+1 of every hidden layer; register entry i of lane g at float4 index i * 32 + g, then the 64 x 64 layers as
+// [layer][k][g] pairs.  Hidden biases times kTanhScale.  Output layer in the order of row64_out_tree: Q = outputs {0, 1},
+// P = outputs {2, 3}, inside each the output the lane keeps at the row_ror:8 level (bit 3 of g) first.
+std::vector<float> pack_row64_weights(const std::vector<float> &theta, int NHID)
+{
+  const int H = 64, NB = (NHID + 1) / 2, NE = 3 + NB + 3;
+  std::vector<float> out((size_t)row64_pack_floats(NHID), 0.0f);
+  std::vector<const float *> Wl(NHID + 1), Bl(NHID + 1);
+  {
+    const float *p = theta.data();
+    int prev = kNetIn;
+    for (int l = 0; l <= NHID; l++) {
+      const int no = (l < NHID) ? H : kNetOut;
+      Wl[l] = p;
+      Bl[l] = p + (size_t)no * prev;
+      p += (size_t)no * prev + no;
+      prev = no;
+    }
+  }
+  for (int g = 0; g < 32; g++) {
+    const int j0 = 2 * g, j1 = 2 * g + 1;
+    auto entry = [&](int i) { return &out[((size_t)i * 32 + g) * 4]; };
+    for (int i = 0; i < 3; i++) {
+      float *e = entry(i);
+      e[0] = Wl[0][j0 * kNetIn + 2 * i]; e[1] = Wl[0][j1 * kNetIn + 2 * i];
+      e[2] = Wl[0][j0 * kNetIn + 2 * i + 1]; e[3] = Wl[0][j1 * kNetIn + 2 * i + 1];
+    }
+    for (int l = 0; l < NHID; l++) {
+      float *e = entry(3 + l / 2) + 2 * (l & 1);
+      e[0] = Bl[l][j0] * kTanhScale; e[1] = Bl[l][j1] * kTanhScale;
+    }
+    const int row = g >> 4, b3 = (g >> 3) & 1;
+    const int qa = b3, qb = 1 - b3, pa = 2 + b3, pb = 3 - b3;
+    const float *W3 = Wl[NHID];
+    float *q = entry(3 + NB), *pp = entry(4 + NB), *c = entry(5 + NB);
+    q[0] = W3[qa * H + j0]; q[1] = W3[qb * H + j0]; q[2] = W3[qa * H + j1]; q[3] = W3[qb * H + j1];
+    pp[0] = W3[pa * H + j0]; pp[1] = W3[pb * H + j0]; pp[2] = W3[pa * H + j1]; pp[3] = W3[pb * H + j1];
+    c[0] = Bl[NHID][2 * row + b3];
+  }
+  float *lds = out.data() + (size_t)NE * 32 * 4;
+  for (int l = 1; l < NHID; l++)
+    for (int k = 0; k < H; k++)
+      for (int g = 0; g < 32; g++) {
+        float *e = lds + (((size_t)(l - 1) * H + k) * 32 + g) * 2;
+        e[0] = Wl[l][(2 * g) * H + k];
+        e[1] = Wl[l][(2 * g + 1) * H + k];
+      }
+  return out;
+}
+
 bool use_mfma(const mppi_handle *h)
 {
   if (h->basis || h->variant_pref == 2 || h->variant_pref == 3) return false;
@@ -436,6 +488,7 @@ bool use_valu_reg(const mppi_handle *h) { return !h->basis && !use_mfma(h) && h-
 // whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD on paper (K = 16384) --
 // sometimes two on one SIMD and none on its neighbour, which doubles the kernel time
 // (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us).
+inline bool is_row64(int b) { return b == 908 || b == 916; }  // rollout_row64.hip, 8 / 16 rollouts per group
 inline bool is_row(int b) { return b == 900 || b == 901; }  // 901: the tree form of the output layer (rollout_row.hip)
 int effective_block(const mppi_handle *h)
 {
@@ -488,7 +541,7 @@ bool has_noise_wave(const mppi_handle *h)
   if (h->basis) return bf_waves(h) == 3;
   if (!use_mfma(h)) return false;
   const int b = effective_block(h);
-  return b == 512 || is_row(b) || ((b == 800 || b > 1000) && !multi_gen(h));
+  return b == 512 || is_row(b) || is_row64(b) || ((b == 800 || b > 1000) && !multi_gen(h));
 }
 
 void fill_cost_args(const mppi_handle *h, CostArgs &c)
@@ -527,7 +580,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.U = h->d_in;
   a.noise = noise;
   a.costs = h->d_costs;
-  a.wpack = use_mfma(h) ? (is_row(effective_block(h)) ? h->d_rowpack : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
+  a.wpack = use_mfma(h) ? (is_row(effective_block(h)) ? h->d_rowpack : is_row64(effective_block(h)) ? h->d_row64pack : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
   a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
@@ -555,6 +608,7 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
                  : (use_mfma(h) && effective_block(h) > 1000)
                      ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
                  : (use_mfma(h) && effective_block(h) == 800) ? launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream)
+                 : (use_mfma(h) && is_row64(effective_block(h))) ? launch_rollout_row64(h->hidden, h->n_hidden, a, effective_block(h) - 900, h->stream)
                  : (use_mfma(h) && is_row(effective_block(h))) ? launch_rollout_row(h->hidden, h->n_hidden, a, effective_block(h) == 901, h->stream)
                  : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
                  : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
@@ -932,7 +986,7 @@ void free_all(mppi_handle *h)
 {
   if (!h) return;
   float *fp[] = {h->d_theta_s, h->d_in_buf[0], h->d_in_buf[1], h->d_scal, h->d_noise, h->d_stage, h->d_costs,
-                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part, h->d_rowpack, h->d_cap};
+                 h->d_w, h->d_theta, h->d_wpack, h->d_map, h->d_part, h->d_rowpack, h->d_row64pack, h->d_cap};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
@@ -1091,6 +1145,8 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   if (h->mfma_ok)
     CR(hipMalloc(&h->d_wpack, sizeof(float) * 64 * (size_t)mfma_pack_floats_per_lane(h->hidden, h->n_hidden)));
   if (h->mfma_ok && row_variant_supported(h->hidden, h->n_hidden)) CR(hipMalloc(&h->d_rowpack, sizeof(float) * (size_t)row_pack_floats()));
+  if (h->mfma_ok && row64_variant_supported(h->hidden, h->n_hidden))
+    CR(hipMalloc(&h->d_row64pack, sizeof(float) * (size_t)row64_pack_floats(h->n_hidden)));
   CR(hipMalloc(&h->d_rng[0], sizeof(uint32_t) * 6 * h->K));
   CR(hipMalloc(&h->d_rng[1], sizeof(uint32_t) * 6 * h->K));
   CR(hipMalloc(&h->d_jump, sizeof(uint32_t) * 18 * h->noise_C));
@@ -1181,6 +1237,10 @@ int mppi_set_nn_params(mppi_handle *h, const float *theta, size_t n)
   if (h->d_rowpack) {
     const std::vector<float> pk = pack_row_weights(h->theta);
     HIPCHK(h, hipMemcpy(h->d_rowpack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (h->d_row64pack) {
+    const std::vector<float> pk = pack_row64_weights(h->theta, h->n_hidden);
+    HIPCHK(h, hipMemcpy(h->d_row64pack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   h->have_nn = true;
   return MPPI_OK;
@@ -1928,6 +1988,8 @@ const char *mppi_rollout_variant(const mppi_handle *h)
              multi_gen(h) ? "_gen" : "");
   else if (is_row(b))
     snprintf(buf, sizeof(buf), "valu_row8w%s_h%d_l%d", b == 901 ? "_tree" : "", h->hidden, h->n_hidden);
+  else if (is_row64(b))
+    snprintf(buf, sizeof(buf), "valu_row64_r%d_tree_h%d_l%d", b - 900, h->hidden, h->n_hidden);
   else
     snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_%s", h->hidden, h->n_hidden,
              b == 512 ? "quad4w" : b == 800 ? (multi_gen(h) ? "oct8w_gen" : "oct8w") : (b == 256 ? "fused_b256" : "fused_b64"));
@@ -1955,6 +2017,13 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     if (!h->mfma_ok || !row_variant_supported(h->hidden, h->n_hidden))
       return fail(h, MPPI_ERR_UNSUPPORTED, "row form exists for 6-32x2-4");
     h->block_threads = strcmp(name, "row_tree") == 0 ? 901 : 900;
+  }
+  else if (strcmp(name, "row64") == 0 || strcmp(name, "row64_r8") == 0 || strcmp(name, "row64_r16") == 0) {
+    if (!h->mfma_ok || !row64_variant_supported(h->hidden, h->n_hidden))
+      return fail(h, MPPI_ERR_UNSUPPORTED, "row64 form exists for 6-64x2-4 and 6-64x4-4");
+    // 8 rollouts per group (one dynamics wave per SIMD) while every such group has a CU of its own, else 16
+    const int r = name[5] == 0 ? ((h->K / 8 <= h->num_simds / 4) ? 8 : 16) : (name[7] == '8' ? 8 : 16);
+    h->block_threads = 900 + r;
   }
   else if (strcmp(name, "oct") == 0 || strcmp(name, "oct_gen") == 0) {
     if (!h->mfma_ok || !oct_variant_supported(h->hidden, h->n_hidden))
@@ -2047,7 +2116,7 @@ int mppi_set_wait_timeout(mppi_handle *h, double seconds)
  * it is -- turns into MPPI_ERR_HIP and not into finite, wrong costs. */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget)
 {
-  if (!h || wave < 0 || wave > 8 || spin_budget < 0) return MPPI_ERR_INVALID;
+  if (!h || wave < 0 || wave > 12 || spin_budget < 0) return MPPI_ERR_INVALID;
   h->fault_wave = wave;
   h->spin_budget = spin_budget;
   return MPPI_OK;

@@ -49,6 +49,13 @@ int row_pack_floats();
 hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, bool tree, hipStream_t stream);
 hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, bool tree, hipStream_t stream);  // grid (groups, instances)
 
+// rollout_row64.hip: latency form of 64-wide nets on the vector ALU -- r / 2 dynamics waves (two rollouts of 32 lanes each) +
+// pose, cost, control and noise wave per r = 8 or 16 rollouts; hidden layers' weights from LDS, output layer as a butterfly
+// (NOT the reference's summation order: opt-in by tolerance); a.wpack = pack_row64_weights (mppi_abi.hip)
+bool row64_variant_supported(int hidden, int n_hidden);
+int row64_pack_floats(int n_hidden);
+hipError_t launch_rollout_row64(int hidden, int n_hidden, const RolloutArgs &a, int r, hipStream_t stream);
+
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {
   int n_layers;

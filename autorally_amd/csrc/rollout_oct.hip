@@ -30,6 +30,7 @@ template <int H, int NHID>
 struct OctShared {
   static constexpr int NW = 4;
   static constexpr int NSW = NHID;  // swaps per step: layer 0 and the NHID-1 hidden -> hidden layers
+  static constexpr int kR = 16;           // rollouts per group
   static constexpr bool kRecByAll = false;  // dynamics wave 0 writes the state records (all four hold the state)
   float xb[2][NW][64][4];                   // [swap parity][wave][lane][.]: a wave's tile of activations
   int xseq[NW][64];                         // swaps published by dynamics wave w

@@ -47,6 +47,7 @@ struct RowShared {
   static constexpr int NW = 4;            // dynamics waves per group, four rollouts each
   static constexpr int NSW = 1;           // xseq[w] = steps published by dynamics wave w
   static constexpr bool kRecByAll = true; // every dynamics wave writes the state records of its own rollouts
+  static constexpr int kR = 16;           // rollouts per group
   int xseq[NW][64];
   float rec[kGRing][kRolloutsPerWave][4];   // s3..s6 before the update of step t; also the layer-0 input of that step
   int cost_done[64];
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (role == 0) RSTAMP(0);  // first instruction
   MrgHalf g0{0, 0, 0};
-  if (role == R::kRng) g0 = group_rng_load(a);  // in front of the barrier: the head of the launch's critical path
+  if (role == R::kRng) g0 = group_rng_load<SH>(a);  // in front of the barrier: the head of the launch's critical path
   if (role == 0) {  // sequence words start at 0; the only barrier
 #pragma unroll
     for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
   const RolloutArgs a = b.inst[i];
   if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;  // a smaller instance than the largest of the batch
   MrgHalf g0{0, 0, 0};
-  if (role == R::kRng) g0 = group_rng_load(a);  // in front of the barrier (with the copy above: 47.7 -> 46.3 us)
+  if (role == R::kRng) g0 = group_rng_load<SH>(a);  // in front of the barrier (with the copy above: 47.7 -> 46.3 us)
   if (role == 0) {
 #pragma unroll
     for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;

@@ -53,26 +53,28 @@ int orc_num_params(const int *layers, int n_layers)
   return n;
 }
 
-/* fma_mode 2 ("tree"): the OUTPUT layer's dot product in the summation order of the row-tree rollout kernel
- * (autorally_amd/csrc/rollout_row.hip, `row_tree`), everything else as fma_mode 1.  NOT the reference's order
- * (neural_net_model.cu:379-394 sums k ascending): the kernel form that uses it is held against the nominal
- * (fma_mode 1) oracle at the north-star tolerance and against THIS mode bit for bit.  The nin = 16 m inputs are
- * dealt to 16 lanes, lane p owning inputs m p .. m p + m - 1; a lane's partial is the ascending chain over its own
- * inputs (a product, then fused multiply-adds), and the 16 partials are summed by a fixed butterfly:
- *   L1[p] = P[p] + P[p^8];  L2[p] = L1[p] + L1[p^7];  L3[p] = L2[p] + L2[p^1];  sum = L3[0] + L3[2]
- * (IEEE addition is commutative, so every lane of the kernel's quad holds these bits). */
+/* fma_mode 2 ("tree"): the OUTPUT layer's dot product in the summation order of the row-tree rollout kernels
+ * (autorally_amd/csrc/rollout_row.hip `row_tree` for 32-wide nets, rollout_row64.hip for 64-wide ones), everything else as
+ * fma_mode 1.  NOT the reference's order (neural_net_model.cu:379-394 sums k ascending): the kernel forms that use it are
+ * held against the nominal (fma_mode 1) oracle at the north-star tolerance and against THIS mode bit for bit.  The nin = 2 n
+ * inputs (n = 16 or 32) are dealt to n lanes, lane p owning inputs 2p, 2p+1; a lane's partial is a product and a fused
+ * multiply-add, and the n partials are summed by a fixed butterfly:
+ *   n = 32 only: L0[p] = P[p] + P[p^16];
+ *   L1[p] = L0[p] + L0[p^8];  L2[p] = L1[p] + L1[p^7];  L3[p] = L2[p] + L2[p^1];  sum = L3[0] + L3[2]
+ * (IEEE addition is commutative, so every lane of the kernel that ends up with this output holds these bits). */
 static float out_tree_dot(const float *w, const float *a, int nin)
 {
-  const int m = nin / 16;
-  float P[16], L1[16], L2[16], L3[16];
-  for (int p = 0; p < 16; p++) {
-    float z = w[m * p] * a[m * p];
-    for (int i = 1; i < m; i++) z = fmaf(w[m * p + i], a[m * p + i], z);
-    P[p] = z;
+  const int n = nin / 2;
+  float P[32], L1[32], L2[32], L3[32];
+  for (int p = 0; p < n; p++) P[p] = fmaf(w[2 * p + 1], a[2 * p + 1], w[2 * p] * a[2 * p]);
+  if (n == 32) {
+    float L0[32];
+    for (int p = 0; p < 32; p++) L0[p] = P[p] + P[p ^ 16];
+    for (int p = 0; p < 32; p++) P[p] = L0[p];
   }
-  for (int p = 0; p < 16; p++) L1[p] = P[p] + P[p ^ 8];
-  for (int p = 0; p < 16; p++) L2[p] = L1[p] + L1[p ^ 7];
-  for (int p = 0; p < 16; p++) L3[p] = L2[p] + L2[p ^ 1];
+  for (int p = 0; p < n; p++) L1[p] = P[p] + P[p ^ 8];
+  for (int p = 0; p < n; p++) L2[p] = L1[p] + L1[p ^ 7];
+  for (int p = 0; p < n; p++) L3[p] = L2[p] + L2[p ^ 1];
   return L3[0] + L3[2];
 }
 
@@ -90,7 +92,7 @@ void orc_nn_forward(const float *theta, const int *layers, int n_layers, const f
     const float *b = theta + off + nout * nin; /* stride_idcs_[2l+1] (:131) */
     for (int j = 0; j < nout; j++) {
       float tmp = 0.0f;
-      if (fma_mode == 2 && l == n_layers - 2 && nin % 16 == 0) tmp = out_tree_dot(W + j * nin, cur, nin);
+      if (fma_mode == 2 && l == n_layers - 2 && (nin == 32 || nin == 64)) tmp = out_tree_dot(W + j * nin, cur, nin);
       else for (int k = 0; k < nin; k++) tmp = mac(W[j * nin + k], cur[k], tmp, fma_mode);
       tmp += b[j];
       if (l < n_layers - 2) tmp = tanhf(tmp); /* MPPI_NNET_NONLINEARITY, :35 */
