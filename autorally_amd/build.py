@@ -11,9 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmppi_hip.so")
-SOURCES = ["mppi_abi.hip", "rollout_mfma.hip", "rollout_multi.hip", "rollout_oct.hip", "rollout_row.hip", "rollout_row64.hip", "rollout_valu.hip", "solve_kernels.hip",
+SOURCES = ["mppi_abi.hip", "abi_forms.hip", "abi_pack.hip", "abi_solve.hip", "abi_host.hip", "rollout_mfma.hip", "rollout_multi.hip", "rollout_oct.hip", "rollout_row.hip", "rollout_row64.hip", "rollout_m44.hip", "rollout_valu.hip", "solve_kernels.hip",
            "noise_mrg32k3a.hip", "rollout_bf.hip", "ddp_feedback.cpp"]
-HEADERS = ["mppi_device.hpp", "mfma_net.hpp", "group_roles.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", "basis_funcs.hpp", "host_net.hpp", "tanhf_vec.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
+HEADERS = ["abi_internal.hpp", "mppi_device.hpp", "mfma_net.hpp", "group_roles.hpp", "mppi_kernels.hpp", "noise_device.hpp", "ddp_feedback.hpp", "basis_funcs.hpp", "host_net.hpp", "tanhf_vec.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
 # -ffp-contract=off: every FMA in the kernels is explicit (see csrc/mppi_device.hpp)
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file), which removes
 # the v_accvgpr_read per accumulator register after every layer

@@ -1,0 +1,218 @@
+// abi_internal.hpp -- what the files behind include/mppi_hip.h share: the handle, the kernel-form codes and the internal
+// functions of one another.  mppi_abi.hip: handle life cycle, setters, getters; abi_forms.hip: which kernel form runs
+// (selection table, names); abi_pack.hip: weight images and generator tables; abi_solve.hip: the solve pipeline (noise,
+// rollout + tail launches, result polling, batched solves); abi_host.hip: the host-side halves of a tick (nominal replays,
+// DDP feedback gains, the helper thread).
+#pragma once
+// mppi_abi.hip -- host side of libmppi_hip.so: the C ABI of include/mppi_hip.h.
+//
+// Owns one HIP stream and all device memory of a solver instance, enqueues one MPPI solve
+// (PI/mppi_controller.cu:600-671) as: [H2D U|hist] -> noise -> rollout -> weights -> weighted
+// reduction -> Savitzky-Golay -> [D2H scal|U], with ONE stream synchronisation per solve (the
+// reference has three plus five blocking parameter uploads).
+// There is no CPU fallback anywhere in this file: without a gfx950 device every compute entry
+// point returns an error.
+#include "../../include/mppi_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <string>
+#include <vector>
+
+#include "mppi_kernels.hpp"
+#include "ddp_feedback.hpp"
+#include "basis_funcs.hpp"
+#include "host_net.hpp"
+
+namespace mppi_abi {
+
+struct Events {
+  // e[0..3]: markers on the handle's stream before noise / before rollout / after rollout / after tail;
+  // e[4], e[5]: begin and end of the rollout kernel's own dispatch (hipExtLaunchKernelGGL, MPPI_LAUNCH_ROLLOUT)
+  hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+}  // namespace mppi_abi
+using mppi_abi::Events;
+
+
+struct mppi_handle {
+  using NetDesc = mppi::NetDesc;
+  using DdpResult = mppi::DdpResult;
+  using HostNetFma = mppi::HostNetFma;
+  mppi_config cfg{};
+  int K = 0, T = 0, k99 = 0;
+  float dt = 0.0f;
+  NetDesc net{};
+  bool mfma_ok = false;
+  int hidden = 0, n_hidden = 0;
+  int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
+  int block_threads = 0;    // 0: auto; 1040: multi form with ND = 4 and six waves (one cost wave); 512: quad (2 dynamics + cost + control waves per 16 rollouts); 800: oct (4 dynamics waves, one M tile of a
+                            // 64-wide net each, + pose, cost, control, noise wave); 64, 256: single-wave form;
+                            // 1000 + ND: multi form (ND dynamics waves of 16 rollouts + cost wave + control wave), ND = 1, 2, 4
+  bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
+  int num_simds = 1024;     // 4 per CU
+  hipStream_t stream = nullptr;
+  // The stream the handle's most recent device work went to: its own, or the device's batch stream after a
+  // batched solve (mppi_compute_control_batch).  nullptr: nothing outstanding anywhere but on `stream`.
+  hipStream_t order_stream = nullptr;
+  int n_slots = 1;  // explicit-noise slots in d_noise: one per iteration
+  bool u_dirty = true;          // host copy of U/hist differs from the device copy in d_in
+  unsigned seq = 0;             // sequence number of the last enqueued solve (last word of every h_res entry)
+  std::vector<float> sg_buf;    // scratch of the host-side Savitzky-Golay pass
+  bool basis = false;  // GeneralizedLinear basis-function dynamics (cfg.n_layers == 0); theta holds W[4][25]
+  // DDP feedback gains (row f2): weights of initDDP (mppi_controller.cu:410-417) and the last result
+  float ddp_Q[7] = {0.5f, 0.5f, 0.25f, 0.0f, 0.05f, 0.01f, 0.01f};
+  float ddp_R[2] = {10.0f, 10.0f};
+  float ddp_Qf[7] = {0, 0, 0, 0, 0, 0, 0};
+  DdpResult ddp;
+  bool have_ddp = false;
+  unsigned *d_counter = nullptr;  // [1 + T] arrival counters of the tail kernel
+  float *d_part = nullptr;        // [T][K/64][2] chain results of the tail kernel when K > 4096
+  float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
+
+  std::vector<float> U, hist, theta, map_rgba;
+  HostNetFma hnet;  // host twin of the network for computeNominalTraj (rebuilt with every mppi_set_nn_params)
+  int map_w = 0, map_h = 0;
+  mppi_cost_params cost{};
+  float r_c1[3] = {0, 0, 0}, r_c2[3] = {0, 0, 0}, trs[3] = {0, 0, 1};
+  float u_lo[2] = {0, 0}, u_hi[2] = {0, 0};
+  bool have_nn = false, have_map = false, have_cost = false;
+
+  float *d_in = nullptr, *d_scal = nullptr;
+  float *d_in_buf[2] = {nullptr, nullptr};  // d_in points at one of them; the tail kernel leaves the
+  int in_cur = 0;                            // stride-slid copy of [U | hist] in the other one
+  bool slid_valid = false;
+  float *d_noise = nullptr, *d_stage = nullptr;
+  // Generator-kernel forms: eps of a solve is drawn by the stand-alone kernel into one of two buffers, on a
+  // stream of its own (all generator launches, in order: the MRG32k3a states advance in launch order); the
+  // draws of the NEXT solve are requested as soon as this solve's rollout has been enqueued and start when
+  // that rollout ends, i.e. they overlap the weights / tail kernels, which leave the chip idle.
+  float *d_gen[2] = {nullptr, nullptr};
+  int gen_cur = 0;             // buffer of the most recent generator-mode solve (holds its applied controls V)
+  bool gen_async = false;      // K T >= 2^20: generator on its own stream, next solve's draws prefetched
+  bool prefetch_valid = false; // d_gen[1 - gen_cur] holds the next solve's draws (ev_gen marks their completion)
+  float *v_buf = nullptr;      // where the last solve's applied controls are
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_gen = nullptr, ev_s1 = nullptr;
+  // stage timing of the asynchronous generator: begin / end of the generator launch on gstream that was enqueued
+  // during a timed solve (it runs BESIDE that solve's rollout or tail: reported as noise_ms, not additive)
+  hipEvent_t ev_gt[2] = {nullptr, nullptr};
+  bool gen_timed = false, gen_time_now = false;
+  float *d_costs = nullptr, *d_w = nullptr;
+  float *d_theta = nullptr, *d_wpack = nullptr, *d_map = nullptr;
+  float *d_theta_s = nullptr;  // theta with hidden-layer biases * kTanhScale (register VALU kernel)
+  float *d_rowpack = nullptr;  // 6-32-32-4: the weights in the register order of the row form (rollout_row.hip)
+  float *d_row64pack = nullptr;  // 64-wide nets: register + LDS image of rollout_row64.hip
+  float *d_m44pack = nullptr;    // 64-wide nets: image of rollout_m44.hip
+  bool valu_reg_ok = false;
+  double *d_invt = nullptr;
+  uint32_t *d_rng[2] = {nullptr, nullptr};
+  uint32_t *d_jump = nullptr, *d_sub = nullptr, *d_one = nullptr;
+  int rng_cur = 0;
+  int noise_L = 1, noise_C = 1;
+  float *h_in = nullptr, *h_res = nullptr;
+  int explicit_iters = 0;  // >0: d_noise holds that many explicit iterations for the next solve
+  bool pending = false;       // a solve is enqueued, results not yet collected
+  bool pending_timed = false;
+  float traj_cost = 0.0f, baseline = 0.0f, eta = 0.0f;
+
+  int spin_budget = 0, fault_wave = 0;  // mppi_debug_inject_handover_fault (0, 0: kSpinBudget, no fault)
+  // mppi_debug_capture_iterations: [num_iters][2T + K] -- the raw weighted mean U and the costs after every iteration
+  float *d_cap = nullptr;
+  bool capture = false, cap_valid = false, cap_explicit = false;
+  double wait_timeout_s = 30.0;  // mppi_set_wait_timeout
+  bool timing = false;
+  int timing_every = 1;      // record stage events on every Nth solve only (events add launch gaps)
+  unsigned timing_count = 0;
+  std::vector<Events> ev;  // one set per iteration
+  mppi_stage_times acc{};
+  std::string err;
+};
+
+namespace mppi_abi {
+using namespace mppi;
+
+
+#define HIPCHK(h, call)                                                  \
+  do {                                                                   \
+    hipError_t e__ = (call);                                             \
+    if (e__ != hipSuccess) return fail((h), MPPI_ERR_HIP, #call, e__);   \
+  } while (0)
+#define OWN(h)                      \
+  do {                              \
+    int rc__ = own_stream(h);       \
+    if (rc__) return rc__;          \
+  } while (0)
+
+int compute_k99(int K);
+std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int NHID);
+std::vector<float> pack_row_weights(const std::vector<float> &theta);
+std::vector<float> pack_row64_weights(const std::vector<float> &theta, int NHID);
+std::vector<float> pack_m44_weights(const std::vector<float> &theta, int NHID);
+int seed_device(mppi_handle *h, uint64_t seed, uint64_t offset);
+int upload_rng_tables(mppi_handle *h);
+bool use_mfma(const mppi_handle *h);
+bool use_valu_reg(const mppi_handle *h);
+int effective_block(const mppi_handle *h);
+bool multi_gen(const mppi_handle *h);
+int bf_waves(const mppi_handle *h);
+bool has_noise_wave(const mppi_handle *h);
+hipStream_t batch_stream(int device);
+void fill_cost_args(const mppi_handle *h, CostArgs &c);
+void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, RolloutArgs &a);
+int launch_rollout(mppi_handle *h, const RolloutArgs &a);
+int check_ready(mppi_handle *h);
+int launch_generator(mppi_handle *h, float *dst);
+int acquire_noise(mppi_handle *h, float **buf_out);
+int prefetch_noise(mppi_handle *h);
+int upload_controls_if_dirty(mppi_handle *h, hipStream_t stream);
+void savgol_host(mppi_handle *h, const float *src, int stride, int off1);
+bool wants_slid_copy(const mppi_handle *h);
+TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last);
+int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess);
+int own_stream(mppi_handle *h);
+void free_all(mppi_handle *h);
+
+// Kernel form for the MFMA path, by the number of 16-rollout groups against the machine (MI355X: 256 CUs of
+// 4 SIMDs).  Measured rollout-kernel times (this file's forms are bit-identical, so only time decides):
+//   * up to one group per CU (K <= 4096): the QUAD form -- the network itself split over two SIMDs, plus a
+//     cost and a control wave; the T-step recurrence is latency bound and this is the shortest chain
+//     (6-32-32-4, T=100, K=4096: quad 71 us, multi1 / multi2 83 us, single-wave 122 us).  64-wide nets: the
+//     OCT form -- one M tile per dynamics wave, four of them, and four riders (rollout_oct.hip; T=100,
+//     K=4096: 6-64-64-4 oct 108 us, quad 134 us; 6-64x4-4 oct 185 us, quad 279 us), also at two groups per
+//     CU (K=8192: 6-64-64-4 oct 172 us, multi2 187 us; 6-64x4-4 oct 365 us, single-wave 503 us; at four
+//     groups per CU it loses: 724 vs 508 us);
+//   * up to two groups per CU (K <= 8192): MULTI2 -- two dynamics waves (whole network each), one cost wave,
+//     one control wave with the in-kernel generator, every wave on a SIMD of its own (K=8192: 83 us; quad
+//     112 us, single-wave 123 us; 6-64-64-4, T=150: 277 us vs 359 / 339 us);
+//   * beyond: MULTI4 with eps from the stand-alone generator kernel -- four dynamics waves per workgroup, one
+//     per SIMD, the cost and control waves riding along (K=16384: 106 us vs 124 us single-wave;
+//     6-64-64-4, T=150: 306 us vs 341 us; the in-kernel generator would load one SIMD too much: 341 us).
+// Shapes the multi form does not have (6-64x4-4: its weights do not fit a wave of a six-wave workgroup) run
+// the single-wave form beyond one group per CU -- in
+// workgroups of FOUR waves: the dispatcher spreads the waves of one workgroup over the four SIMDs of a CU,
+// whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD on paper (K = 16384) --
+// sometimes two on one SIMD and none on its neighbour, which doubles the kernel time
+// (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us).
+inline bool is_m44(int b) { return b == 944; }  // rollout_m44.hip
+inline bool is_row64(int b) { return b == 908 || b == 916; }  // rollout_row64.hip, 8 / 16 rollouts per group
+inline bool is_row(int b) { return b == 900 || b == 901; }  // 901: the tree form of the output layer (rollout_row.hip)
+// where small follow-up work (upload of U, the slide kernel) goes: behind the handle's latest work, wherever it is
+inline hipStream_t work_stream(const mppi_handle *h) { return h->order_stream ? h->order_stream : h->stream; }
+
+// abi_host.hip: the helper thread of the paired host work (mppi_set_host_threads)
+extern std::atomic<int> g_host_threads;
+void host_helper_arm();
+
+}  // namespace mppi_abi

@@ -56,6 +56,13 @@ bool row64_variant_supported(int hidden, int n_hidden);
 int row64_pack_floats(int n_hidden);
 hipError_t launch_rollout_row64(int hidden, int n_hidden, const RolloutArgs &a, int r, hipStream_t stream);
 
+// rollout_m44.hip: latency form of 64-wide nets on v_mfma_f32_4x4x1 with A-matrix broadcast -- four dynamics waves (four
+// rollouts each, all hidden weights in registers) + pose, cost, control and noise wave per 16 rollouts; output layer as a
+// butterfly (NOT the reference's summation order: opt-in by tolerance); a.wpack = pack_m44_weights (mppi_abi.hip)
+bool m44_variant_supported(int hidden, int n_hidden);
+int m44_pack_floats(int n_hidden);
+hipError_t launch_rollout_m44(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
+
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {
   int n_layers;

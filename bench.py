@@ -441,7 +441,8 @@ def main():
             fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            inline_noise = (("quad" in variant or "oct8w" in variant or "row8w" in variant or "multi" in variant) and not variant.endswith("_gen")) \
+            inline_noise = (("quad" in variant or "oct8w" in variant or "row8w" in variant or "row64" in variant or "m44" in variant or "multi" in variant)
+                            and not variant.endswith("_gen")) \
                 or variant.endswith("_3w")  # the kernel's own noise / control wavefront draws eps
             bpu = ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}

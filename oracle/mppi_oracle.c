@@ -78,6 +78,24 @@ static float out_tree_dot(const float *w, const float *a, int nin)
   return L3[0] + L3[2];
 }
 
+/* fma_mode 3: the OUTPUT layer in the order of the 4x4x1-MFMA kernel (autorally_amd/csrc/rollout_m44.hip: m44_out_tree),
+ * 64 inputs only: 16 blocks of 4 consecutive inputs, a block's partial = a product and three fused multiply-adds ascending,
+ * the blocks summed by the butterfly  L1[b] = P[b] + P[b^8];  L2[b] = L1[b] + L1[b^4];  L3[b] = L2[b] + L2[b^2];
+ * sum = L3[0] + L3[1].  Like mode 2: everything else as fma_mode 1, and NOT the reference's order. */
+static float out_tree_dot_m44(const float *w, const float *a)
+{
+  float P[16], L1[16], L2[16], L3[16];
+  for (int b = 0; b < 16; b++) {
+    float z = w[4 * b] * a[4 * b];
+    for (int s = 1; s < 4; s++) z = fmaf(w[4 * b + s], a[4 * b + s], z);
+    P[b] = z;
+  }
+  for (int b = 0; b < 16; b++) L1[b] = P[b] + P[b ^ 8];
+  for (int b = 0; b < 16; b++) L2[b] = L1[b] + L1[b ^ 4];
+  for (int b = 0; b < 16; b++) L3[b] = L2[b] + L2[b ^ 2];
+  return L3[0] + L3[1];
+}
+
 /* PI/neural_net_model.cu:357-410.  k ascending, bias added after the dot product (:389-394). */
 void orc_nn_forward(const float *theta, const int *layers, int n_layers, const float *in,
                     float *out, int fma_mode)
@@ -93,6 +111,7 @@ void orc_nn_forward(const float *theta, const int *layers, int n_layers, const f
     for (int j = 0; j < nout; j++) {
       float tmp = 0.0f;
       if (fma_mode == 2 && l == n_layers - 2 && (nin == 32 || nin == 64)) tmp = out_tree_dot(W + j * nin, cur, nin);
+      else if (fma_mode == 3 && l == n_layers - 2 && nin == 64) tmp = out_tree_dot_m44(W + j * nin, cur);
       else for (int k = 0; k < nin; k++) tmp = mac(W[j * nin + k], cur[k], tmp, fma_mode);
       tmp += b[j];
       if (l < n_layers - 2) tmp = tanhf(tmp); /* MPPI_NNET_NONLINEARITY, :35 */

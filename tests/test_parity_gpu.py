@@ -33,8 +33,8 @@ def _built():
 
 def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
     """HIP solve and the oracle on the same inputs.  The oracle runs in the arithmetic mode of the kernel form that served
-    the solve: mode 1 (the reference's summation order) for every form but the row-tree form, whose output layer is summed as
-    a butterfly (mode 2) -- for that form the NOMINAL oracle's U / trajectory cost / costs come along as ref["nominal"] and
+    the solve: mode 1 (the reference's summation order) for every form but the tree forms, whose output layer is summed as
+    a butterfly (row-tree / row64: mode 2, the 4x4x1-MFMA form: mode 3) -- for those the NOMINAL oracle's U / trajectory cost / costs come along as ref["nominal"] and
     every caller's north-star criteria are checked against them here."""
     eps = noise_for(cfg, seed)
     U0 = np.zeros((cfg["T"], 2), np.float32) if U0 is None else U0
@@ -52,7 +52,8 @@ def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
     sol.close()
     tree = "_tree" in got["variant"]
     iters = cfg.get("num_iters", 1)
-    ref = O.Oracle(cfg, fma_mode=2 if tree else 1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
+    mode = 3 if "m44" in got["variant"] else (2 if tree else 1)  # the output layer's summation order of the form that ran
+    ref = O.Oracle(cfg, fma_mode=mode, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
     if tree:
         nom = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
         ref["nominal"] = nom
@@ -236,7 +237,7 @@ def test_oct_kernel_agrees_bitwise_with_the_single_wave_form(K, T, layers):
     cfg = S.make_config(K, T, track="oval", layers=l, theta=th)
     U0 = warm_U(cfg)
     _, a = _solve_both(cfg, U0=U0, variant="fused")
-    for v in ("oct", "auto"):
+    for v in ("oct",):
         _, m = _solve_both(cfg, U0=U0, variant=v)
         assert "oct8w" in m["variant"]
         np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))
@@ -466,11 +467,16 @@ def test_solve_with_the_other_shipped_models(golden_dir, name, negate):
     _, f = _solve_both(cfg, U0=U0, variant="fused")
     assert "quad" in q["variant"] and "fused" in f["variant"]
     np.testing.assert_array_equal(q["costs"].view(np.uint32), f["costs"].view(np.uint32))
-    if layers[1] == 64:  # the eight-wave form of the 64-wide nets (the automatic choice at this size)
-        _, x = _solve_both(cfg, U0=U0)
+    if layers[1] == 64:  # the eight-wave form of the 64-wide nets: the same bits; the automatic choice at this size is the
+        # 4x4x1-MFMA form, whose output layer is a butterfly (its own oracle mode + the nominal criteria inside _solve_both)
+        _, x = _solve_both(cfg, U0=U0, variant="oct")
         assert "oct8w" in x["variant"]
         np.testing.assert_array_equal(x["costs"].view(np.uint32), f["costs"].view(np.uint32))
         np.testing.assert_array_equal(x["U"].view(np.uint32), f["U"].view(np.uint32))
+        r3, m = _solve_both(cfg, U0=U0)
+        assert "m44" in m["variant"]
+        np.testing.assert_array_equal(m["V"].view(np.uint32), r3["V"][-1].view(np.uint32))
+        assert float(np.percentile(rel_err(m["costs"], r3["costs"]), 95)) < 1e-5 and np.max(np.abs(m["U"] - r3["U"])) <= 1e-4
     np.testing.assert_array_equal(q["V"].view(np.uint32), ref["V"][-1].view(np.uint32))
     err = rel_err(q["costs"], ref["costs"])
     assert int(np.sum(err > 1e-4)) <= 3 and float(np.percentile(err, 95)) < 1e-5

@@ -13,7 +13,8 @@ An iteration outside that is then classified, in this order:
                    differ from each other by more than the HIP path differs from the nearer one;
   BAD              none of these: a candidate for a named regression test or a fix.
 Third argument "row" / "row_tree": only the draws the vector-ALU row form serves (6-32-32-4, at most one group per CU), on
-that form ("row_tree": against the NOMINAL oracle, i.e. the north-star tolerance for the re-associated output layer).
+that form ("row_tree": against the NOMINAL oracle, i.e. the north-star tolerance for the re-associated output layer);
+"m44": only the 64-wide draws (6-64-64-4, 6-64-64-64-64-4, K <= 4096) on the 4x4x1-MFMA form, likewise against the nominal oracle.
 Prints one line per draw that needed a classification and a summary; exit code 1 if any draw is BAD."""
 import os
 import sys
@@ -29,7 +30,8 @@ from tests.helpers import solve_with_iterations, teacher_forced_iterations  # no
 gd = os.path.join(ROOT, "tests", "golden")
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 only_row = sys.argv[3] if len(sys.argv) > 3 else None
-assert only_row in (None, "row", "row_tree")
+assert only_row in (None, "row", "row_tree", "m44")
+WANT = ([6, 64, 64, 4], [6, 64, 64, 64, 64, 4]) if only_row == "m44" else ([6, 32, 32, 4],)
 n_draws = n_iter = bad = conditioned = granular = illcond = 0
 worst_clean, worst_any, forms = 0.0, 0.0, {}
 for seed in range(lo, hi):
@@ -39,11 +41,12 @@ for seed in range(lo, hi):
         r = np.random.RandomState(seed)
         K_ = 64 * int(r.choice([1, 2, 3, 5, 8, 16, 17, 32, 64, 65, 100]))
         r.choice([2, 3, 5, 9, 16, 20, 33, 47, 60, 100])
-        if F.LAYERS[r.randint(len(F.LAYERS))] is not None or K_ > 4096:
+        lay = F.LAYERS[r.randint(len(F.LAYERS))]
+        if (lay if lay is not None else [6, 32, 32, 4]) not in WANT or K_ > 4096:
             continue
     cfg, variant, hist = F._draw(gd, seed)
     if only_row:
-        if cfg.get("bf_W") is not None or list(cfg["layers"]) != [6, 32, 32, 4] or cfg["K"] > 4096:
+        if cfg.get("bf_W") is not None or list(cfg["layers"]) not in WANT or cfg["K"] > 4096:
             continue
         variant = only_row
     iters = cfg["num_iters"]
