@@ -63,14 +63,14 @@ SYMBOLS = [
     "mppi_enable_stage_timing", "mppi_reset_stage_times", "mppi_get_stage_times",
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
     "mppi_debug_inject_handover_fault", "mppi_compute_feedback_gains_pair", "mppi_set_host_threads",
-    "mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout",
+    "mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout", "mppi_debug_form_candidates",
 ]
 
 ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
                 "mppi_compute_control_batch", "mppi_compute_control_batch_async", "mppi_control_ticks_batch",
                 "mppi_nominal_traj_pair")
 ABI3_SYMBOLS = ("mppi_compute_feedback_gains_pair", "mppi_set_host_threads")
-ABI4_SYMBOLS = ("mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout")
+ABI4_SYMBOLS = ("mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout", "mppi_debug_form_candidates")
 
 _lib = None
 
@@ -154,6 +154,7 @@ def lib():
             L.mppi_debug_capture_iterations.argtypes = [hp, C.c_int]
             L.mppi_debug_get_iterations.argtypes = [hp, fp, fp, fp]
             L.mppi_set_wait_timeout.argtypes = [hp, C.c_double]
+            L.mppi_debug_form_candidates.argtypes = [hp, C.POINTER(C.c_char_p), C.c_int]
         for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
             if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS) and (v4 or s not in ABI4_SYMBOLS):
                 getattr(L, s)
@@ -403,6 +404,12 @@ class Solver:
         if with_V:
             out["V"] = V
         return out
+
+    def form_candidates(self):
+        """Names of the kernel forms the selection table knows for this model (mppi_debug_form_candidates)."""
+        buf = (C.c_char_p * 16)()
+        n = self.L.mppi_debug_form_candidates(self.h, buf, 16)
+        return [buf[i].decode() for i in range(n)]
 
     def set_wait_timeout(self, seconds):
         self._ck(self.L.mppi_set_wait_timeout(self.h, float(seconds)))

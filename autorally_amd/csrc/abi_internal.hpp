@@ -37,6 +37,21 @@
 
 namespace mppi_abi {
 
+// Kernel forms of the rollout (abi_forms.hip has the table that picks one, and what each is).
+enum class Form : int {
+  Auto = 0,
+  Fused64, Fused256,                // rollout_mfma.hip: one wave per 16 rollouts does everything (workgroups of 1 / 4 waves)
+  Quad,                             // rollout_mfma.hip: network split over two waves + cost + control wave per 16 rollouts
+  Oct,                              // rollout_oct.hip: 64-wide nets, four dynamics waves (one M tile each) + four riders
+  Multi1, Multi2, Multi4, Multi4U,  // rollout_multi.hip: ND dynamics waves of 16 rollouts + riders (4U: six waves)
+  Row, RowTree,                     // rollout_row.hip: 6-32-32-4 on the vector ALU; Tree: butterfly output layer
+  Row64R8, Row64R16,                // rollout_row64.hip: 64-wide nets on the vector ALU, 8 / 16 rollouts per group
+  M44,                              // rollout_m44.hip: 64-wide nets on v_mfma_f32_4x4x1 with A-broadcast
+  ValuReg, ValuLds,                 // rollout_valu.hip: throughput-style vector kernels (any layer list: ValuLds)
+  Bf1, Bf2, Bf3,                    // rollout_bf.hip: basis-function model, waves per 64 rollouts
+};
+enum class Pref : int { Auto = 0, Mfma, Valu, ValuLds };
+
 struct Events {
   // e[0..3]: markers on the handle's stream before noise / before rollout / after rollout / after tail;
   // e[4], e[5]: begin and end of the rollout kernel's own dispatch (hipExtLaunchKernelGGL, MPPI_LAUNCH_ROLLOUT)
@@ -56,10 +71,8 @@ struct mppi_handle {
   NetDesc net{};
   bool mfma_ok = false;
   int hidden = 0, n_hidden = 0;
-  int variant_pref = 0;  // 0 auto, 1 mfma, 2 valu
-  int block_threads = 0;    // 0: auto; 1040: multi form with ND = 4 and six waves (one cost wave); 512: quad (2 dynamics + cost + control waves per 16 rollouts); 800: oct (4 dynamics waves, one M tile of a
-                            // 64-wide net each, + pose, cost, control, noise wave); 64, 256: single-wave form;
-                            // 1000 + ND: multi form (ND dynamics waves of 16 rollouts + cost wave + control wave), ND = 1, 2, 4
+  mppi_abi::Pref pref = mppi_abi::Pref::Auto;   // "auto" | "mfma" | "valu" | "valu_lds"
+  mppi_abi::Form forced = mppi_abi::Form::Auto;  // a kernel form asked for by name (mppi_set_rollout_variant); Auto: the selection table
   bool multi_standalone_noise = false;  // multi form: eps from the stand-alone generator kernel instead of the control wave
   int num_simds = 1024;     // 4 per CU
   hipStream_t stream = nullptr;
@@ -164,10 +177,14 @@ int seed_device(mppi_handle *h, uint64_t seed, uint64_t offset);
 int upload_rng_tables(mppi_handle *h);
 bool use_mfma(const mppi_handle *h);
 bool use_valu_reg(const mppi_handle *h);
-int effective_block(const mppi_handle *h);
-bool multi_gen(const mppi_handle *h);
-int bf_waves(const mppi_handle *h);
+Form form_of(const mppi_handle *h);
+bool form_generator_noise(const mppi_handle *h);
 bool has_noise_wave(const mppi_handle *h);
+int form_bf_waves(Form f);
+int form_multi_nd(Form f);
+int form_fused_threads(Form f);
+inline bool form_is_row(Form f) { return f == Form::Row || f == Form::RowTree; }
+inline bool form_is_row64(Form f) { return f == Form::Row64R8 || f == Form::Row64R16; }
 hipStream_t batch_stream(int device);
 void fill_cost_args(const mppi_handle *h, CostArgs &c);
 void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, RolloutArgs &a);
@@ -184,30 +201,6 @@ int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess);
 int own_stream(mppi_handle *h);
 void free_all(mppi_handle *h);
 
-// Kernel form for the MFMA path, by the number of 16-rollout groups against the machine (MI355X: 256 CUs of
-// 4 SIMDs).  Measured rollout-kernel times (this file's forms are bit-identical, so only time decides):
-//   * up to one group per CU (K <= 4096): the QUAD form -- the network itself split over two SIMDs, plus a
-//     cost and a control wave; the T-step recurrence is latency bound and this is the shortest chain
-//     (6-32-32-4, T=100, K=4096: quad 71 us, multi1 / multi2 83 us, single-wave 122 us).  64-wide nets: the
-//     OCT form -- one M tile per dynamics wave, four of them, and four riders (rollout_oct.hip; T=100,
-//     K=4096: 6-64-64-4 oct 108 us, quad 134 us; 6-64x4-4 oct 185 us, quad 279 us), also at two groups per
-//     CU (K=8192: 6-64-64-4 oct 172 us, multi2 187 us; 6-64x4-4 oct 365 us, single-wave 503 us; at four
-//     groups per CU it loses: 724 vs 508 us);
-//   * up to two groups per CU (K <= 8192): MULTI2 -- two dynamics waves (whole network each), one cost wave,
-//     one control wave with the in-kernel generator, every wave on a SIMD of its own (K=8192: 83 us; quad
-//     112 us, single-wave 123 us; 6-64-64-4, T=150: 277 us vs 359 / 339 us);
-//   * beyond: MULTI4 with eps from the stand-alone generator kernel -- four dynamics waves per workgroup, one
-//     per SIMD, the cost and control waves riding along (K=16384: 106 us vs 124 us single-wave;
-//     6-64-64-4, T=150: 306 us vs 341 us; the in-kernel generator would load one SIMD too much: 341 us).
-// Shapes the multi form does not have (6-64x4-4: its weights do not fit a wave of a six-wave workgroup) run
-// the single-wave form beyond one group per CU -- in
-// workgroups of FOUR waves: the dispatcher spreads the waves of one workgroup over the four SIMDs of a CU,
-// whereas 64-thread workgroups are placed one by one and -- at one wave per SIMD on paper (K = 16384) --
-// sometimes two on one SIMD and none on its neighbour, which doubles the kernel time
-// (tools/placement_probe.hip: 106 of 1024 SIMDs doubled on a first launch; rollout 601 us vs 341 us).
-inline bool is_m44(int b) { return b == 944; }  // rollout_m44.hip
-inline bool is_row64(int b) { return b == 908 || b == 916; }  // rollout_row64.hip, 8 / 16 rollouts per group
-inline bool is_row(int b) { return b == 900 || b == 901; }  // 901: the tree form of the output layer (rollout_row.hip)
 // where small follow-up work (upload of U, the slide kernel) goes: behind the handle's latest work, wherever it is
 inline hipStream_t work_stream(const mppi_handle *h) { return h->order_stream ? h->order_stream : h->stream; }
 

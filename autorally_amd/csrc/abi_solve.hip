@@ -57,7 +57,9 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.U = h->d_in;
   a.noise = noise;
   a.costs = h->d_costs;
-  a.wpack = use_mfma(h) ? (is_row(effective_block(h)) ? h->d_rowpack : is_row64(effective_block(h)) ? h->d_row64pack : is_m44(effective_block(h)) ? h->d_m44pack : h->d_wpack) : (use_valu_reg(h) ? h->d_theta_s : h->d_theta);
+  const Form f = form_of(h);
+  a.wpack = form_is_row(f) ? h->d_rowpack : form_is_row64(f) ? h->d_row64pack : f == Form::M44 ? h->d_m44pack
+            : f == Form::ValuReg ? h->d_theta_s : (f == Form::ValuLds || h->basis) ? h->d_theta : h->d_wpack;
   a.inv_t = h->d_invt;
   a.K = h->K;
   a.T = h->T;
@@ -81,16 +83,23 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
 int launch_rollout(mppi_handle *h, const RolloutArgs &a)
 {
   // basis-function model: the two-wave form while both waves of a group get a SIMD of their own
-  hipError_t e = h->basis ? launch_rollout_bf(a, bf_waves(h), h->stream)
-                 : (use_mfma(h) && effective_block(h) > 1000)
-                     ? launch_rollout_multi(h->hidden, h->n_hidden, a, effective_block(h) - 1000, h->stream)
-                 : (use_mfma(h) && effective_block(h) == 800) ? launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream)
-                 : (use_mfma(h) && is_m44(effective_block(h))) ? launch_rollout_m44(h->hidden, h->n_hidden, a, h->stream)
-                 : (use_mfma(h) && is_row64(effective_block(h))) ? launch_rollout_row64(h->hidden, h->n_hidden, a, effective_block(h) - 900, h->stream)
-                 : (use_mfma(h) && is_row(effective_block(h))) ? launch_rollout_row(h->hidden, h->n_hidden, a, effective_block(h) == 901, h->stream)
-                 : use_mfma(h) ? launch_rollout_mfma(h->hidden, h->n_hidden, a, effective_block(h), h->stream)
-                 : use_valu_reg(h) ? launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream)
-                                   : launch_rollout_valu(h->net, a, h->stream);
+  const Form f = form_of(h);
+  hipError_t e = hipSuccess;
+  switch (f) {
+    case Form::Bf1: case Form::Bf2: case Form::Bf3: e = launch_rollout_bf(a, form_bf_waves(f), h->stream); break;
+    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U:
+      e = launch_rollout_multi(h->hidden, h->n_hidden, a, form_multi_nd(f), h->stream);
+      break;
+    case Form::Oct: e = launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream); break;
+    case Form::M44: e = launch_rollout_m44(h->hidden, h->n_hidden, a, h->stream); break;
+    case Form::Row64R8: case Form::Row64R16: e = launch_rollout_row64(h->hidden, h->n_hidden, a, f == Form::Row64R8 ? 8 : 16, h->stream); break;
+    case Form::Row: case Form::RowTree: e = launch_rollout_row(h->hidden, h->n_hidden, a, f == Form::RowTree, h->stream); break;
+    case Form::Quad: case Form::Fused64: case Form::Fused256:
+      e = launch_rollout_mfma(h->hidden, h->n_hidden, a, form_fused_threads(f), h->stream);
+      break;
+    case Form::ValuReg: e = launch_rollout_valu_reg(h->hidden, h->n_hidden, a, h->stream); break;
+    default: e = launch_rollout_valu(h->net, a, h->stream); break;
+  }
   if (e != hipSuccess) return fail(h, MPPI_ERR_HIP, "rollout launch", e);
   return MPPI_OK;
 }
@@ -444,10 +453,9 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
   for (int i = 0; i < n && together; i++) {
     const mppi_handle *h = hs[i];
     // network model: the four-wavefront form; basis-function model: its three-wavefront form (in-kernel generator)
-    const bool form_ok = h->basis ? (h0->basis && bf_waves(h) == 3)
-                                  : (!h0->basis && use_mfma(h) && use_mfma(h0) &&
-                                     (effective_block(h) == 512 || is_row(effective_block(h))) &&
-                                     effective_block(h) == effective_block(h0) &&
+    const Form f = form_of(h);
+    const bool form_ok = h->basis ? (h0->basis && f == Form::Bf3)
+                                  : (!h0->basis && (f == Form::Quad || form_is_row(f)) && f == form_of(h0) &&
                                      h->hidden == h0->hidden && h->n_hidden == h0->n_hidden);
     together = form_ok && h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
                h->K <= 4096 && !h->timing && !h->capture && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
@@ -505,7 +513,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     }
     for (int i = n; i < kMaxBatch; i++) qb.inst[i] = qb.inst[0];
     hipError_t e = h0->basis ? launch_rollout_bf_batch(qb, S)
-                   : is_row(effective_block(h0)) ? launch_rollout_row_batch(qb, effective_block(h0) == 901, S)
+                   : form_is_row(form_of(h0)) ? launch_rollout_row_batch(qb, form_of(h0) == Form::RowTree, S)
                                                 : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
     if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
     if (e != hipSuccess) return fail(h0, MPPI_ERR_HIP, "batched launch", e);

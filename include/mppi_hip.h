@@ -32,7 +32,8 @@ extern "C" {
  *    mppi_debug_inject_handover_fault; mppi_slide_control_seq(h, 0) is MPPI_OK (was MPPI_ERR_INVALID); "fused" =
  *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w", "valu_row8w_*"; variants "row", "multi4u". */
 /* 3: + mppi_set_host_threads, mppi_compute_feedback_gains_pair. */
-/* 4: + mppi_debug_capture_iterations, mppi_debug_get_iterations, mppi_set_wait_timeout; variants "row_tree", "row_exact". */
+/* 4: + mppi_debug_capture_iterations, mppi_debug_get_iterations, mppi_set_wait_timeout, mppi_debug_form_candidates; variants
+ *    "row_tree", "row_exact", "row64[_r8|_r16]", "m44"; names "valu_row8w_tree_*", "valu_row64_r*_tree_*", "mfma4x4x1_*_m44_tree". */
 #define MPPI_ABI_VERSION 4
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
@@ -295,6 +296,11 @@ int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
  * (explicit-noise solves only: MPPI_ERR_STATE otherwise); each may be NULL. */
 int mppi_debug_capture_iterations(mppi_handle *h, int on);
 int mppi_debug_get_iterations(mppi_handle *h, float *U_raw, float *costs, float *V);
+
+/* Test / tooling hook (not part of the drop-in surface): the kernel forms the library's selection table knows for this
+ * handle's model, as names for mppi_set_rollout_variant, the table's order; returns how many were written (<= max_n).
+ * tests/test_form_selection_gpu.py times them against the automatic choice. */
+int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max_n);
 
 /* How long a blocking call (mppi_compute_control, mppi_synchronize, mppi_get_results ...) polls for a solve's result block
  * before it gives up with MPPI_ERR_HIP; default 30 s.  (The reference blocks in cudaStreamSynchronize without a limit,

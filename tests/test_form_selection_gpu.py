@@ -1,0 +1,69 @@
+"""The selection table of autorally_amd/csrc/abi_forms.hip against the clock: for every bucket (model shape x rollouts per CU)
+the candidates the table knows are timed for a few dozen launches each (the rollout kernel's own dispatch time, HIP events), and
+the automatic choice must be within 10 % of the best of them.  The table's rows cite the profiles they came from; this test
+is what notices when a kernel change moves a crossover."""
+import os
+
+import numpy as np
+import pytest
+
+from autorally_amd import capi
+from autorally_amd import params as P
+from autorally_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+BUCKETS = [  # (layers or model file, K, T)
+    (None, 1920, 100), (None, 4096, 100), (None, 8192, 100), (None, 16384, 100),
+    ([6, 64, 64, 4], 4096, 100), ([6, 64, 64, 4], 8192, 100), ([6, 64, 64, 4], 16384, 100),
+    ("wider_deeper_network_08_20_2020", 1920, 100), ("wider_deeper_network_08_20_2020", 8192, 60),
+    ([6, 32, 32, 32, 32, 4], 4096, 100),
+]
+
+
+def _rollout_us(cfg, variant, n=40):
+    sol = capi.Solver(cfg)
+    sol.set_rollout_variant(variant)
+    name = sol.rollout_variant()
+    st = cfg["start_state"]
+    for _ in range(60):  # clocks up, code objects loaded
+        sol.compute_control(st)
+    best = []
+    for _ in range(3):
+        sol.enable_stage_timing(1)
+        sol.reset_stage_times()
+        for _ in range(n):
+            sol.compute_control(st)
+            sol.slide_control_seq(1)
+        t = sol.get_stage_times()
+        sol.enable_stage_timing(0)
+        best.append(1e3 * t["rollout_ms"] / max(1, t["n_solves"]) / cfg.get("num_iters", 1))
+    sol.close()
+    return min(best), name
+
+
+@pytest.mark.parametrize("model,K,T", BUCKETS)
+def test_automatic_form_is_within_ten_percent_of_the_best_candidate(golden_dir, model, K, T):
+    if isinstance(model, str):
+        layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", model + ".npz"))
+        cfg = S.make_config(K, T, layers=layers, theta=theta, track="oval", negate_yaw_der=False)
+    elif model is None:
+        cfg = S.make_config(K, T, track="oval")
+    else:
+        layers, theta = P.synthetic_model(model, seed=4)
+        cfg = S.make_config(K, T, layers=layers, theta=theta, track="oval")
+    probe = capi.Solver(cfg)
+    cands = probe.form_candidates()
+    probe.close()
+    assert len(cands) >= 2, cands
+    t_auto, auto_name = _rollout_us(cfg, "auto")
+    times = {}
+    for v in cands:
+        try:
+            times[v], _ = _rollout_us(cfg, v)
+        except capi.MppiError:
+            continue  # a form this K cannot take (multi forms: K a multiple of 16 ND)
+    best = min(times.values())
+    print("form selection %s K=%d T=%d: auto = %s %.1f us; candidates %s" % (
+        "-".join(map(str, cfg["layers"])), K, T, auto_name, t_auto, {k: round(x, 1) for k, x in sorted(times.items(), key=lambda kv: kv[1])}))
+    assert t_auto <= 1.10 * best, (auto_name, round(t_auto, 1), {k: round(x, 1) for k, x in times.items()})
