@@ -39,7 +39,10 @@ def kernel_sources_sha16():
     import glob
     import hashlib
     h = hashlib.sha256()
+    host_side = ("abi_", "mppi_abi", "host_net", "tanhf_vec", "ddp_")  # the C ABI's host files: no device code
     for f in sorted(glob.glob(os.path.join(ROOT, "autorally_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "autorally_amd", "csrc", "*.hpp"))):
+        if os.path.basename(f).startswith(host_side):
+            continue
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
