@@ -34,6 +34,57 @@ Mat<R, C> mul(const Mat<R, K> &a, const Mat<K, C> &b)
     }
   return o;
 }
+// The Riccati step's products on eight lanes: a matrix with up to 8 columns keeps every row in one AVX2 register (padded
+// with zeros), and C[i][:] = sum_k A[i][k] * B[k][:] runs k ascending with a separate multiply and add per term (this file
+// is compiled with -ffp-contract=off) -- element for element the operations of mul() above in the same order, hence the
+// same bits; only seven of them advance per instruction (99 steps x ~2.5 products of 7 x 7 x 7 were 20 % of a pass).
+template <int R>
+struct Mat8 {
+  alignas(32) float v[R][8];
+};
+template <int R, int C>
+Mat8<R> pad8(const Mat<R, C> &a)
+{
+  static_assert(C <= 8, "one register per row");
+  Mat8<R> o;
+  for (int i = 0; i < R; i++) {
+    for (int j = 0; j < C; j++) o.v[i][j] = a.v[i][j];
+    for (int j = C; j < 8; j++) o.v[i][j] = 0.0f;
+  }
+  return o;
+}
+template <int R, int C>
+Mat<R, C> unpad8(const Mat8<R> &a)
+{
+  Mat<R, C> o;
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j < C; j++) o.v[i][j] = a.v[i][j];
+  return o;
+}
+// A [R][K] (plain) times B [K][<= 8] (padded rows)
+template <int R, int K>
+Mat8<R> mul8(const float (&a)[R][K], const Mat8<K> &b)
+{
+  Mat8<R> o;
+  for (int i = 0; i < R; i++) {
+    __m256 s = _mm256_setzero_ps();
+    for (int k = 0; k < K; k++) s = _mm256_add_ps(s, _mm256_mul_ps(_mm256_set1_ps(a[i][k]), _mm256_load_ps(b.v[k])));
+    _mm256_store_ps(o.v[i], s);
+  }
+  return o;
+}
+template <int R, int K>
+Mat8<R> mul8(const Mat8<R> &a, const Mat8<K> &b)  // the first K columns of a
+{
+  Mat8<R> o;
+  for (int i = 0; i < R; i++) {
+    __m256 s = _mm256_setzero_ps();
+    for (int k = 0; k < K; k++) s = _mm256_add_ps(s, _mm256_mul_ps(_mm256_set1_ps(a.v[i][k]), _mm256_load_ps(b.v[k])));
+    _mm256_store_ps(o.v[i], s);
+  }
+  return o;
+}
+
 template <int R, int C>
 Mat<C, R> transpose(const Mat<R, C> &a)
 {
@@ -336,11 +387,12 @@ int ddp_feedback_gains(const DdpNet &net, const DdpProblem &p, const float *x0, 
       for (int m = 0; m < kDdpS; m++) s += BT.v[j][m] * Vx[m];
       qu[j] = dL[(size_t)k * kDdpSC + kDdpS + j] * dt + s;
     }
-    const Mat<kDdpC, kDdpS> BtV = mul(BT, Vxx);
-    Mat<kDdpC, kDdpS> qux = mul(BtV, Phi);           // d2L's bottom-left block is zero
-    Mat<kDdpS, kDdpS> qxx = mul(mul(PhiT, Vxx), Phi);
+    const Mat8<kDdpS> Vxx8 = pad8(Vxx), Phi8 = pad8(Phi), B8 = pad8(B);
+    const Mat8<kDdpC> BtV8 = mul8(BT.v, Vxx8);
+    Mat<kDdpC, kDdpS> qux = unpad8<kDdpC, kDdpS>(mul8<kDdpC, kDdpS>(BtV8, Phi8));  // d2L's bottom-left block is zero
+    Mat<kDdpS, kDdpS> qxx = unpad8<kDdpS, kDdpS>(mul8<kDdpS, kDdpS>(mul8(PhiT.v, Vxx8), Phi8));
     for (int i = 0; i < kDdpS; i++) qxx.v[i][i] = p.Q[i] * dt + qxx.v[i][i];
-    Mat<kDdpC, kDdpC> quu = mul(BtV, B);
+    Mat<kDdpC, kDdpC> quu = unpad8<kDdpC, kDdpC>(mul8<kDdpC, kDdpS>(BtV8, B8));
     for (int j = 0; j < kDdpC; j++) quu.v[j][j] = p.R[j] * dt + quu.v[j][j];
     const Ldlt2 ldlt(quu);
     if (!ldlt.ok) return 1;
@@ -363,7 +415,7 @@ int ddp_feedback_gains(const DdpNet &net, const DdpProblem &p, const float *x0, 
     }
     // value function, ddp.h:117-122
     const Mat<kDdpS, kDdpC> quxT = transpose(qux);
-    const Mat<kDdpS, kDdpS> corr = mul(quxT, Lk);
+    const Mat<kDdpS, kDdpS> corr = unpad8<kDdpS, kDdpS>(mul8(quxT.v, pad8(Lk)));
     Mat<kDdpS, kDdpS> Vn;
     for (int i = 0; i < kDdpS; i++)
       for (int j = 0; j < kDdpS; j++) Vn.v[i][j] = qxx.v[i][j] + corr.v[i][j];
