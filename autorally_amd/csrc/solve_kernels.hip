@@ -394,6 +394,9 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   // (s_waitcnt vmcnt(0)) and only then one lane bumps the agent-scope counter; the last arriver
   // runs one agent-scope acquire (last_arriver_acquire) and reads every handed-off word with sc1
   // loads.  No buffer_wbl2 on this path. ----
+#ifdef MPPI_DIAG_TAIL_NOARRIVE  // diagnostic build: what do the arrival counter and the last workgroup's smoothing cost?
+  return;
+#endif
   __syncthreads();  // is_last may still be read from the row hand-off above
   if (tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -540,6 +540,15 @@ class MPPIControllerT {
     h_ = nullptr;
   }
   mppi_handle *handle() { return h_; }
+  // Not in the reference: which rollout kernel form serves this controller (mppi_set_rollout_variant).  "auto" (default)
+  // lets the library choose; "mfma" keeps the reference's summation order in every layer (the automatic choice for
+  // 6-32-32-4 and 64-wide nets at K <= 8192 sums the OUTPUT layer as a butterfly, inside the 1e-4 tolerance: INTEGRATION.md 2)
+  void setRolloutVariant(const std::string &name)
+  {
+    if (mppi_set_rollout_variant(h_, name.c_str()) != MPPI_OK)
+      throw std::runtime_error(std::string("setRolloutVariant: ") + mppi_last_error(h_));
+  }
+  std::string rolloutVariant() const { return mppi_rollout_variant(h_); }
 
   // setCudaStream(stream), mppi_controller.cuh:109 / mppi_controller.cu:365-370: the handle owns its stream (one
   // per controller, created with it), so there is nothing to rebind; kept for code written against the reference

@@ -36,7 +36,7 @@ template <class DYNAMICS_T, class MAKE_MODEL>
 int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL make_model)
 {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s <launch.xml> [--rollouts K] [--layers 6-32-32-4] [--max-iter N] [--no-sleep] [--host-threads 1|2] "
+    fprintf(stderr, "usage: %s <launch.xml> [--rollouts K] [--layers 6-32-32-4] [--max-iter N] [--no-sleep] [--host-threads 1|2] [--rollout-variant auto|mfma|...] "
                     "[--device D] [--trace file] [--set key=value]\n", argv[0]);
     return 2;
   }
@@ -58,6 +58,8 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
   // --host-threads 1|2: mppi_set_host_threads -- 2 (default here): the two controllers' nominal replays and DDP passes of
   // a tick side by side, on the optimizer thread and one helper (the reference runs them one after the other)
   int host_threads = 2;
+  // --rollout-variant NAME: mppi_set_rollout_variant on both controllers ("mfma": the reference's summation order in every layer)
+  const char *rollout_variant = nullptr;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--rollouts") && i + 1 < argc) rollouts = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--layers") && i + 1 < argc) layers = parse_layers(argv[++i]);
@@ -67,6 +69,7 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     else if (!strcmp(argv[i], "--set") && i + 1 < argc) overrides.push_back(argv[++i]);
     else if (!strcmp(argv[i], "--no-sleep")) sleep_to_rate = false;
     else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--rollout-variant") && i + 1 < argc) rollout_variant = argv[++i];
     else if (!strcmp(argv[i], "--dcfg-desired-speed") && i + 1 < argc) { dcfg_speed = atof(argv[++i]); have_dcfg = true; }
     else if (!strcmp(argv[i], "--debug-image")) debug_image = true;
     else if (!strcmp(argv[i], "--pose-script") && i + 1 < argc) pose_script = argv[++i];
@@ -105,6 +108,10 @@ int path_integral_main(int argc, char **argv, int default_rollouts, MAKE_MODEL m
     // both controllers seed their generator with 1234 (mppi_controller.cu:331): identical streams
     MPPIControllerT<DYNAMICS_T> actual(&model, &costs, exploration_std, init_u, hz, T, stride, gamma, num_iters, rollouts, device);
     MPPIControllerT<DYNAMICS_T> predicted(&model, &costs, exploration_std, init_u, hz, T, stride, gamma, num_iters, rollouts, device);
+    if (rollout_variant) {
+      actual.setRolloutVariant(rollout_variant);
+      predicted.setRolloutVariant(rollout_variant);
+    }
     SimPlant robot;
     if (have_dcfg) {  // one dynamic_reconfigure message waiting at the first tick (cfg defaults + the given speed)
       robot.new_dcfg = true;
