@@ -57,13 +57,16 @@ def test_automatic_form_is_within_ten_percent_of_the_best_candidate(golden_dir, 
     probe.close()
     assert len(cands) >= 2, cands
     t_auto, auto_name = _rollout_us(cfg, "auto")
-    times = {}
+    times, names = {}, {}
     for v in cands:
         try:
-            times[v], _ = _rollout_us(cfg, v)
+            times[v], names[v] = _rollout_us(cfg, v)
         except capi.MppiError:
             continue  # a form this K cannot take (multi forms: K a multiple of 16 ND)
     best = min(times.values())
+    fastest = min(times, key=times.get)
     print("form selection %s K=%d T=%d: auto = %s %.1f us; candidates %s" % (
         "-".join(map(str, cfg["layers"])), K, T, auto_name, t_auto, {k: round(x, 1) for k, x in sorted(times.items(), key=lambda kv: kv[1])}))
-    assert t_auto <= 1.10 * best, (auto_name, round(t_auto, 1), {k: round(x, 1) for k, x in times.items()})
+    # (the automatic choice IS one of the candidates: when it is the fastest one by name, two timings of the same kernel
+    # are not compared with each other -- boxes of the pool show +-5 % between runs of one kernel)
+    assert names[fastest] == auto_name or t_auto <= 1.10 * best, (auto_name, round(t_auto, 1), {k: round(x, 1) for k, x in times.items()})
