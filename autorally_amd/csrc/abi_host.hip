@@ -2,6 +2,8 @@
 // feedback gains (:402-445), and the helper thread that takes one of a pair (mppi_set_host_threads).
 #include "abi_internal.hpp"
 
+#include <stdexcept>
+
 using namespace mppi;
 using namespace mppi_abi;
 
@@ -46,11 +48,21 @@ class HostHelper {
       return;
     }
     job_ = &other;
+    failed_.store(false);
     done_.store(false);
     posted_.store(true);
     arm();
-    mine();
-    while (!done_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    // the caller leaves only after the helper is through with `other` (which refers to the caller's frame), whatever
+    // `mine` does: an exception of `mine` is rethrown after the wait, one of `other` (caught on the helper) afterwards
+    struct Wait {
+      std::atomic<bool> &d;
+      ~Wait() { while (!d.load(std::memory_order_acquire)) __builtin_ia32_pause(); }
+    };
+    {
+      Wait w{done_};
+      mine();
+    }
+    if (failed_.load()) throw std::runtime_error("host helper: the paired job threw");
   }
 
  private:
@@ -70,7 +82,11 @@ class HostHelper {
         for (;;) {
           if (posted_.load(std::memory_order_acquire)) {
             posted_.store(false);
-            (*job_)();
+            try {
+              (*job_)();
+            } catch (...) {  // (bad_alloc of a result vector ...): reported by run_pair on the caller's thread
+              failed_.store(true);
+            }
             done_.store(true, std::memory_order_release);
             until = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
           } else {
@@ -87,7 +103,7 @@ class HostHelper {
   std::mutex mu_, pair_mu_;
   std::condition_variable cv_;
   bool wake_ = false, quit_ = false;
-  std::atomic<bool> spinning_{false}, posted_{false}, done_{false};
+  std::atomic<bool> spinning_{false}, posted_{false}, done_{false}, failed_{false};
   const std::function<void()> *job_ = nullptr;
 };
 std::atomic<int> g_host_threads{1};
@@ -157,6 +173,21 @@ int mppi_nominal_traj_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM],
                         ha->net.n_layers == hb->net.n_layers &&
                         memcmp(ha->net.layers, hb->net.layers, sizeof(ha->net.layers)) == 0 && state_a && state_b &&
                         state_seq_a && state_seq_b && control_seq_a && control_seq_b;
+  if (g_host_threads.load(std::memory_order_relaxed) >= 2) {  // one replay per thread (mppi_set_host_threads), any model
+    for (mppi_handle *h : {ha, hb})
+      if (h->pending) {
+        const int rc = mppi_synchronize(h);
+        if (rc) return rc;
+      }
+    int rca = MPPI_OK, rcb = MPPI_OK;
+    try {
+      host_helper().run_pair([&] { rcb = mppi_nominal_traj(hb, state_b, state_seq_b, control_seq_b); },
+                             [&] { rca = mppi_nominal_traj(ha, state_a, state_seq_a, control_seq_a); });
+    } catch (const std::exception &e) {
+      return fail(ha, MPPI_ERR_HIP, e.what());
+    }
+    return rca ? rca : rcb;
+  }
   if (!lockstep) {
     const int rc = mppi_nominal_traj(ha, state_a, state_seq_a, control_seq_a);
     return rc ? rc : mppi_nominal_traj(hb, state_b, state_seq_b, control_seq_b);
@@ -166,12 +197,6 @@ int mppi_nominal_traj_pair(mppi_handle *ha, const float state_a[MPPI_STATE_DIM],
       const int rc = mppi_synchronize(h);
       if (rc) return rc;
     }
-  if (g_host_threads.load(std::memory_order_relaxed) >= 2) {  // one replay per thread (mppi_set_host_threads)
-    int rca = MPPI_OK, rcb = MPPI_OK;
-    host_helper().run_pair([&] { rcb = mppi_nominal_traj(hb, state_b, state_seq_b, control_seq_b); },
-                           [&] { rca = mppi_nominal_traj(ha, state_a, state_seq_a, control_seq_a); });
-    return rca ? rca : rcb;
-  }
   mppi_handle *hs[2] = {ha, hb};
   float *sseq[2] = {state_seq_a, state_seq_b}, *cseq[2] = {control_seq_a, control_seq_b};
   float s[2][kStateDim], sd[2][kStateDim], in6[2][6];
@@ -262,8 +287,12 @@ int mppi_compute_feedback_gains_pair(mppi_handle *ha, const float state_a[MPPI_S
         if (rc) return rc;
       }
     int rca = MPPI_OK, rcb = MPPI_OK;
-    host_helper().run_pair([&] { rcb = mppi_compute_feedback_gains(hb, state_b, target_state_seq_b, target_control_seq_b); },
-                           [&] { rca = mppi_compute_feedback_gains(ha, state_a, target_state_seq_a, target_control_seq_a); });
+    try {  // no exception crosses the ABI: one thrown on either thread (an allocation of the result vectors) becomes a status
+      host_helper().run_pair([&] { rcb = mppi_compute_feedback_gains(hb, state_b, target_state_seq_b, target_control_seq_b); },
+                             [&] { rca = mppi_compute_feedback_gains(ha, state_a, target_state_seq_a, target_control_seq_a); });
+    } catch (const std::exception &e) {
+      return fail(ha, MPPI_ERR_HIP, e.what());
+    }
     return rca ? rca : rcb;
   }
   const int rc = mppi_compute_feedback_gains(ha, state_a, target_state_seq_a, target_control_seq_a);

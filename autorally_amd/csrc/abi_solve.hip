@@ -457,7 +457,14 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     const bool form_ok = h->basis ? (h0->basis && f == Form::Bf3)
                                   : (!h0->basis && (f == Form::Quad || form_is_row(f)) && f == form_of(h0) &&
                                      h->hidden == h0->hidden && h->n_hidden == h0->n_hidden);
-    together = form_ok && h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
+    // one kernel instance serves the whole batch: the instances must agree on what it is specialised for (affine / projective
+    // costmap transform, control cost or none) -- a superset kernel would compute 0 * x where the single solve computes
+    // nothing, which differs for a non-finite x; such a pair is solved one by one
+    CostArgs ci, c0;
+    fill_cost_args(h, ci);
+    fill_cost_args(h0, c0);
+    together = form_ok && ci.affine == c0.affine && ci.need_control_cost == c0.need_control_cost &&
+               h->cfg.device == h0->cfg.device && h->cfg.num_iters == h0->cfg.num_iters &&
                h->K <= 4096 && !h->timing && !h->capture && !h->prefetch_valid && h->have_nn && h->have_map && h->have_cost;
     // waves of a group that need a SIMD each: quad 4, row 4 dynamics waves (its riders ride), basis functions 3
     waves += h->basis ? 3 * (h->K / 64) : 4 * (h->K / kRolloutsPerWave);
@@ -474,19 +481,37 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
   const hipStream_t S = batch_stream(h0->cfg.device);
   if (!S) return fail(h0, MPPI_ERR_HIP, "no batch stream");
   const int iters = h0->cfg.num_iters;
+  // First pass: everything that can fail without having touched a handle -- every handle's previous solve collected,
+  // every handle's explicit noise checked -- so that one handle's error does not leave its partners half-advanced.
   for (int i = 0; i < n; i++) {
     mppi_handle *h = hs[i];
     int rc = wait_pending(h);  // finish a previous asynchronous solve first
     if (rc) return rc;
     if (h->explicit_iters > 0 && h->explicit_iters != iters)
       return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
+  }
+  // From here on handles change (sequence numbers, generator buffers, the slid copy's validity).  A HIP error below
+  // leaves every handle of the batch in the state "nothing on the device can be trusted": the host copies of U / hist
+  // are uploaded again by the next solve, no slid copy is offered to mppi_slide_control_seq.
+  auto poison = [&](int rc_) {
+    for (int i = 0; i < n; i++) {
+      hs[i]->slid_valid = false;
+      hs[i]->u_dirty = true;
+      hs[i]->pending = false;
+    }
+    return rc_;
+  };
+  for (int i = 0; i < n; i++) {
+    mppi_handle *h = hs[i];
+    int rc = MPPI_OK;
     if (h->order_stream != S) {  // first batched solve after work on the handle's own streams: let that finish
-      HIPCHK(h, hipStreamSynchronize(h->order_stream ? h->order_stream : h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->gstream));
+      hipError_t e = hipStreamSynchronize(h->order_stream ? h->order_stream : h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->gstream);
+      if (e != hipSuccess) return poison(fail(h, MPPI_ERR_HIP, "batched solve: stream hand-over", e));
       h->order_stream = S;
     }
     rc = upload_controls_if_dirty(h, S);
-    if (rc) return rc;
+    if (rc) return poison(rc);
     h->seq++;
   }
   for (int it = 0; it < iters; it++) {
@@ -516,7 +541,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
                    : form_is_row(form_of(h0)) ? launch_rollout_row_batch(qb, form_of(h0) == Form::RowTree, S)
                                                 : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
     if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
-    if (e != hipSuccess) return fail(h0, MPPI_ERR_HIP, "batched launch", e);
+    if (e != hipSuccess) return poison(fail(h0, MPPI_ERR_HIP, "batched launch", e));
   }
   for (int i = 0; i < n; i++) {
     hs[i]->explicit_iters = 0;

@@ -277,3 +277,44 @@ def test_batches_the_library_cannot_share_a_launch_for_fall_back_to_per_handle_s
     with pytest.raises(capi.MppiError):
         capi.compute_control_batch([s, s], [states[0], states[0]])
     s.close()
+
+
+@pytest.mark.parametrize("state_kind", ["finite", "inf_x", "nan_speed"])
+def test_a_mixed_batch_equals_the_single_solves_also_for_non_finite_states(state_kind):
+    """One controller on an affine costmap transform without control cost, its partner on a projective transform WITH control
+    cost: a kernel specialised for the superset would compute 0 * x where the single solve computes nothing -- different bits
+    for a non-finite x.  The library shares a launch only between instances of equal specialisation, so this pair is solved
+    one by one and every controller's results are those of its own mppi_compute_control, finite or not."""
+    a = S.make_config(512, 30, track="oval")
+    cost_b = dict(P.DEFAULT_COST, steering_coeff=0.3, throttle_coeff=0.25)
+    b = S.make_config(512, 30, track="oval", cost=cost_b)
+    # a projective costmap transform: third components of the columns non-trivial (costs.cu:373-377 divides by w)
+    b["r_c1"] = (b["r_c1"][0], b["r_c1"][1], 0.001)
+    b["r_c2"] = (b["r_c2"][0], b["r_c2"][1], -0.002)
+    sa, sb = a["start_state"].copy(), b["start_state"].copy()
+    if state_kind == "inf_x":
+        sa[0] = np.inf
+    elif state_kind == "nan_speed":
+        sa[4] = np.nan
+    ref, bat = [capi.Solver(a), capi.Solver(b)], [capi.Solver(a), capi.Solver(b)]
+    for s in ref + bat:
+        s.seed(77, 0)
+    outs = []
+    for pair, batched in ((ref, False), (bat, True)):
+        try:
+            if batched:
+                capi.compute_control_batch(pair, [sa, sb])
+            else:
+                pair[0].compute_control(sa)
+                pair[1].compute_control(sb)
+            outs.append([s.get_results() for s in pair])
+        except capi.MppiError as e:
+            outs.append(("error", e.status))
+    if isinstance(outs[0], tuple) or isinstance(outs[1], tuple):
+        assert outs[0] == outs[1], outs  # the same loud failure both ways
+    else:
+        for r, g in zip(outs[0], outs[1]):
+            for key in ("U", "costs", "w"):
+                np.testing.assert_array_equal(g[key].view(np.uint32), r[key].view(np.uint32), err_msg=key)
+    for s in ref + bat:
+        s.close()
