@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak.py [ticks]: long runs of the latency forms for rare hand-over failures.  Two handles with the same seed run
 `ticks` solve + slide ticks each -- one through mppi_control_ticks, the other through batched ticks with a partner -- and must
-end with bit-identical control sequences; a third pair runs the oct form.  Any starved wave would surface as MPPI_ERR_HIP
+end with bit-identical control sequences; further pairs run the other latency forms (K = 8192, 64-wide nets).  Any starved wave would surface as MPPI_ERR_HIP
 (NaN normaliser); any race in the rings as a difference.  Prints one JSON line."""
 import json
 import os
@@ -16,7 +16,13 @@ from autorally_amd import capi, params as P, synthetic as S  # noqa: E402
 
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 out = {"ticks": ticks}
-for name, kw, K in (("row", {}, 4096), ("row_k1920", {}, 1920), ("oct", dict(zip(("layers", "theta"), P.synthetic_model([6, 64, 64, 4], seed=4))), 2048)):
+def net(layers):
+    return dict(zip(("layers", "theta"), P.synthetic_model(layers, seed=4)))
+
+
+# (the automatic forms: row-tree for 6-32-32-4 up to two groups per CU, the 4x4x1-MFMA form for 64-wide nets)
+for name, kw, K in (("row", {}, 4096), ("row_k1920", {}, 1920), ("row_k8192", {}, 8192), ("h64", net([6, 64, 64, 4]), 2048),
+                    ("h64x4_k1920", net([6, 64, 64, 64, 64, 4]), 1920)):
     cfg = S.make_config(K, 100, track="oval", **kw)
     a, b, partner = capi.Solver(cfg), capi.Solver(cfg), capi.Solver(dict(cfg, seed=77))
     st = cfg["start_state"]
