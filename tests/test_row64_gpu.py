@@ -52,7 +52,8 @@ def _gpu(cfg, U0, eps, variant):
 
 
 CASES = [("h64", 64, 7, "row64_r8"), ("h64", 256, 40, "row64_r8"), ("h64", 256, 40, "row64_r16"), ("h64", 4096, 100, "row64"),
-         ("h64", 2048, 100, "row64"), ("wd", 1920, 100, "row64"), ("wd", 192, 37, "row64_r16"), ("wd", 4096, 60, "row64")]
+         ("h64", 2048, 100, "row64"), ("wd", 1920, 100, "row64"), ("wd", 192, 37, "row64_r16"), ("wd", 4096, 60, "row64"),
+         ("h64", 16384, 150, "row64_r16")]  # BASELINE config 4 at full size: the tuned vector-ALU arm of its MFMA-vs-VALU A/B
 
 
 @pytest.mark.parametrize("model,K,T,variant", CASES)
