@@ -27,7 +27,8 @@ bool form_supported(Form f, int hidden, int n_hidden)
     case Form::Row64R8: case Form::Row64R16: return row64_variant_supported(hidden, n_hidden);
     case Form::Oct: return oct_variant_supported(hidden, n_hidden);
     case Form::Row: case Form::RowTree: return row_variant_supported(hidden, n_hidden);
-    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: return multi_variant_supported(hidden, n_hidden);
+    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
+      return multi_variant_supported(hidden, n_hidden);
     case Form::Quad: case Form::Fused64: case Form::Fused256: return mfma_variant_supported(hidden, n_hidden);
     default: return false;
   }
@@ -56,7 +57,10 @@ const FormRule kFormRules[] = {
     {0, 0, 1, Form::Quad, true, "6-32-32-4 K=4096: quad 71 us, multi1 / multi2 83, single-wave 122 (profiles/r02_*); row_exact 45.8 is not bit-for-bit needed when \"mfma\" is asked for"},
     // up to two: two dynamics waves (whole network each) + cost + control wave, every wave on a SIMD of its own
     {0, 0, 2, Form::Multi2, true, "K=8192: multi2 77-83 us, quad 112, single-wave 123, row at two groups per CU 93; 6-64-64-4 T=150: 277 vs 359 / 339 us"},
-    // beyond: four dynamics waves per workgroup, one per SIMD, riders on the side, eps from the stand-alone generator kernel
+    // beyond: four dynamics waves per workgroup, one per SIMD, riders on the side, eps from the stand-alone generator kernel;
+    // the output layer -- 8 of 28 / 16 of 88 matrix instructions per step for 4 useful rows of a 16-row tile -- as a butterfly
+    // over the four lanes of a rollout (mfma_net.hpp: nn_last_tree; inside the north-star tolerance, tests/test_multi_tree_gpu.py)
+    {0, 0, 0, Form::Multi4Tree, false, "profiles/r04_l_multi4_tree.txt"},
     {0, 0, 0, Form::Multi4, true, "K=16384: 87.5 us (profiles/r03_i_k16384_*) vs 124 single-wave; 6-64-64-4 T=150: 271 us (profiles/r03_d_cfg4_*) vs 341; the in-kernel generator would load one SIMD too much: 341 us"},
     // shapes the multi form does not have (6-64x4-4 beyond two groups per CU): one wave per 16 rollouts does everything, in
     // workgroups of FOUR waves -- the dispatcher spreads a workgroup's waves over the four SIMDs of a CU, whereas 64-thread
@@ -93,7 +97,7 @@ bool form_generator_noise(const mppi_handle *h)
 {
   if (h->forced != Form::Auto) return h->multi_standalone_noise;
   const Form f = form_of(h);
-  return f == Form::Multi4 || f == Form::Multi4U;
+  return f == Form::Multi4 || f == Form::Multi4U || f == Form::Multi4Tree;
 }
 
 // does the rollout kernel draw eps itself (a control / noise wavefront with the in-kernel MRG32k3a)?
@@ -102,7 +106,7 @@ bool has_noise_wave(const mppi_handle *h)
   switch (form_of(h)) {
     case Form::Bf3: case Form::Quad: case Form::Row: case Form::RowTree: case Form::Row64R8: case Form::Row64R16: case Form::M44:
       return true;
-    case Form::Oct: case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U:
+    case Form::Oct: case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
       return !form_generator_noise(h);
     default:
       return false;
@@ -110,7 +114,10 @@ bool has_noise_wave(const mppi_handle *h)
 }
 
 int form_bf_waves(Form f) { return f == Form::Bf3 ? 3 : f == Form::Bf2 ? 2 : 1; }
-int form_multi_nd(Form f) { return f == Form::Multi1 ? 1 : f == Form::Multi2 ? 2 : f == Form::Multi4 ? 4 : 40; }  // 40: multi4u
+int form_multi_nd(Form f)  // launch_rollout_multi's code: 40 = multi4u, 44 = multi4 with the tree output layer
+{
+  return f == Form::Multi1 ? 1 : f == Form::Multi2 ? 2 : f == Form::Multi4 ? 4 : f == Form::Multi4Tree ? 44 : 40;
+}
 int form_fused_threads(Form f) { return f == Form::Quad ? 512 : f == Form::Fused256 ? 256 : 64; }
 
 }  // namespace mppi_abi
@@ -130,6 +137,7 @@ const char *mppi_rollout_variant(const mppi_handle *h)
     case Form::ValuReg: return "valu_reg_lds";
     case Form::ValuLds: return "valu_lds";
     case Form::Multi4U: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi4u%s", h->hidden, h->n_hidden, gen); break;
+    case Form::Multi4Tree: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi4_tree%s", h->hidden, h->n_hidden, gen); break;
     case Form::Multi1: case Form::Multi2: case Form::Multi4:
       snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi%d%s", h->hidden, h->n_hidden, form_multi_nd(f), gen);
       break;
@@ -185,6 +193,12 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     h->forced = Form::Oct;
     h->multi_standalone_noise = name[3] != 0;
   }
+  else if (strcmp(name, "multi4_tree") == 0 || strcmp(name, "multi4_tree_gen") == 0) {  // ND = 4, butterfly output layer
+    if ((rc = need(h->K % 64 == 0, "multi form needs K to be a multiple of 16 ND"))) return rc;
+    if ((rc = need(h->mfma_ok && multi_variant_supported(h->hidden, h->n_hidden), "multi form exists for 6-32x2-4, 6-32x4-4 and 6-64x2-4"))) return rc;
+    h->forced = Form::Multi4Tree;
+    h->multi_standalone_noise = name[11] != 0;
+  }
   else if (strcmp(name, "multi4u") == 0 || strcmp(name, "multi4u_gen") == 0) {  // ND = 4, six waves (one cost wave)
     if ((rc = need(h->K % 64 == 0, "multi form needs K to be a multiple of 16 ND"))) return rc;
     if ((rc = need(h->mfma_ok && multi_variant_supported(h->hidden, h->n_hidden), "multi form exists for 6-32x2-4, 6-32x4-4 and 6-64x2-4"))) return rc;
@@ -224,6 +238,7 @@ int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max
       case Form::RowTree: put("row_tree"); put("row_exact"); break;
       case Form::Quad: put("quad"); break;
       case Form::Multi2: if (h->K % 32 == 0) put("multi2"); break;
+      case Form::Multi4Tree: if (h->K % 64 == 0) put("multi4_tree_gen"); break;
       case Form::Multi4: if (h->K % 64 == 0) put("multi4_gen"); break;
       case Form::Fused256: put("fused"); break;
       default: break;

@@ -44,6 +44,7 @@ enum class Form : int {
   Quad,                             // rollout_mfma.hip: network split over two waves + cost + control wave per 16 rollouts
   Oct,                              // rollout_oct.hip: 64-wide nets, four dynamics waves (one M tile each) + four riders
   Multi1, Multi2, Multi4, Multi4U,  // rollout_multi.hip: ND dynamics waves of 16 rollouts + riders (4U: six waves)
+  Multi4Tree,                       // ... ND = 4 with the output layer as a butterfly over a rollout's four lanes
   Row, RowTree,                     // rollout_row.hip: 6-32-32-4 on the vector ALU; Tree: butterfly output layer
   Row64R8, Row64R16,                // rollout_row64.hip: 64-wide nets on the vector ALU, 8 / 16 rollouts per group
   M44,                              // rollout_m44.hip: 64-wide nets on v_mfma_f32_4x4x1 with A-broadcast

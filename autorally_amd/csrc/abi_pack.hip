@@ -56,7 +56,8 @@ std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int
   const int nA0 = MT * 2, nAH = MT * KSH, nAL = KSH;
   const int nA = nA0 + (NHID - 1) * nAH + nAL;
   const int nBias = NHID * MT * 4 + 4;
-  std::vector<float> out((size_t)(nA + nBias) * 64, 0.0f);
+  const int nTree = 4 * KSH + 1;  // mfma_net.hpp: MfmaTree -- the output layer for the butterfly form, behind the MFMA image
+  std::vector<float> out((size_t)(nA + nBias + nTree) * 64, 0.0f);
   // offsets of W_l / b_l in theta, layers = 6, H x NHID, 4
   std::vector<int> wo, bo, nin, nout;
   int off = 0, prev = kNetIn;
@@ -100,6 +101,10 @@ std::vector<float> pack_mfma_weights(const std::vector<float> &theta, int H, int
         for (int r = 0; r < 4; r++)
           out[(size_t)(nA + l * MT * 4 + m * 4 + r) * 64 + lane] = theta[bo[l] + 16 * m + 4 * r + g];
     for (int r = 0; r < 4; r++) out[(size_t)(nA + NHID * MT * 4 + r) * 64 + lane] = theta[bo[NHID] + r];
+    // tree form of the output layer: lane (j, g) multiplies activation 4 s + g into outputs 0..3; its bias is b3[g]
+    for (int s = 0; s < KSH; s++)
+      for (int o = 0; o < 4; o++) out[(size_t)(nA + nBias + 4 * s + o) * 64 + lane] = theta[wo[NHID] + o * H + 4 * s + g];
+    out[(size_t)(nA + nBias + 4 * KSH) * 64 + lane] = theta[bo[NHID] + g];
   }
   return out;
 }

@@ -87,7 +87,7 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
   hipError_t e = hipSuccess;
   switch (f) {
     case Form::Bf1: case Form::Bf2: case Form::Bf3: e = launch_rollout_bf(a, form_bf_waves(f), h->stream); break;
-    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U:
+    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
       e = launch_rollout_multi(h->hidden, h->n_hidden, a, form_multi_nd(f), h->stream);
       break;
     case Form::Oct: e = launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream); break;

@@ -120,11 +120,80 @@ __device__ __forceinline__ void nn_last(const float (&A)[MfmaNet<H, NHID>::nA],
       act[m * 4 + r + 1] = v.y;
     }
   f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef MPPI_DIAG_NOLAST  // diagnostic build: what do the output layer's KSH matrix instructions cost? (results are garbage)
+  // (every activation stays live: four fma chains over the lane's MT * 4 activations -- about what a per-lane partial of
+  // a butterfly output layer would cost)
+#pragma unroll
+  for (int i = 0; i < MT * 4; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) o[r] = fmaf(act[i], A[aoff + ((i + r) % KSH)], o[r]);
+#else
 #pragma unroll
   for (int s = 0; s < KSH; s++)
     o = __builtin_amdgcn_mfma_f32_16x16x4f32(A[aoff + s], act[s], o, 0, 0, 0);
+#endif
 #pragma unroll
   for (int r = 0; r < 4; r++) d[r] = o[r] + Bi[bl + r];
+}
+
+// piece 3, TREE form (rollout_multi.hip "multi4_tree"): the output layer as a reduction over the four lanes of a rollout
+// instead of KSH matrix instructions on a 16-row tile of which 4 rows are outputs (8 of 28 MFMAs per step at 6-32-32-4,
+// 16 of 88 at 6-64-64-4).  Lane (j, g) holds the activations of neurons 4 s + g, s = 0 .. KSH-1 (k-slot g of k-step s): it
+// multiplies them into the four outputs -- a product and KSH - 1 fused multiply-adds each, s ascending, packed in pairs --
+// and the four lanes' partials are summed by the halving butterfly of rollout_m44.hip: v_permlane32_swap (g < 2 keeps
+// outputs {0, 1}), v_permlane16_swap (even g keeps the first of the pair).  Lane (j, g) ends with output g = the state
+// component layer 0 takes from it.  NOT the reference's summation order (test oracle: fma_mode 4).
+//   wt[2 s] = (W3[0][4s+g], W3[1][4s+g]), wt[2 s + 1] = (W3[2][4s+g], W3[3][4s+g]); bo = b3[g]
+template <int H, int NHID>
+struct MfmaTree {
+  static constexpr int KSH = H / 4;
+  static constexpr int nT = 4 * KSH + 1;  // floats per lane behind the MFMA image in wpack
+};
+template <int H, int NHID>
+__device__ __forceinline__ void load_tree_weights(const float *wpack, int lane, f32x2 (&wt)[2 * MfmaTree<H, NHID>::KSH], float &bo)
+{
+  constexpr int KSH = MfmaTree<H, NHID>::KSH;
+  const float *t = wpack + MfmaNet<H, NHID>::nPack * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < KSH; s++) {
+    wt[2 * s] = f32x2{t[(4 * s + 0) * 64], t[(4 * s + 1) * 64]};
+    wt[2 * s + 1] = f32x2{t[(4 * s + 2) * 64], t[(4 * s + 3) * 64]};
+  }
+  bo = t[4 * KSH * 64];
+}
+template <int H, int NHID>
+__device__ __forceinline__ float nn_last_tree(const f32x2 (&wt)[2 * MfmaTree<H, NHID>::KSH], float bo,
+                                              const float (&Bi)[MfmaNet<H, NHID>::nBias],
+                                              const f32x4 (&acc)[MfmaNet<H, NHID>::MT])
+{
+  using N = MfmaNet<H, NHID>;
+  constexpr int MT = N::MT, KSH = N::KSH;
+  const int boff = (NHID - 1) * MT * 4;
+  float act[MT * 4];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2 v = tanh_bias2(f32x2{acc[m][r], acc[m][r + 1]},
+                                 f32x2{Bi[boff + m * 4 + r], Bi[boff + m * 4 + r + 1]});
+      act[m * 4 + r] = v.x;
+      act[m * 4 + r + 1] = v.y;
+    }
+  f32x2 Q = wt[0] * f32x2{act[0], act[0]}, P = wt[1] * f32x2{act[0], act[0]};
+#pragma unroll
+  for (int s = 1; s < KSH; s++) {
+    Q = __builtin_elementwise_fma(wt[2 * s], f32x2{act[s], act[s]}, Q);
+    P = __builtin_elementwise_fma(wt[2 * s + 1], f32x2{act[s], act[s]}, P);
+  }
+  {
+    auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(Q.x), __float_as_uint(P.x), false, false);
+    auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(Q.y), __float_as_uint(P.y), false, false);
+    Q = f32x2{__uint_as_float(x[0]), __uint_as_float(y[0])};
+    P = f32x2{__uint_as_float(x[1]), __uint_as_float(y[1])};
+  }
+  const f32x2 r = Q + P;
+  auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(r.x), __float_as_uint(r.y), false, false);
+  return (__uint_as_float(z[0]) + __uint_as_float(z[1])) + bo;
 }
 
 // d[0..3] = NN(s3..s6, u0, u1) for the lane's rollout; every lane of the rollout gets all four.

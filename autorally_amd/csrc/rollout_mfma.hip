@@ -723,7 +723,7 @@ bool mfma_variant_supported(int hidden, int n_hidden)
 int mfma_pack_floats_per_lane(int hidden, int n_hidden)
 {
   const int MT = hidden / 16, KSH = hidden / 4;
-  return MT * 2 + (n_hidden - 1) * MT * KSH + KSH + n_hidden * MT * 4 + 4;
+  return MT * 2 + (n_hidden - 1) * MT * KSH + KSH + n_hidden * MT * 4 + 4 + (4 * KSH + 1);  // + the tree image (mfma_net.hpp: MfmaTree)
 }
 
 hipError_t launch_rollout_mfma(int hidden, int n_hidden, const RolloutArgs &a, int block_threads,

@@ -77,7 +77,9 @@ __device__ unsigned long long g_multi_stamps[8];
 #define MSTAMP(var) do { } while (0)
 #endif
 
-template <int H, int NHID, int ND, class SH>
+// TREE: the output layer as a butterfly over the four lanes of a rollout (mfma_net.hpp: nn_last_tree) instead of KSH matrix
+// instructions; a lane then carries ONE state component, s[3 + g] -- exactly the layer-0 operand it feeds
+template <int H, int NHID, int ND, class SH, bool TREE = false>
 __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, const int w)
 {
   using N = MfmaNet<H, NHID>;
@@ -86,9 +88,16 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
   const int T = a.T;
   float A[N::nA], Bi[N::nBias];
   load_weights<H, NHID>(a.wpack, lane, A, Bi);
+  f32x2 wt[2 * MfmaTree<H, NHID>::KSH];
+  float bo = 0.0f;
+  if constexpr (TREE) {
+    load_tree_weights<H, NHID>(a.wpack, lane, wt, bo);
+#pragma unroll
+    for (int i = 0; i < 2 * MfmaTree<H, NHID>::KSH; i++) asm volatile("" : "+v"(wt[i]));
+  }
   // pinned: the waits for these loads sit here, not (one s_waitcnt vmcnt per first use) inside the T loop
 #pragma unroll
-  for (int i = 0; i < N::nA; i++) asm volatile("" : "+v"(A[i]));
+  for (int i = 0; i < (TREE ? N::nA - N::nAL : N::nA); i++) asm volatile("" : "+v"(A[i]));
 #pragma unroll
   for (int i = 0; i < N::nBias; i++) asm volatile("" : "+v"(Bi[i]));
 
@@ -104,6 +113,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
   const lds_float_p p_b1 = (lds_float_p)&sh.ctl_b1[0][w][lane];
 
   float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
+  float sv = a.state[3 + g];  // TREE: this lane's component
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == 1 + w);
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   // (s_setprio 3 here -- issue priority over the cost / control wave sharing this wave's SIMD -- changes nothing:
@@ -133,7 +143,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
     const float b1 = b1_next;  // [u0, u1, 0, 0][g] after the clamp (control wave)
     // k-step 0 of layer 0 needs the state only: its MFMAs go first, and the step's LDS traffic below is issued
     // in their shadow instead of in front of the chain
-    const float b0 = row_sel(g, s3, s4, s5, s6);
+    const float b0 = TREE ? sv : row_sel(g, s3, s4, s5, s6);
     f32x4 acc[N::MT];
 #pragma unroll
     for (int m = 0; m < N::MT; m++)
@@ -152,12 +162,16 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
 #pragma unroll
     for (int m = 0; m < N::MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m * 2 + 1], b1, acc[m], 0, 0, 0);
     nn_hidden<H, NHID>(A, Bi, acc);
-    float d[4];
-    nn_last<H, NHID>(A, Bi, acc, d);
-    s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
-    s4 = fmaf(d[1], a.dt, s4);
-    s5 = fmaf(d[2], a.dt, s5);
-    s6 = fmaf(d[3], a.dt, s6);
+    if constexpr (TREE) {
+      sv = fmaf(nn_last_tree<H, NHID>(wt, bo, Bi, acc), a.dt, sv);  // incrementState, neural_net_model.cu:334-344
+    } else {
+      float d[4];
+      nn_last<H, NHID>(A, Bi, acc, d);
+      s3 = fmaf(d[0], a.dt, s3);  // incrementState, neural_net_model.cu:334-344
+      s4 = fmaf(d[1], a.dt, s4);
+      s5 = fmaf(d[2], a.dt, s5);
+      s6 = fmaf(d[3], a.dt, s6);
+    }
 
     MSTAMP(m2);
     __builtin_amdgcn_sched_barrier(0);  // ... and their first use down here, behind the network
@@ -178,7 +192,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
     mprev = m3;
 #endif
   }
-  record(T - 1, row_sel(g, s3, s4, s5, s6));
+  record(T - 1, TREE ? sv : row_sel(g, s3, s4, s5, s6));
 #ifdef MPPI_STAMPS
   if (blockIdx.x == 0 && w == 0 && lane == 0)
     for (int i = 0; i < 6; i++) g_multi_stamps[i] = ma[i];
@@ -191,7 +205,7 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
 // and one rider per SIMD.  For 64-wide nets beyond one group per SIMD (K > 16384): the eight-wave form needs 172
 // VGPRs = two waves per SIMD = ONE workgroup per CU, and a second round of workgroups simply doubles the time
 // (K=32768, T=150, 6-64-64-4: 0.547 ms = 2 x 0.272).
-template <int H, int NHID, int ND, bool SPLIT_ = (ND == 4)>
+template <int H, int NHID, int ND, bool SPLIT_ = (ND == 4), bool TREE = false>
 __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLIT_) ? 3 : 1) void rollout_multi_kernel(const RolloutArgs a)
 {
   using SH = MultiShared<ND, SPLIT_>;
@@ -231,7 +245,7 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
   __syncthreads();
 
   if (role < ND) {
-    multi_dynamics<H, NHID, ND, SH>(a, sh, role);
+    multi_dynamics<H, NHID, ND, SH, TREE>(a, sh, role);
   } else if (role == kCtl) {
     // -------------------------------- control wave: one lane per rollout --------------------------------
     const bool inl = a.inline_noise != 0;
@@ -505,7 +519,8 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
 template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (nd == 40) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, false>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
+  if (nd == 44) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, true, true>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);  // tree output layer
+  else if (nd == 40) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, false>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
   else if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
   else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
   else if (nd == 1) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
@@ -522,7 +537,7 @@ bool multi_variant_supported(int hidden, int n_hidden)
 
 hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (a.K % (16 * (nd == 40 ? 4 : nd)) != 0) return hipErrorInvalidValue;  // nd = 40: ND = 4, six-wave form
+  if (a.K % (16 * (nd >= 40 ? 4 : nd)) != 0) return hipErrorInvalidValue;  // nd = 40: ND = 4, six-wave form; 44: ND = 4, tree output layer
   if (hidden == 32 && n_hidden == 2) return launch_multi_t<32, 2>(a, nd, stream);
   if (hidden == 64 && n_hidden == 2) return launch_multi_t<64, 2>(a, nd, stream);
   if (hidden == 32 && n_hidden == 4) return launch_multi_t<32, 4>(a, nd, stream);

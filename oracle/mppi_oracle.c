@@ -96,6 +96,20 @@ static float out_tree_dot_m44(const float *w, const float *a)
   return L3[0] + L3[1];
 }
 
+/* fma_mode 4: the OUTPUT layer in the order of the multi4-tree kernel (autorally_amd/csrc/mfma_net.hpp: nn_last_tree): four
+ * interleaved chains, chain g over the inputs 4 s + g, s ascending (a product, then fused multiply-adds), summed as
+ * (P[0] + P[2]) + (P[1] + P[3]).  Like modes 2, 3: everything else as fma_mode 1, and NOT the reference's order. */
+static float out_tree_dot_multi(const float *w, const float *a, int nin)
+{
+  float P[4];
+  for (int g = 0; g < 4; g++) {
+    float z = w[g] * a[g];
+    for (int s = 1; s < nin / 4; s++) z = fmaf(w[4 * s + g], a[4 * s + g], z);
+    P[g] = z;
+  }
+  return (P[0] + P[2]) + (P[1] + P[3]);
+}
+
 /* PI/neural_net_model.cu:357-410.  k ascending, bias added after the dot product (:389-394). */
 void orc_nn_forward(const float *theta, const int *layers, int n_layers, const float *in,
                     float *out, int fma_mode)
@@ -112,6 +126,7 @@ void orc_nn_forward(const float *theta, const int *layers, int n_layers, const f
       float tmp = 0.0f;
       if (fma_mode == 2 && l == n_layers - 2 && (nin == 32 || nin == 64)) tmp = out_tree_dot(W + j * nin, cur, nin);
       else if (fma_mode == 3 && l == n_layers - 2 && nin == 64) tmp = out_tree_dot_m44(W + j * nin, cur);
+      else if (fma_mode == 4 && l == n_layers - 2 && nin % 4 == 0) tmp = out_tree_dot_multi(W + j * nin, cur, nin);
       else for (int k = 0; k < nin; k++) tmp = mac(W[j * nin + k], cur[k], tmp, fma_mode);
       tmp += b[j];
       if (l < n_layers - 2) tmp = tanhf(tmp); /* MPPI_NNET_NONLINEARITY, :35 */

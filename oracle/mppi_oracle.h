@@ -70,7 +70,8 @@ typedef struct {
   const float *map_rgba; /* float4[H][W], x fastest, costs.cu:206-216 */
   int fma_mode;       /* 1: nvcc-style FMA contraction (nominal), 0: none,
                          2: as 1 with the output layer summed in the row-tree kernels' order (mppi_oracle.c: out_tree_dot),
-                         3: as 1 with the output layer in the 4x4x1-MFMA kernel's order (out_tree_dot_m44) */
+                         3: as 1 with the output layer in the 4x4x1-MFMA kernel's order (out_tree_dot_m44),
+                         4: as 1 with the output layer in the multi4-tree kernel's order (out_tree_dot_multi) */
   int nthreads;       /* OpenMP threads for the k loop; <=1 = serial */
   /* Second dynamics family: GeneralizedLinear<CarBasisFuncs,7,2,25,CarKinematics,3>,
    * PI/generalized_linear.cu:169-245 + PI/car_bfs.cuh:44-120.  bf_W != NULL selects it (theta/layers

@@ -5,6 +5,17 @@ from autorally_amd import synthetic as S
 from oracle import oracle as O
 
 
+def oracle_mode_for(variant_name):
+    """The oracle's arithmetic mode (orc_problem.fma_mode) that states the summation order of a kernel form, by the name
+    mppi_rollout_variant gives it: 1 = the reference's order in every layer (every "exact" form); the tree forms re-associate
+    the OUTPUT layer only -- 2: row-tree / row64 butterflies, 3: the 4x4x1-MFMA form, 4: the multi4-tree form."""
+    if "m44" in variant_name:
+        return 3
+    if "multi4_tree" in variant_name:
+        return 4
+    return 2 if "_tree" in variant_name else 1
+
+
 def noise_for(cfg, seed=1234, iters=None):
     """Explicit eps[num_iters][K][T][2] from the oracle's statement of the noise spec."""
     it = int(cfg.get("num_iters", 1)) if iters is None else iters

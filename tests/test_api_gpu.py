@@ -190,9 +190,11 @@ def test_baseline_config4_full_size_parity():
     against the CPU oracle's complete solve (mppi_controller.cu:600-675; it needs a few seconds on 8-16
     threads) with the criteria of test_rollout_costs_and_controls: applied controls bit-exact, cost p99 < 5e-6,
     flipped rollouts <= K/200 moving < 1e-4 of the weight mass, U L-inf <= 1e-4, trajectory cost rel <= 1e-4.
-    The automatic form (multi4 + generator kernel) on explicit noise AND in generator mode (the device's own
-    MRG32k3a draws against O.generate_noise); the other kernel forms must equal it bit for bit; plus the
-    size-independent properties (softmax, hull, float64 weighted mean)."""
+    The multi4 form + generator kernel on explicit noise; the other exact kernel forms must equal it bit for bit; the
+    AUTOMATIC form (round 4: multi4 with the output layer as a butterfly, "multi4_tree_gen") against its own oracle mode (4)
+    at the same criteria and against the nominal oracle at the north-star ones, on explicit noise AND in generator mode (the
+    device's own MRG32k3a draws against O.generate_noise); plus the size-independent properties (softmax, hull, float64
+    weighted mean)."""
     K, T = 16384, 150
     layers, theta = P.synthetic_model([6, 64, 64, 4], seed=4)
     cfg = S.make_config(K, T, layers=layers, theta=theta, track="oval")
@@ -202,6 +204,8 @@ def test_baseline_config4_full_size_parity():
     eps = rng.standard_normal((1, K, T, 2)).astype(np.float32)
     orc = O.Oracle(cfg, fma_mode=1, nthreads=16)
     ref = orc.compute_control(cfg["start_state"], U0, hist, eps)
+    orc4 = O.Oracle(cfg, fma_mode=4, nthreads=16)  # the butterfly's summation order (tests/helpers.py: oracle_mode_for)
+    ref4 = orc4.compute_control(cfg["start_state"], U0, hist, eps)
 
     def check(got, ref, what):
         np.testing.assert_array_equal(got["V"].view(np.uint32), ref["V"][-1].view(np.uint32), err_msg=what)
@@ -213,7 +217,7 @@ def test_baseline_config4_full_size_parity():
         assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"]), what
 
     outs = {}
-    for variant in ("auto", "quad", "fused", "multi4", "multi4u_gen"):
+    for variant in ("auto", "multi4_gen", "quad", "fused", "multi4", "multi4u_gen"):
         sol = capi.Solver(cfg)
         sol.set_rollout_variant(variant)
         sol.set_control_seq(U0)
@@ -229,10 +233,17 @@ def test_baseline_config4_full_size_parity():
                 sol.compute_control(cfg["start_state"])
                 gen = dict(sol.get_results(), V=sol.get_applied_controls())
                 eps_g = O.generate_noise(4321, 2 * T * it, K, T)[None]
-                check(gen, orc.compute_control(cfg["start_state"], U0, hist, eps_g), "generator mode, solve %d" % it)
+                check(gen, orc4.compute_control(cfg["start_state"], U0, hist, eps_g), "generator mode, solve %d" % it)
+                nom = orc.compute_control(cfg["start_state"], U0, hist, eps_g)
+                assert np.max(np.abs(gen["U"] - nom["U"])) <= 1e-4 and abs(gen["traj_cost"] - nom["traj_cost"]) <= 1e-4 * abs(nom["traj_cost"])
         sol.close()
-    a = outs["auto"]
-    # auto: four dynamics waves + pose / fetch / cost / control waves per 64 rollouts, eps from the generator kernel
+    t = outs["auto"]
+    # auto: four dynamics waves + pose / fetch / cost / control waves per 64 rollouts, eps from the generator kernel, butterfly output
+    assert "multi4_tree_gen" in t["name"]
+    check(t, ref4, "tree form, explicit noise, its own oracle mode")
+    assert np.max(np.abs(t["U"] - ref["U"])) <= 1e-4 and abs(t["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"])
+    assert int(np.sum(rel_err(t["costs"], ref["costs"]) > 1e-4)) <= K // 200
+    a = outs["multi4_gen"]
     assert "multi4_gen" in a["name"] and "quad" in outs["quad"]["name"] and "fused" in outs["fused"]["name"]
     check(a, ref, "explicit noise")
     # non-degenerate: most rollouts stay on the track and the weights are spread
@@ -396,7 +407,7 @@ def test_prefetched_generator_draws_are_the_right_ones():
     cfg = S.make_config(K, T, track="oval")
     gen = capi.Solver(dict(cfg, seed=77))
     ref = capi.Solver(dict(cfg, seed=77))
-    assert "multi4_gen" in gen.rollout_variant()
+    assert "multi4" in gen.rollout_variant() and gen.rollout_variant().endswith("_gen")
     x = cfg["start_state"]
 
     def both(offset, label):
@@ -424,10 +435,14 @@ def test_prefetched_generator_draws_are_the_right_ones():
     np.testing.assert_array_equal(gen.get_control_seq().view(np.uint32), ref.get_control_seq().view(np.uint32))
     both(10 * T, "after an explicit-noise solve")
     # a form with its own noise wavefront takes over the prefetched draws, then continues the stream itself
-    gen.set_rollout_variant("quad")
+    # (the reference handle follows: the quad form keeps the reference's summation order, the automatic form at this K sums
+    # the output layer as a butterfly -- equal draws, not equal bits, between the two)
+    for s in (gen, ref):
+        s.set_rollout_variant("quad")
     both(12 * T, "quad form, prefetched draws")
     both(14 * T, "quad form, in-kernel generator")
-    gen.set_rollout_variant("auto")
+    for s in (gen, ref):
+        s.set_rollout_variant("auto")
     both(16 * T, "back to the generator kernel")
     # re-seeding discards what was prefetched
     gen.seed(123, 10)

@@ -16,7 +16,7 @@ from autorally_amd import capi
 from autorally_amd import params as P
 from autorally_amd import synthetic as S
 from oracle import oracle as O
-from tests.helpers import load_nn_golden, noise_for, rel_err, warm_U
+from tests.helpers import load_nn_golden, noise_for, oracle_mode_for, rel_err, warm_U
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def _built():
 def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
     """HIP solve and the oracle on the same inputs.  The oracle runs in the arithmetic mode of the kernel form that served
     the solve: mode 1 (the reference's summation order) for every form but the tree forms, whose output layer is summed as
-    a butterfly (row-tree / row64: mode 2, the 4x4x1-MFMA form: mode 3) -- for those the NOMINAL oracle's U / trajectory cost / costs come along as ref["nominal"] and
+    a butterfly (tests/helpers.py: oracle_mode_for) -- for those the NOMINAL oracle's U / trajectory cost / costs come along as ref["nominal"] and
     every caller's north-star criteria are checked against them here."""
     eps = noise_for(cfg, seed)
     U0 = np.zeros((cfg["T"], 2), np.float32) if U0 is None else U0
@@ -52,7 +52,7 @@ def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
     sol.close()
     tree = "_tree" in got["variant"]
     iters = cfg.get("num_iters", 1)
-    mode = 3 if "m44" in got["variant"] else (2 if tree else 1)  # the output layer's summation order of the form that ran
+    mode = oracle_mode_for(got["variant"])  # the output layer's summation order of the form that ran
     ref = O.Oracle(cfg, fma_mode=mode, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
     if tree:
         nom = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)

@@ -14,6 +14,7 @@ An iteration outside that is then classified, in this order:
   BAD              none of these: a candidate for a named regression test or a fix.
 Third argument "row" / "row_tree": only the draws the vector-ALU row form serves (6-32-32-4, at most one group per CU), on
 that form ("row_tree": against the NOMINAL oracle, i.e. the north-star tolerance for the re-associated output layer);
+"multi4_tree[_gen]": the draws of the shapes the multi form has, forced onto its butterfly-output form, against the nominal oracle;
 "m44": only the 64-wide draws (6-64-64-4, 6-64-64-64-64-4, K <= 4096) on the 4x4x1-MFMA form, likewise against the nominal oracle.
 Prints one line per draw that needed a classification and a summary; exit code 1 if any draw is BAD."""
 import os
@@ -30,8 +31,11 @@ from tests.helpers import solve_with_iterations, teacher_forced_iterations  # no
 gd = os.path.join(ROOT, "tests", "golden")
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 only_row = sys.argv[3] if len(sys.argv) > 3 else None
-assert only_row in (None, "row", "row_tree", "m44")
-WANT = ([6, 64, 64, 4], [6, 64, 64, 64, 64, 4]) if only_row == "m44" else ([6, 32, 32, 4],)
+assert only_row in (None, "row", "row_tree", "m44", "multi4_tree", "multi4_tree_gen")
+WANT = {"m44": ([6, 64, 64, 4], [6, 64, 64, 64, 64, 4]),
+        "multi4_tree": ([6, 32, 32, 4], [6, 32, 32, 32, 32, 4], [6, 64, 64, 4]),
+        "multi4_tree_gen": ([6, 32, 32, 4], [6, 32, 32, 32, 32, 4], [6, 64, 64, 4])}.get(only_row, ([6, 32, 32, 4],))
+KMAX = 1 << 30 if (only_row or "").startswith("multi4") else 4096  # the latency forms serve up to 4096 (8192) rollouts
 n_draws = n_iter = bad = conditioned = granular = illcond = 0
 worst_clean, worst_any, forms = 0.0, 0.0, {}
 for seed in range(lo, hi):
@@ -42,11 +46,11 @@ for seed in range(lo, hi):
         K_ = 64 * int(r.choice([1, 2, 3, 5, 8, 16, 17, 32, 64, 65, 100]))
         r.choice([2, 3, 5, 9, 16, 20, 33, 47, 60, 100])
         lay = F.LAYERS[r.randint(len(F.LAYERS))]
-        if (lay if lay is not None else [6, 32, 32, 4]) not in WANT or K_ > 4096:
+        if (lay if lay is not None else [6, 32, 32, 4]) not in WANT or K_ > KMAX:
             continue
     cfg, variant, hist = F._draw(gd, seed)
     if only_row:
-        if cfg.get("bf_W") is not None or list(cfg["layers"]) not in WANT or cfg["K"] > 4096:
+        if cfg.get("bf_W") is not None or list(cfg["layers"]) not in WANT or cfg["K"] > KMAX:
             continue
         variant = only_row
     iters = cfg["num_iters"]
