@@ -249,23 +249,22 @@ int mppi_debug_cost_raster(mppi_handle *h, float x, float y, float heading, int 
 int mppi_enable_stage_timing(mppi_handle *h, int on);
 int mppi_reset_stage_times(mppi_handle *h);
 int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
-/* Name of the rollout kernel variant in use: "valu_row8w_h32_l2" (6-32-32-4 up to one group of 16 rollouts per CU: the
- * recurrence on the vector ALU, four dynamics wavefronts of four rollouts + pose, cost, control and noise wavefront),
- * "mfma16x16x4_h32_l2_quad4w" (four wavefronts per 16
- * rollouts), "..._oct8w[_gen]" (eight, 64-wide nets), "..._multi{1,2,4}[_gen]", "..._fused_b256" / "_b64" (one
- * wavefront per 16 rollouts), "valu_reg_lds", "valu_lds", "basis_funcs25_valu[_2w|_3w]". */
+/* Name of the rollout kernel form in use.  Forms that keep the reference's k-ascending sums in EVERY layer (bit-identical to
+ * one another): "mfma16x16x4_h<H>_l<N>_quad4w" | "_oct8w[_gen]" | "_multi{1,2,4}[_gen]" | "_multi4u[_gen]" | "_fused_b256" |
+ * "_fused_b64", "valu_row8w_h32_l2" (row form, exact output chain), "valu_reg_lds", "valu_lds",
+ * "basis_funcs25_valu[_2w|_3w]".  Forms whose OUTPUT layer is summed as a butterfly over lanes (hidden layers unchanged; inside
+ * the 1e-4 tolerance on the controls, not bit-identical to the former): "valu_row8w_tree_h32_l2" (6-32-32-4 up to 8192
+ * rollouts: the automatic choice), "mfma4x4x1_h64_l<N>_m44_tree" (64-wide nets up to 8192 rollouts: automatic),
+ * "mfma16x16x4_h<H>_l<N>_multi4_tree[_gen]" (beyond: automatic), "valu_row64_r{8,16}_tree_h64_l<N>" (opt-in). */
 const char *mppi_rollout_variant(const mppi_handle *h);
-/* Force a variant (A/B of SURVEY cfg 4 and of the kernel forms): "auto"; "mfma" | "valu" | "valu_lds"
- * (arithmetic unit: "mfma" keeps the matrix-instruction forms at every K, "valu" / "valu_lds" are the throughput-style
- * vector kernels); "row" = "row_exact" (the vector-ALU latency form, 6-32-32-4 only) | "row_tree" (the same with the OUTPUT layer summed as
- * per-lane partials + a butterfly instead of the reference's k-ascending chain: not bit-identical to the other forms, held to
- * the 1e-4 tolerance on the controls; tests/test_row_tree_gpu.py); form of the MFMA kernel: "quad" (network split over two wavefronts + cost + control
- * wavefront per 16 rollouts) | "multi4" | "multi2" | "multi1" (ND dynamics wavefronts of 16 rollouts + one
- * cost + one control wavefront; "_gen" appended: eps from the stand-alone generator kernel) | "oct" | "oct_gen"
- * (64-wide nets: four dynamics wavefronts, one M tile each, + pose, cost, control, noise wavefront per 16
- * rollouts) | "fused" = "block256" | "block64" (one wavefront per 16 rollouts does everything; workgroups of 4
- * or 1 waves).  Basis-function model: "bf3" (dynamics + cost + control wavefront per 64 rollouts) | "quad"
- * (dynamics + cost) | "fused" (one).  MPPI_ERR_UNSUPPORTED if the handle's model has no such form. */
+/* Force a form (A/B of SURVEY cfg 4 and of the kernel forms): "auto" (the selection table of csrc/abi_forms.hip);
+ * "mfma" (the table restricted to forms that keep the reference's summation order in every layer) | "valu" | "valu_lds" (the
+ * throughput-style vector kernels); by name: "row" = "row_exact" | "row_tree" (6-32-32-4 on the vector ALU), "m44" (64-wide
+ * nets on v_mfma_f32_4x4x1), "row64" | "row64_r8" | "row64_r16" (64-wide nets on the vector ALU, weights from LDS), "quad",
+ * "oct" | "oct_gen", "multi4" | "multi2" | "multi1" ("_gen" appended: eps from the stand-alone generator kernel),
+ * "multi4_tree[_gen]", "multi4u[_gen]", "fused" = "block256" | "block64".  Basis-function model: "bf3" (dynamics + cost +
+ * control wavefront per 64 rollouts) | "quad" (dynamics + cost) | "fused" (one).  MPPI_ERR_UNSUPPORTED if the handle's model
+ * has no such form; a form name given to a handle whose model runs on the generic vector kernel is accepted and ignored. */
 int mppi_set_rollout_variant(mppi_handle *h, const char *name);
 
 /* Test hook (not part of the drop-in surface): d/dt of n independent (state[7], control[2])
