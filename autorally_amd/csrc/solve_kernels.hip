@@ -214,6 +214,14 @@ struct TailArgs {
 
 // body of solve_tail_kernel for workgroup `block` of the instance `a` (the batched kernel passes blockIdx.x minus
 // the instance's first workgroup)
+// CV: float4 of the cost vector a thread holds when the workgroup computes beta and eta itself (a.pre == 0): 4 covers
+// K <= 4096 (one chunk per row: the latency path, untouched since round 2), 8 covers K <= 8192 ("wide": rows of two chunks,
+// every workgroup still recomputes beta and eta from all K costs -- 32 KB of L2 reads and 32 exps per thread -- which saves
+// the one-workgroup weights_kernel in front: K = 8192 19.3 -> 15 us behind the rollout kernel.  With 16 float4 it would reach
+// K = 16384, measured: K=16384 T=100 23.8 -> 21.3 us, but T=150 30.0 -> 32.2 us -- the longer workgroups cost what the
+// removed kernel saved; so beyond 8192 the weights come from weights_kernel as before.)
+constexpr int kWideK = 8192;
+template <int CV>
 __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int block)
 {
   // chunk rows padded by 2 floats per 64-rollout group: lanes of one wave (m varies) hit
@@ -275,7 +283,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   } else {
     // The K <= kRedChunk costs, 16 per thread, are requested with four 16-B loads that are in flight
     // together (and together with the row above): one memory round trip for the min and the exp pass.
-    constexpr int kCostV = kRedChunk / 4 / kTailThreads;
+    constexpr int kCostV = CV;
     const float4 *c4 = reinterpret_cast<const float4 *>(a.costs);
     const int K4 = K / 4;
     float4 cv[kCostV];
@@ -298,18 +306,36 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
         const float e1 = expf(-a.gamma * (cv[i].y - beta));
         const float e2 = expf(-a.gamma * (cv[i].z - beta));
         const float e3 = expf(-a.gamma * (cv[i].w - beta));
-        float *wt = &wtile[k + (k >> 6)];
-        wt[0] = e0; wt[1] = e1; wt[2] = e2; wt[3] = e3;
+        if (CV == kRedChunk / 4 / kTailThreads || (k >= base && k < base + n)) {  // (wide: only this workgroup's chunk is staged)
+          const int kl = k - base;
+          float *wt = &wtile[kl + (kl >> 6)];
+          wt[0] = e0; wt[1] = e1; wt[2] = e2; wt[3] = e3;
+        }
+        if (CV != kRedChunk / 4 / kTailThreads) cv[i] = make_float4(e0, e1, e2, e3);  // kept for the extra workgroup below
         part += (e0 + e1) + (e2 + e3);
       }
     }
     eta = block_sum(part, red, &bc);
     if (extra) {
       float tc = 0.0f;
-      for (int k = tid; k < K; k += kTailThreads) {
-        const float e = wtile[k + (k >> 6)];
-        a.w[k] = e;
-        tc += e * e / eta;  // :651 (Q8)
+      if (CV == kRedChunk / 4 / kTailThreads) {
+        for (int k = tid; k < K; k += kTailThreads) {
+          const float e = wtile[k + (k >> 6)];
+          a.w[k] = e;
+          tc += e * e / eta;  // :651 (Q8)
+        }
+      } else {  // wide: the weights are in this thread's registers
+#pragma unroll
+        for (int i = 0; i < kCostV; i++) {
+          const int q = i * kTailThreads + tid;
+          if (q < K4) {
+            reinterpret_cast<float4 *>(a.w)[q] = cv[i];
+            tc += cv[i].x * cv[i].x / eta;
+            tc += cv[i].y * cv[i].y / eta;
+            tc += cv[i].z * cv[i].z / eta;
+            tc += cv[i].w * cv[i].w / eta;
+          }
+        }
       }
       const float traj = block_sum(tc, red, &bc);
       if (tid == 0) {
@@ -458,7 +484,11 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
 
 __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs a)
 {
-  solve_tail_body(a, (int)blockIdx.x);
+  solve_tail_body<kRedChunk / 4 / kTailThreads>(a, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(kTailThreads) void solve_tail_wide_kernel(const TailArgs a)  // kRedChunk < K <= kWideK, a.pre == 0
+{
+  solve_tail_body<kWideK / 4 / kTailThreads>(a, (int)blockIdx.x);
 }
 
 // The tails of several instances (K <= kRedChunk each: T + 1 workgroups per instance) in one launch, behind
@@ -474,7 +504,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const Ta
   // argument segment (rollout_row.hip: rollout_row_batch_kernel)
   const TailArgs a = b.inst[blockIdx.y];  // a copy (a reference makes the body re-read its parameters from the segment)
   if ((int)blockIdx.x > a.T) return;
-  solve_tail_body(a, (int)blockIdx.x);
+  solve_tail_body<kRedChunk / 4 / kTailThreads>(a, (int)blockIdx.x);
 }
 
 // slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
@@ -590,7 +620,7 @@ static TailArgs fill_tail(const TailLaunch &l)
   a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res;
   a.counter = l.counter; a.part = l.part;
   a.K = l.K; a.T = l.T; a.gamma = l.gamma; a.last_iter = l.last_iter; a.seq = l.seq;
-  a.pre = (l.K > kRedChunk) ? 1 : 0;
+  a.pre = (l.K > kWideK) ? 1 : 0;  // beyond: beta, eta and w[] from weights_kernel
   return a;
 }
 
@@ -603,7 +633,10 @@ hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
   if (a.pre)
     hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, l.costs, l.w, l.scal, K, l.gamma,
                        l.last_iter ? l.res : nullptr, T, l.seq);
-  hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a);
+  if (K > kRedChunk && !a.pre)
+    hipLaunchKernelGGL(solve_tail_wide_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a);
+  else
+    hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a);
   return hipGetLastError();
 }
 
