@@ -21,7 +21,7 @@ def net(layers):
 
 
 # (the automatic forms: row-tree for 6-32-32-4 up to two groups per CU, the 4x4x1-MFMA form for 64-wide nets)
-for name, kw, K in (("row", {}, 4096), ("row_k1920", {}, 1920), ("row_k8192", {}, 8192), ("h64", net([6, 64, 64, 4]), 2048),
+for name, kw, K in (("row", {}, 4096), ("row_k1920", {}, 1920), ("row_k8192", {}, 8192), ("multi4_tree_k16384", {}, 16384), ("h64", net([6, 64, 64, 4]), 2048),
                     ("h64x4_k1920", net([6, 64, 64, 64, 64, 4]), 1920)):
     cfg = S.make_config(K, 100, track="oval", **kw)
     a, b, partner = capi.Solver(cfg), capi.Solver(cfg), capi.Solver(dict(cfg, seed=77))
