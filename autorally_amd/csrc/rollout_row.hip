@@ -13,7 +13,8 @@
 //     bias afterwards) -- bit-identical to every other form -- with the activation a_k broadcast to both halves of the
 //     packed multiply-add (op_sel);
 //   * the activations of a layer never leave the registers: `row_newbcast:q` of the DPP hands every lane of a row the
-//     value of lane q, one v_mov_b32_dpp per k, issued in the shadow of the multiply-add of k-1 (round 3, second half;
+//     value of lane q, one v_mov_b64_dpp per PAIR of k (round 4; one v_mov_b32_dpp per k before), issued in the shadow of
+//     the multiply-adds (round 3, second half;
 //     before that a layer's activations went through LDS -- one 8-B write and eight 16-B broadcast reads per lane and layer:
 //     tools/ub/row_bcast_ub.hip measures the recurrence alone on a SIMD at 865 cycles per step against 1 120).  No other
 //     wave is involved: no sequence word, no poll, no barrier on the recurrence;
@@ -117,39 +118,46 @@ __device__ __forceinline__ void row_load(const float *rowpack, int p, RowWeights
   }
 }
 
-// The activation of neuron k of this lane's rollout, from the registers of the lane that computed it: a rollout is one
-// 16-lane DPP row, `row_newbcast:q` hands every lane of a row the value of lane q (one v_mov_b32_dpp per k, off the
-// dependent chain).  gfx90a+ DPP control 0x150 + q; works on 32-bit operands on gfx950 (tools/ub/row_bcast_ub.hip checks
-// the bits against the LDS form).
+// A value of this lane's rollout from the registers of the lane that holds it: a rollout is one 16-lane DPP row,
+// `row_newbcast:q` hands every lane of a row the value of lane q (off the dependent chain).  gfx90a+ DPP control 0x150 + q;
+// works on 32-bit operands on gfx950 (tools/ub/row_bcast_ub.hip checks the bits against the LDS form) and on 64-bit ones
+// (row_bc2 below).  This 32-bit form brings the state components to layer 0.
 template <int Q>
 __device__ __forceinline__ float row_bc(float a)
 {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0x150 + Q, 0xF, 0xF, false));
 }
-// z = sum_k w[k] * a[k] over the 32 activations of the rollout (lane q holds a[2q], a[2q+1]), k ascending.  Written as the
-// schedule it has to be: the move for k+1, then the multiply-add of k -- a dependent v_pk_fma_f32 can issue every ~9 cycles,
-// the move fills the slot in between -- and held there by scheduling barriers (left alone inside the kernel, the scheduler
-// hoists all 32 moves in front of the chain: ~130 cycles more per layer).
-template <int K>
-__device__ __forceinline__ float row_bc_k(f32x2 a)
+// z = sum_k w[k] * a[k] over the 32 activations of the rollout (lane q holds a[2q], a[2q+1]), k ascending: ONE chain of
+// dependent v_pk_fma_f32 (8.5 cycles apart, tools/ub/valu_issue_ub.hip).  The PAIR of lane q comes by one v_mov_b64_dpp
+// `row_newbcast:q` (the 64-bit move takes the same DPP control) and serves the multiply-adds of k = 2q (both halves read
+// the pair's low word: op_sel) and k = 2q+1 (the high word): 16 moves + 32 multiply-adds per layer instead of 32 + 32 with
+// 32-bit moves -- the same arithmetic bit for bit, rollout 36.9 -> 34.3 us, step 0.0486 -> 0.0461 ms
+// (profiles/r04_r_mov64_ab.txt).  Written as the schedule it has to be -- multiply-add of 2q, the move for q+1 in its
+// shadow, multiply-add of 2q+1 -- and held there by scheduling barriers (left alone inside the kernel, the scheduler hoists
+// all moves in front of the chain: ~130 cycles more per layer).
+template <int Q>
+__device__ __forceinline__ f32x2 row_bc2(f32x2 a)
 {
-  return row_bc<(K >> 1)>((K & 1) ? a.y : a.x);
+  return __builtin_bit_cast(f32x2, (long long)__builtin_amdgcn_mov_dpp(__builtin_bit_cast(long long, a), 0x150 + Q, 0xF, 0xF, false));
 }
-template <int K>
-__device__ __forceinline__ void row_dot_step(f32x2 &z, float &v, const f32x2 *w, f32x2 a)
+template <int Q>
+__device__ __forceinline__ void row_dot_step(f32x2 &z, f32x2 &b, const f32x2 *w, f32x2 a)
 {
-  const float vn = row_bc_k<(K + 1 < 32 ? K + 1 : 31)>(a);
-  z = __builtin_elementwise_fma(w[K], f32x2{v, v}, z);
+  z = __builtin_elementwise_fma(w[2 * Q], f32x2{b.x, b.x}, z);
   __builtin_amdgcn_sched_barrier(0);
-  v = vn;
+  const f32x2 bn = row_bc2<(Q + 1 < 16 ? Q + 1 : 15)>(a);
+  __builtin_amdgcn_sched_barrier(0);
+  z = __builtin_elementwise_fma(w[2 * Q + 1], f32x2{b.y, b.y}, z);
+  __builtin_amdgcn_sched_barrier(0);
+  b = bn;
 }
 __device__ __forceinline__ f32x2 row_dot_bc(const f32x2 *w, f32x2 a)
 {
   f32x2 z = {0.0f, 0.0f};
-  float v = row_bc_k<0>(a);
+  f32x2 b = row_bc2<0>(a);
   __builtin_amdgcn_sched_barrier(0);
-#define RD4(K) row_dot_step<K>(z, v, w, a); row_dot_step<K + 1>(z, v, w, a); row_dot_step<K + 2>(z, v, w, a); row_dot_step<K + 3>(z, v, w, a);
-  RD4(0) RD4(4) RD4(8) RD4(12) RD4(16) RD4(20) RD4(24) RD4(28)
+#define RD4(Q) row_dot_step<Q>(z, b, w, a); row_dot_step<Q + 1>(z, b, w, a); row_dot_step<Q + 2>(z, b, w, a); row_dot_step<Q + 3>(z, b, w, a);
+  RD4(0) RD4(4) RD4(8) RD4(12)
 #undef RD4
   return z;
 }

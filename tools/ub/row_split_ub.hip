@@ -6,6 +6,8 @@
 //   form 1: two chains (even k / odd k), still one v_mov_b32_dpp per k
 //   form 2: two chains, one v_mov_b64_dpp row_newbcast per PAIR (a[2q], a[2q+1]), the halves picked by op_sel
 //   form 3: four chains (k mod 4), one v_mov_b64_dpp per pair
+//   form 4: ONE chain, k ascending (the reference's order, bit for bit form 0), one v_mov_b64_dpp per pair
+//   form 5: as 4, the move between the two multiply-adds of a pair
 // hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ub/row_split_ub.hip -o row_split_ub
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -114,6 +116,38 @@ __device__ __forceinline__ f32x2 dot3(const f32x2 *w, f32x2 a)
   return (z[0] + z[1]) + (z[2] + z[3]);
 }
 
+// ---- form 4 / 5 ----
+template <int Q, bool MID>
+__device__ __forceinline__ void step4(f32x2 &z, f32x2 &b, const f32x2 *w, f32x2 a)
+{
+  if constexpr (MID) {
+    z = __builtin_elementwise_fma(w[2 * Q], f32x2{b.x, b.x}, z);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 bn = bc64<(Q + 1 < 16 ? Q + 1 : 15)>(a);
+    __builtin_amdgcn_sched_barrier(0);
+    z = __builtin_elementwise_fma(w[2 * Q + 1], f32x2{b.y, b.y}, z);
+    __builtin_amdgcn_sched_barrier(0);
+    b = bn;
+  } else {
+    const f32x2 bn = bc64<(Q + 1 < 16 ? Q + 1 : 15)>(a);
+    z = __builtin_elementwise_fma(w[2 * Q], f32x2{b.x, b.x}, z);
+    z = __builtin_elementwise_fma(w[2 * Q + 1], f32x2{b.y, b.y}, z);
+    __builtin_amdgcn_sched_barrier(0);
+    b = bn;
+  }
+}
+template <bool MID>
+__device__ __forceinline__ f32x2 dot4(const f32x2 *w, f32x2 a)
+{
+  f32x2 z = {0.0f, 0.0f};
+  f32x2 b = bc64<0>(a);
+  __builtin_amdgcn_sched_barrier(0);
+#define R4(Q) step4<Q, MID>(z, b, w, a); step4<Q + 1, MID>(z, b, w, a); step4<Q + 2, MID>(z, b, w, a); step4<Q + 3, MID>(z, b, w, a);
+  R4(0) R4(4) R4(8) R4(12)
+#undef R4
+  return z;
+}
+
 template <int FORM>
 __global__ __launch_bounds__(256) void ub_kernel(const float *wsrc, float *out, long long *ticks, int iters)
 {
@@ -123,7 +157,8 @@ __global__ __launch_bounds__(256) void ub_kernel(const float *wsrc, float *out, 
   for (int k = 0; k < H; k++) w[k] = f32x2{wsrc[(2 * p) * H + k], wsrc[(2 * p + 1) * H + k]};
 #pragma unroll
   for (int k = 0; k < H; k++) asm volatile("" : "+v"(w[k]));
-  f32x2 a = {0.01f * (float)(2 * p), 0.01f * (float)(2 * p + 1)};
+  const f32x2 a_init = {0.01f * (float)(2 * p) + 0.003f, 0.01f * (float)(2 * p + 1) - 0.002f};
+  f32x2 a = a_init;
   const long long t0 = wall_clock64();
   const long long c0 = clock64();
   for (int i = 0; i < iters; i++) {
@@ -131,8 +166,10 @@ __global__ __launch_bounds__(256) void ub_kernel(const float *wsrc, float *out, 
     if (FORM == 0) z = dot0(w, a);
     else if (FORM == 1) z = dot1(w, a);
     else if (FORM == 2) z = dot2(w, a);
-    else z = dot3(w, a);
-    a = z;
+    else if (FORM == 3) z = dot3(w, a);
+    else if (FORM == 4) z = dot4<false>(w, a);
+    else z = dot4<true>(w, a);
+    a = z + a_init;  // (the values stay O(0.1): the bit comparisons below mean something)
   }
   const long long c1 = clock64();
   const long long t1 = wall_clock64();
@@ -149,15 +186,17 @@ int main()
   hipMalloc(&dw, hw.size() * 4); hipMalloc(&dout, 512 * 4); hipMalloc(&dt, 8 * 8);
   hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   const int iters = 2000;
-  float ref[4][4] = {};
+  float ref[6][4] = {};
   for (int waves = 1; waves <= 4; waves *= 4) {  // one wave (one SIMD) / four waves (one per SIMD)
-    for (int form = 0; form < 4; form++) {
+    for (int form = 0; form < 6; form++) {
       for (int rep = 0; rep < 3; rep++) {
         switch (form) {
           case 0: hipLaunchKernelGGL(ub_kernel<0>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
           case 1: hipLaunchKernelGGL(ub_kernel<1>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
           case 2: hipLaunchKernelGGL(ub_kernel<2>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
-          default: hipLaunchKernelGGL(ub_kernel<3>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
+          case 3: hipLaunchKernelGGL(ub_kernel<3>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
+          case 4: hipLaunchKernelGGL(ub_kernel<4>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
+          default: hipLaunchKernelGGL(ub_kernel<5>, dim3(1), dim3(64 * waves), 0, 0, dw, dout, dt, iters); break;
         }
         hipDeviceSynchronize();
       }
@@ -169,7 +208,9 @@ int main()
              (double)ht[0] / iters, (double)ht[1] * 10.0 / iters, ho[0], ho[1]);
     }
   }
-  printf("forms 2 and 1 agree: %s; forms 0 and 2 differ by %.3g (re-association)\n",
-         (ref[1][0] == ref[2][0] && ref[1][1] == ref[2][1]) ? "bit for bit" : "NO", (double)(ref[0][0] - ref[2][0]));
+  printf("forms 2 and 1 agree: %s; forms 4, 5 and 0 agree: %s; forms 0 and 2 differ by %.3g (re-association)\n",
+         (ref[1][0] == ref[2][0] && ref[1][1] == ref[2][1]) ? "bit for bit" : "NO",
+         (ref[4][0] == ref[0][0] && ref[4][1] == ref[0][1] && ref[5][0] == ref[0][0] && ref[5][1] == ref[0][1]) ? "bit for bit" : "NO",
+         (double)(ref[0][0] - ref[2][0]));
   return 0;
 }
