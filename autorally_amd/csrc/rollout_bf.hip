@@ -450,9 +450,14 @@ __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const Rollout
 // loop): workgroup (x, y) runs group x of instance y
 __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const QuadBatchArgs b)
 {
-  const RolloutArgs a = b.inst[blockIdx.y];  // (a copy, the instance from the workgroup's own index: rollout_row.hip, rollout_row_batch_kernel)
-  if ((int)blockIdx.x >= a.K / kBfLanes) return;
-  bf3_group(a, (int)blockIdx.x);
+  // the instance from the workgroup's own index, its argument block at a compile-time position (MPPI_BATCH_DISPATCH)
+#define MPPI_BF_BODY(A)                                  \
+  do {                                                   \
+    if ((int)blockIdx.x >= (A).K / kBfLanes) return;     \
+    bf3_group((A), (int)blockIdx.x);                     \
+  } while (0)
+  MPPI_BATCH_DISPATCH(b, MPPI_BF_BODY);
+#undef MPPI_BF_BODY
 }
 
 // test entry (mppi_debug_dynamics): state derivative of n independent (state, control) pairs

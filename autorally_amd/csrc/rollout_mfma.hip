@@ -624,11 +624,15 @@ template <int H, int NHID, bool AFFINE, bool CTRL>
 __global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatchArgs b)
 {
   __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
-  // grid (groups of the largest instance, instances): the instance from the workgroup's own index -- one round trip to the
-  // argument segment instead of two dependent ones (rollout_row.hip: rollout_row_batch_kernel)
-  const RolloutArgs a = b.inst[blockIdx.y];  // a copy: through a reference the waves re-read parameters from the segment in their loops
-  if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;
-  quad_group<H, NHID, AFFINE, CTRL>(a, sh, (int)blockIdx.x);
+  // grid (groups of the largest instance, instances): the instance from the workgroup's own index, its argument block at a
+  // compile-time position of the segment (MPPI_BATCH_DISPATCH, mppi_device.hpp)
+#define MPPI_QUAD_BODY(A)                                          \
+  do {                                                             \
+    if ((int)blockIdx.x >= (A).K / kRolloutsPerWave) return;       \
+    quad_group<H, NHID, AFFINE, CTRL>((A), sh, (int)blockIdx.x);   \
+  } while (0)
+  MPPI_BATCH_DISPATCH(b, MPPI_QUAD_BODY);
+#undef MPPI_QUAD_BODY
 }
 
 // Debug/test entry: state derivative of n independent (state, control) pairs through the

@@ -305,12 +305,12 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
+// one group (workgroup): the four dynamics waves and the four riders
 template <int H, bool AFFINE, bool CTRL, bool TREE>
-__global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
+__device__ __forceinline__ void row_group(const RolloutArgs &a, RowShared<H> &sh)
 {
   using SH = RowShared<H>;
   using R = GroupRoles<SH>;
-  __shared__ __attribute__((aligned(16))) SH sh;
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (role == 0) RSTAMP(0);  // first instruction
@@ -338,42 +338,28 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
   else { group_rng_wave<SH, true>(a, sh, g0); RSTAMP(8); }
 }
 
+template <int H, bool AFFINE, bool CTRL, bool TREE>
+__global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
+{
+  __shared__ __attribute__((aligned(16))) RowShared<H> sh;
+  row_group<H, AFFINE, CTRL, TREE>(a, sh);
+}
+
 // several instances in one launch (mppi_compute_control_batch): grid (groups of the largest instance, instances) -- workgroup
-// (x, y) runs group x of instance y, whose argument block sits at a position the workgroup knows from its own index: ONE
-// round trip to the argument segment, as in the single-instance kernel (a search of the instance in a table of first
-// workgroups made it two dependent ones, ~1 us of every launch -- the argument segment is not close memory)
+// (x, y) runs group x of instance y, whose argument block sits at a position the workgroup knows from its own index
+// (MPPI_BATCH_DISPATCH, mppi_device.hpp: one branch per instance, so that the block is read as the single-instance kernel
+// reads its arguments -- with a run-time index the block went through scratch: 44.8 us beside 33.8 us alone)
 template <int H, bool AFFINE, bool CTRL, bool TREE>
 __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchArgs b)
 {
-  using SH = RowShared<H>;
-  using R = GroupRoles<SH>;
-  __shared__ __attribute__((aligned(16))) SH sh;
-  const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = (int)blockIdx.y;  // workgroup-uniform
-  // A COPY of the instance's block, not a reference into the argument segment: through the reference the riders re-read
-  // their parameters from the segment inside their loops (38 scalar loads in the kernel, 30 of them in loops; 12 and 1 with
-  // the copy, as in the single-instance kernel): 48.3 -> 47.4 us by rocprofv3
-  const RolloutArgs a = b.inst[i];
-  if ((int)blockIdx.x >= a.K / kRolloutsPerWave) return;  // a smaller instance than the largest of the batch
-  MrgHalf g0{0, 0, 0};
-  if (role == R::kRng) g0 = group_rng_load<SH>(a);  // in front of the barrier (with the copy above: 47.7 -> 46.3 us)
-  if (role == 0) {
-#pragma unroll
-    for (int w = 0; w < 4; w++) sh.xseq[w][lane] = 0;
-    sh.cost_done[lane] = 0;
-    sh.ctl_pub[lane] = 0;
-    sh.pose_pub[lane] = 0;
-    sh.rng_pub[lane] = 0;
-    sh.fail[lane & 3] = 0;
-    sh.fin[lane & 7] = 0;
-  }
-  __syncthreads();
-  if (role < 4) row_dynamics<H, TREE>(a, sh, role);
-  else if (role == R::kCost) group_cost_wave4<SH, CTRL>(a, sh);
-  else if (role == R::kCtl) group_control_wave(a, sh);
-  else if (role == R::kPose) group_pose_wave4<SH, AFFINE>(a, sh);
-  else group_rng_wave<SH, true>(a, sh, g0);
+  __shared__ __attribute__((aligned(16))) RowShared<H> sh;
+#define MPPI_ROW_BODY(A)                                                                                   \
+  do {                                                                                                     \
+    if ((int)blockIdx.x >= (A).K / kRolloutsPerWave) return; /* a smaller instance than the largest */     \
+    row_group<H, AFFINE, CTRL, TREE>((A), sh);                                                             \
+  } while (0)
+  MPPI_BATCH_DISPATCH(b, MPPI_ROW_BODY);
+#undef MPPI_ROW_BODY
 }
 
 bool row_variant_supported(int hidden, int n_hidden) { return hidden == 32 && n_hidden == 2; }

@@ -485,14 +485,17 @@ def main():
                 # the k-ascending chain of the exact form: 70 dependent v_pk_fma_f32 + two tanh = 865 cycles alone on a SIMD; the
                 # tree form replaces the output layer's 32 links by 2 packed products + a 4-deep butterfly: 6 + 32 links, two
                 # tanh, the butterfly (profiles/r03_j_row_bcast_ub.txt and DESIGN.md 4.2c)
-                floor = 865.0 - 32 * 9.0 + 60.0 if tree else 865.0
+                # (round 4: one v_mov_b64_dpp per activation pair -- a 32-link layer 292 -> 272 cycles alone on a SIMD,
+                # tools/ub/row_split_ub.hip forms 0 / 4, profiles/r04_q_row_split_ub.txt)
+                floor = (865.0 - 32 * 9.0 + 60.0 - 20.0) if tree else (865.0 - 40.0)
                 out["roofline"]["pipe"] = "vector ALU (v_pk_fma_f32), no MFMA issued; f32 vector peak = f32 MFMA peak"
                 out["roofline"]["recurrence"] = {
                     "cycles_per_step": cyc, "bare_recurrence_cycles_per_step": floor, "frac_of_floor": floor / cyc if cyc > 0 else 0.0,
                     "clock_GHz_assumed": clk_ghz,
                     "note": "event-measured kernel time / T (launch, prologue and riders included) against one dynamics wavefront's "
-                            "recurrence alone on a SIMD (tools/ub/row_bcast_ub.hip: 865 cycles for the exact chain; tree form: that "
-                            "minus 32 links of ~9 cycles plus ~60 for two packed products and the butterfly)"}
+                            "recurrence alone on a SIMD (tools/ub/row_bcast_ub.hip: 865 cycles for the exact chain with 32-bit moves; tree form: "
+                            "that minus 32 links of ~9 cycles plus ~60 for two packed products and the butterfly; 64-bit moves: "
+                            "20 cycles less per 32-link layer, tools/ub/row_split_ub.hip)"}
             if "quad" in variant and cfg.get("bf_W") is None:
                 # The configuration is latency bound (one 16-rollout group per CU, T sequential steps), so next
                 # to the throughput roofline: the step time of the recurrence against (a) what its two dynamics
