@@ -468,10 +468,14 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   // the other buffer, so that the control loop's slide -> solve costs no kernel and no upload.
   if (a.slid != nullptr) {
     const int st = a.slide_stride;
+    // (i & 1 == tid & 1: the value is picked HERE, between two scalar registers -- written as `j ? a.init1 : a.init0` inside
+    // the loop's conditional the compiler made it a load from a two-element private array, i.e. two scratch stores in every
+    // workgroup's prologue and flat loads in this loop)
+    const float init_j = (tid & 1) ? a.init1 : a.init0;
     // hist rows sit in X[0..3] (the smoothing's left padding)
     for (int i = tid; i < 2 * T; i += kTailThreads) {
       const int r = i >> 1, j = i & 1;
-      a.slid[i] = (r < T - st) ? Y[(r + st) * 2 + j] : (j ? a.init1 : a.init0);
+      a.slid[i] = (r < T - st) ? Y[(r + st) * 2 + j] : init_j;
     }
     if (tid < 4) {
       float hv;
