@@ -91,6 +91,7 @@ struct mppi_handle {
   float ddp_Qf[7] = {0, 0, 0, 0, 0, 0, 0};
   DdpResult ddp;
   bool have_ddp = false;
+  hipStream_t batch_s = nullptr;  // the device's batch stream, looked up once (mppi_compute_control_batch)
   unsigned *d_counter = nullptr;  // [1 + T] arrival counters of the tail kernel
   float *d_part = nullptr;        // [T][K/64][2] chain results of the tail kernel when K > 4096
   float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
@@ -163,6 +164,14 @@ using namespace mppi;
     hipError_t e__ = (call);                                             \
     if (e__ != hipSuccess) return fail((h), MPPI_ERR_HIP, #call, e__);   \
   } while (0)
+// The calling thread's current device is `dev` afterwards: hipGetDevice (a thread-local read, 0.07 us) and hipSetDevice only
+// when it differs -- a control loop calls the solve entries from one thread whose device never changes.
+inline hipError_t ensure_device(int dev)
+{
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == dev) return hipSuccess;
+  return hipSetDevice(dev);
+}
 #define OWN(h)                      \
   do {                              \
     int rc__ = own_stream(h);       \

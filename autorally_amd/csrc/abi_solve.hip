@@ -417,7 +417,7 @@ extern "C" {
 int mppi_compute_control_async(mppi_handle *h, const float state[MPPI_STATE_DIM])
 {
   if (!h) return MPPI_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, ensure_device(h->cfg.device));
   return enqueue_solve(h, state);
 }
 
@@ -437,6 +437,15 @@ int mppi_compute_control(mppi_handle *h, const float state[MPPI_STATE_DIM])
 int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states, int n)
 {
   if (!hs || !states || n < 1) return MPPI_ERR_INVALID;
+#ifdef MPPI_HOSTPROF
+  static double hb[8] = {0}; static double hbn = 0; static std::chrono::steady_clock::time_point hb_prev_end;
+  auto hb_t = std::chrono::steady_clock::now();
+  if (hbn > 0) hb[0] += std::chrono::duration<double, std::micro>(hb_t - hb_prev_end).count();  // previous batch_async returned -> this one entered (synchronize + slides of the caller)
+  // (the first call creates the device's batch stream, ~3 ms: read these averages over many calls with that in mind)
+#define HB(i) do { auto n__ = std::chrono::steady_clock::now(); hb[i] += std::chrono::duration<double, std::micro>(n__ - hb_t).count(); hb_t = n__; } while (0)
+#else
+#define HB(i) do { } while (0)
+#endif
   for (int i = 0; i < n; i++) {
     if (!hs[i]) return MPPI_ERR_INVALID;
     for (int q = 0; q < i; q++)
@@ -477,10 +486,14 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     }
     return MPPI_OK;
   }
-  HIPCHK(h0, hipSetDevice(h0->cfg.device));
-  const hipStream_t S = batch_stream(h0->cfg.device);
+  HB(1);  // the decision: one launch for all?
+  // (the device's batch stream is looked up once per handle)
+  HIPCHK(h0, ensure_device(h0->cfg.device));
+  if (!h0->batch_s) h0->batch_s = batch_stream(h0->cfg.device);
+  const hipStream_t S = h0->batch_s;
   if (!S) return fail(h0, MPPI_ERR_HIP, "no batch stream");
   const int iters = h0->cfg.num_iters;
+  HB(2);  // current device + the batch stream
   // First pass: everything that can fail without having touched a handle -- every handle's previous solve collected,
   // every handle's explicit noise checked -- so that one handle's error does not leave its partners half-advanced.
   for (int i = 0; i < n; i++) {
@@ -501,6 +514,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     }
     return rc_;
   };
+  HB(3);  // wait_pending of every handle
   for (int i = 0; i < n; i++) {
     mppi_handle *h = hs[i];
     int rc = MPPI_OK;
@@ -537,10 +551,13 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
       if (last) h->slid_valid = wants_slid_copy(h);
     }
     for (int i = n; i < kMaxBatch; i++) qb.inst[i] = qb.inst[0];
+    HB(4);  // uploads + argument blocks
     hipError_t e = h0->basis ? launch_rollout_bf_batch(qb, S)
                    : form_is_row(form_of(h0)) ? launch_rollout_row_batch(qb, form_of(h0) == Form::RowTree, S)
                                                 : launch_rollout_quad_batch(h0->hidden, h0->n_hidden, qb, S);
+    HB(5);  // rollout launch
     if (e == hipSuccess) e = launch_solve_tail_batch(tl, n, S);
+    HB(6);  // tail launch
     if (e != hipSuccess) return poison(fail(h0, MPPI_ERR_HIP, "batched launch", e));
   }
   for (int i = 0; i < n; i++) {
@@ -548,6 +565,13 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
     hs[i]->pending = true;
     hs[i]->pending_timed = false;
   }
+#ifdef MPPI_HOSTPROF
+  hbn += 1;
+  hb_prev_end = std::chrono::steady_clock::now();
+  if (((long)hbn % 1000) == 0)
+    fprintf(stderr, "hostprof batch (us per call, %.0f calls): between calls %.2f | decide %.2f | device + stream %.2f | wait_pending %.2f | upload+args %.2f | rollout launch %.2f | tail launch %.2f\n",
+            hbn, hb[0] / hbn, hb[1] / hbn, hb[2] / hbn, hb[3] / hbn, hb[4] / hbn, hb[5] / hbn, hb[6] / hbn);
+#endif
   return MPPI_OK;
 }
 

@@ -59,23 +59,43 @@ struct RolloutArgs {
 // Argument block of the batched rollout kernels: grid (groups of the largest instance, instances), workgroup (x, y) runs
 // group x of inst[y]: every kernel indexes an instance's rollouts by blockIdx.x alone.
 constexpr int kMaxBatch = 4;
-struct QuadBatchArgs {
+template <int NB>
+struct QuadBatchArgsT {
   int n;
-  RolloutArgs inst[kMaxBatch];
+  RolloutArgs inst[NB];
 };
+using QuadBatchArgs = QuadBatchArgsT<kMaxBatch>;  // what the ABI layer fills; the launchers pass the two-instance form when n <= 2
+// (the two controllers of a tick do not carry two unused blocks through the kernel-argument segment, nor two unused branches
+// through the instruction cache: launch call 4.1 -> 3.9 us for the rollout, 3.3 -> 3.0 us for the tail, host profile of
+// profiles/r04_t_hostprof_batch.txt)
+template <int NB>
+inline QuadBatchArgsT<NB> batch_args_prefix(const QuadBatchArgs &b)
+{
+  QuadBatchArgsT<NB> s;
+  s.n = b.n;
+  for (int i = 0; i < NB; i++) s.inst[i] = b.inst[i];
+  return s;
+}
 // The argument block of instance blockIdx.y of a batched launch, handed to BODY at a COMPILE-TIME position of the
 // kernel-argument segment: the body then reads its parameters exactly as the single-instance kernel does (scalar loads with
 // immediate offsets into scalar registers).  With a run-time index the compiler either re-reads the segment inside the
 // waves' loops (a reference) or parks a private copy of the block in SCRATCH and turns every pointer loaded from it into a
 // flat access (a copy): round 4 found the batched row kernel at 44.8 us beside 33.8 us for the same work launched alone.
 static_assert(kMaxBatch == 4, "MPPI_BATCH_DISPATCH");
-#define MPPI_BATCH_DISPATCH(B, BODY)      \
-  switch ((int)blockIdx.y) {             \
-    case 0: BODY((B).inst[0]); break;    \
-    case 1: BODY((B).inst[1]); break;    \
-    case 2: BODY((B).inst[2]); break;    \
-    default: BODY((B).inst[3]); break;   \
-  }
+#define MPPI_BATCH_DISPATCH(NB, B, BODY)     \
+  do {                                      \
+    if constexpr ((NB) == 2) {              \
+      if (blockIdx.y == 0) BODY((B).inst[0]); \
+      else BODY((B).inst[1]);               \
+    } else {                                \
+      switch ((int)blockIdx.y) {            \
+        case 0: BODY((B).inst[0]); break;   \
+        case 1: BODY((B).inst[1]); break;   \
+        case 2: BODY((B).inst[2]); break;   \
+        default: BODY((B).inst[3]); break;  \
+      }                                     \
+    }                                       \
+  } while (0)
 
 // Thresholds for the reference's float-vs-double-literal comparisons, as floats:
 //   (double)x > 1.57   <=>  x >= kRollCrash   (costs.cu:302)

@@ -448,7 +448,8 @@ __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_kernel(const Rollout
 
 // several instances in one launch (mppi_compute_control_batch: the two controllers of path_integral_bf's control
 // loop): workgroup (x, y) runs group x of instance y
-__global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const QuadBatchArgs b)
+template <int NB>
+__global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const QuadBatchArgsT<NB> b)
 {
   // the instance from the workgroup's own index, its argument block at a compile-time position (MPPI_BATCH_DISPATCH)
 #define MPPI_BF_BODY(A)                                  \
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(3 * kBfLanes) void rollout_bf3_batch_kernel(const Q
     if ((int)blockIdx.x >= (A).K / kBfLanes) return;     \
     bf3_group((A), (int)blockIdx.x);                     \
   } while (0)
-  MPPI_BATCH_DISPATCH(b, MPPI_BF_BODY);
+  MPPI_BATCH_DISPATCH(NB, b, MPPI_BF_BODY);
 #undef MPPI_BF_BODY
 }
 
@@ -496,7 +497,8 @@ hipError_t launch_rollout_bf_batch(const QuadBatchArgs &b, hipStream_t stream)
   if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;
   int gmax = 0;
   for (int i = 0; i < b.n; i++) gmax = b.inst[i].K / kBfLanes > gmax ? b.inst[i].K / kBfLanes : gmax;
-  hipLaunchKernelGGL(rollout_bf3_batch_kernel, dim3(gmax, b.n), dim3(3 * kBfLanes), 0, stream, b);
+  if (b.n <= 2) hipLaunchKernelGGL(rollout_bf3_batch_kernel<2>, dim3(gmax, b.n), dim3(3 * kBfLanes), 0, stream, batch_args_prefix<2>(b));
+  else hipLaunchKernelGGL(rollout_bf3_batch_kernel<4>, dim3(gmax, b.n), dim3(3 * kBfLanes), 0, stream, b);
   return hipGetLastError();
 }
 

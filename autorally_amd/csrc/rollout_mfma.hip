@@ -620,8 +620,8 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const RolloutArgs a)
 // 256 CUs): workgroup (x, y) runs group x of instance y with that instance's own argument block (state, U,
 // noise / generator states, costmap, cost parameters).  The per-group code is quad_group, so every instance's
 // results equal a stand-alone launch bit for bit.
-template <int H, int NHID, bool AFFINE, bool CTRL>
-__global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatchArgs b)
+template <int H, int NHID, bool AFFINE, bool CTRL, int NB>
+__global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatchArgsT<NB> b)
 {
   __shared__ __attribute__((aligned(16))) QuadShared<H, NHID> sh;
   // grid (groups of the largest instance, instances): the instance from the workgroup's own index, its argument block at a
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void rollout_quad_batch_kernel(const QuadBatch
     if ((int)blockIdx.x >= (A).K / kRolloutsPerWave) return;       \
     quad_group<H, NHID, AFFINE, CTRL>((A), sh, (int)blockIdx.x);   \
   } while (0)
-  MPPI_BATCH_DISPATCH(b, MPPI_QUAD_BODY);
+  MPPI_BATCH_DISPATCH(NB, b, MPPI_QUAD_BODY);
 #undef MPPI_QUAD_BODY
 }
 
@@ -689,21 +689,26 @@ static hipError_t launch_rollout_t(const RolloutArgs &a, int block_threads, hipS
   return hipGetLastError();
 }
 
+template <int H, int NHID, int NB>
+static void launch_quad_batch_nb(const QuadBatchArgsT<NB> &b, dim3 grid, bool affine, bool ctrl, hipStream_t stream)
+{
+  const dim3 block(256);
+  if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, false, NB>), grid, block, 0, stream, b);
+  else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, true, NB>), grid, block, 0, stream, b);
+  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, false, NB>), grid, block, 0, stream, b);
+  else hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, true, NB>), grid, block, 0, stream, b);
+}
 template <int H, int NHID>
 static hipError_t launch_quad_batch_t(const QuadBatchArgs &b, bool affine, bool ctrl, hipStream_t stream)
 {
   int gmax = 0;
   for (int i = 0; i < b.n; i++) gmax = b.inst[i].K / kRolloutsPerWave > gmax ? b.inst[i].K / kRolloutsPerWave : gmax;
-  const dim3 grid(gmax, b.n), block(256);
-  if (affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, false>), grid, block, 0, stream, b);
-  else if (affine && ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, true, true>), grid, block, 0, stream, b);
-  else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, false>), grid, block, 0, stream, b);
-  else hipLaunchKernelGGL((rollout_quad_batch_kernel<H, NHID, false, true>), grid, block, 0, stream, b);
+  const dim3 grid(gmax, b.n);
+  if (b.n <= 2) launch_quad_batch_nb<H, NHID, 2>(batch_args_prefix<2>(b), grid, affine, ctrl, stream);  // (mppi_device.hpp)
+  else launch_quad_batch_nb<H, NHID, 4>(b, grid, affine, ctrl, stream);
   return hipGetLastError();
 }
 
-// The kernel instance is chosen for the whole batch: the general forms are exact supersets (u / w with w == 1 is
-// u, the control-cost term with zero coefficients is +0), so an instance's bits do not depend on its partners.
 hipError_t launch_rollout_quad_batch(int hidden, int n_hidden, const QuadBatchArgs &b, hipStream_t stream)
 {
   if (b.n < 1 || b.n > kMaxBatch) return hipErrorInvalidValue;

@@ -349,8 +349,8 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
 // (x, y) runs group x of instance y, whose argument block sits at a position the workgroup knows from its own index
 // (MPPI_BATCH_DISPATCH, mppi_device.hpp: one branch per instance, so that the block is read as the single-instance kernel
 // reads its arguments -- with a run-time index the block went through scratch: 44.8 us beside 33.8 us alone)
-template <int H, bool AFFINE, bool CTRL, bool TREE>
-__global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchArgs b)
+template <int H, bool AFFINE, bool CTRL, bool TREE, int NB>
+__global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchArgsT<NB> b)
 {
   __shared__ __attribute__((aligned(16))) RowShared<H> sh;
 #define MPPI_ROW_BODY(A)                                                                                   \
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512) void rollout_row_batch_kernel(const QuadBatchA
     if ((int)blockIdx.x >= (A).K / kRolloutsPerWave) return; /* a smaller instance than the largest */     \
     row_group<H, AFFINE, CTRL, TREE>((A), sh);                                                             \
   } while (0)
-  MPPI_BATCH_DISPATCH(b, MPPI_ROW_BODY);
+  MPPI_BATCH_DISPATCH(NB, b, MPPI_ROW_BODY);
 #undef MPPI_ROW_BODY
 }
 
@@ -373,6 +373,13 @@ int row_pack_floats() { return kRowPackEntries * 16 * 4; }
     else if (!affine && !ctrl) LAUNCH((KERN<32, false, false, TREE>), __VA_ARGS__);                           \
     else LAUNCH((KERN<32, false, true, TREE>), __VA_ARGS__);                                                  \
   } while (0)
+#define MPPI_ROW_BATCH_DISPATCH(TREE, NB, ...)                                                                                  \
+  do {                                                                                                                          \
+    if (affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, false, TREE, NB>), __VA_ARGS__);                \
+    else if (affine && ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, true, true, TREE, NB>), __VA_ARGS__);             \
+    else if (!affine && !ctrl) hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, false, TREE, NB>), __VA_ARGS__);         \
+    else hipLaunchKernelGGL((rollout_row_batch_kernel<32, false, true, TREE, NB>), __VA_ARGS__);                                \
+  } while (0)
 
 hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, bool tree, hipStream_t stream)
 {
@@ -385,8 +392,14 @@ hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, bool tree, hipStream
     gmax = b.inst[i].K / kRolloutsPerWave > gmax ? b.inst[i].K / kRolloutsPerWave : gmax;
   }
   const dim3 grid(gmax, b.n), block(512);
-  if (tree) MPPI_ROW_DISPATCH(hipLaunchKernelGGL, rollout_row_batch_kernel, true, grid, block, 0, stream, b);
-  else MPPI_ROW_DISPATCH(hipLaunchKernelGGL, rollout_row_batch_kernel, false, grid, block, 0, stream, b);
+  if (b.n <= 2) {  // the two controllers of a tick: half the argument segment
+    const QuadBatchArgsT<2> b2 = batch_args_prefix<2>(b);
+    if (tree) MPPI_ROW_BATCH_DISPATCH(true, 2, grid, block, 0, stream, b2);
+    else MPPI_ROW_BATCH_DISPATCH(false, 2, grid, block, 0, stream, b2);
+  } else {
+    if (tree) MPPI_ROW_BATCH_DISPATCH(true, 4, grid, block, 0, stream, b);
+    else MPPI_ROW_BATCH_DISPATCH(false, 4, grid, block, 0, stream, b);
+  }
   return hipGetLastError();
 }
 
@@ -400,6 +413,7 @@ hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, bo
   return hipGetLastError();
 }
 #undef MPPI_ROW_DISPATCH
+#undef MPPI_ROW_BATCH_DISPATCH
 
 }  // namespace mppi
 

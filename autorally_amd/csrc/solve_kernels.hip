@@ -497,18 +497,22 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_wide_kernel(const Tai
 
 // The tails of several instances (K <= kRedChunk each: T + 1 workgroups per instance) in one launch, behind
 // rollout_quad_batch_kernel: grid (T + 1 of the longest instance, instances), workgroup (x, y) is row x of instance y.
+template <int NB>
 struct TailBatchArgs {
-  int n;
-  int first[kMaxBatch + 1];
-  TailArgs inst[kMaxBatch];
+  TailArgs inst[NB];
 };
-__global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const TailBatchArgs b)
+template <int NB>
+__global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const TailBatchArgs<NB> b)
 {
-  // grid (T + 1 of the longest instance, instances): the instance from the workgroup's own index, one round trip to the
-  // argument segment (rollout_row.hip: rollout_row_batch_kernel)
-  const TailArgs a = b.inst[blockIdx.y];  // a copy (a reference makes the body re-read its parameters from the segment)
-  if ((int)blockIdx.x > a.T) return;
-  solve_tail_body<kRedChunk / 4 / kTailThreads>(a, (int)blockIdx.x);
+  // grid (T + 1 of the longest instance, instances): the instance from the workgroup's own index, its block at a compile-time
+  // position of the argument segment (MPPI_BATCH_DISPATCH, mppi_device.hpp); NB = 2 for the two controllers of a tick
+#define MPPI_TAIL_BODY(A)                                                   \
+  do {                                                                      \
+    if ((int)blockIdx.x > (A).T) return;                                    \
+    solve_tail_body<kRedChunk / 4 / kTailThreads>((A), (int)blockIdx.x);    \
+  } while (0)
+  MPPI_BATCH_DISPATCH(NB, b, MPPI_TAIL_BODY);
+#undef MPPI_TAIL_BODY
 }
 
 // slideControlSeq (mppi_controller.cu:527-554) on the device copy of [U(2T) | hist(4)], so that a
@@ -644,26 +648,25 @@ hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
   return hipGetLastError();
 }
 
+template <int NB>
+static void launch_tail_batch_nb(const TailLaunch *l, int n, int tmax, size_t dyn, hipStream_t stream)
+{
+  TailBatchArgs<NB> b;
+  for (int i = 0; i < NB; i++) b.inst[i] = fill_tail(l[i < n ? i : 0]);
+  hipLaunchKernelGGL(solve_tail_batch_kernel<NB>, dim3(tmax + 1, n), dim3(kTailThreads), dyn, stream, b);
+}
 hipError_t launch_solve_tail_batch(const TailLaunch *l, int n, hipStream_t stream)
 {
   if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
-  TailBatchArgs b;
-  b.n = n;
-  b.first[0] = 0;
   size_t dyn = 0;
+  int tmax = 0;
   for (int i = 0; i < n; i++) {
     if (l[i].K > kRedChunk) return hipErrorInvalidValue;  // one workgroup per row only
-    b.inst[i] = fill_tail(l[i]);
-    b.first[i + 1] = b.first[i] + l[i].T + 1;
     dyn = tail_dyn_bytes(l[i].K, l[i].T) > dyn ? tail_dyn_bytes(l[i].K, l[i].T) : dyn;
+    tmax = l[i].T > tmax ? l[i].T : tmax;
   }
-  for (int i = n; i < kMaxBatch; i++) {
-    b.inst[i] = b.inst[0];
-    b.first[i + 1] = b.first[n];
-  }
-  int tmax = 0;
-  for (int i = 0; i < n; i++) tmax = l[i].T > tmax ? l[i].T : tmax;
-  hipLaunchKernelGGL(solve_tail_batch_kernel, dim3(tmax + 1, n), dim3(kTailThreads), dyn, stream, b);
+  if (n <= 2) launch_tail_batch_nb<2>(l, n, tmax, dyn, stream);
+  else launch_tail_batch_nb<4>(l, n, tmax, dyn, stream);
   return hipGetLastError();
 }
 
