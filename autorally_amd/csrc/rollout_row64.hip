@@ -109,30 +109,38 @@ __device__ __forceinline__ void r64_rows(float a, float &lo, float &up)
   lo = __uint_as_float(x[0]);
   up = __uint_as_float(x[1]);
 }
-// activation k of this lane's rollout
-template <int K>
-__device__ __forceinline__ float r64_act(f32x2 L, f32x2 U)
+// the activation PAIR (a[2P], a[2P+1]) of this lane's rollout: one v_mov_b64_dpp row_newbcast (rollout_row.hip: row_bc2) of the
+// lower rows' pair (P < 16) or the upper rows' (P >= 16)
+template <int P>
+__device__ __forceinline__ f32x2 r64_pair(f32x2 L, f32x2 U)
 {
-  return r64_bc<(K >> 1) & 15>(K < 32 ? ((K & 1) ? L.y : L.x) : ((K & 1) ? U.y : U.x));
+  const f32x2 src = (P < 16) ? L : U;
+  return __builtin_bit_cast(f32x2, (long long)__builtin_amdgcn_mov_dpp(__builtin_bit_cast(long long, src), 0x150 + (P & 15), 0xF, 0xF, false));
 }
 typedef const volatile f32x2 __attribute__((address_space(3))) *r64_lds_p;
-// one link of the chain, written as the schedule it has to be (rollout_row.hip: row_dot_step): the weight request kPF links
-// ahead, the move for k + 1, the multiply-add of k
-template <int K>
-__device__ __forceinline__ void r64_step(f32x2 &z, float &v, f32x2 *ring, r64_lds_p base, f32x2 L, f32x2 U)
+// two links of the chain, written as the schedule they have to be (rollout_row.hip: row_dot_step): the weight requests kPF
+// links ahead, the multiply-add of 2P, the move for P + 1 in its shadow, the multiply-add of 2P + 1
+template <int P>
+__device__ __forceinline__ void r64_step(f32x2 &z, f32x2 &b, f32x2 *ring, r64_lds_p base, f32x2 L, f32x2 U)
 {
-  const f32x2 wk = ring[K % kPF];
+  constexpr int K = 2 * P;
+  const f32x2 w0 = ring[K % kPF];
   if constexpr (K + kPF < kH64) ring[K % kPF] = base[(K + kPF) * 32];
-  const float vn = r64_act<(K + 1 < kH64 ? K + 1 : kH64 - 1)>(L, U);
-  z = __builtin_elementwise_fma(wk, f32x2{v, v}, z);
+  z = __builtin_elementwise_fma(w0, f32x2{b.x, b.x}, z);
   __builtin_amdgcn_sched_barrier(0);
-  v = vn;
+  const f32x2 bn = r64_pair<(P + 1 < kH64 / 2 ? P + 1 : kH64 / 2 - 1)>(L, U);
+  const f32x2 w1 = ring[(K + 1) % kPF];
+  if constexpr (K + 1 + kPF < kH64) ring[(K + 1) % kPF] = base[(K + 1 + kPF) * 32];
+  __builtin_amdgcn_sched_barrier(0);
+  z = __builtin_elementwise_fma(w1, f32x2{b.y, b.y}, z);
+  __builtin_amdgcn_sched_barrier(0);
+  b = bn;
 }
-template <int K0>
-__device__ __forceinline__ void r64_steps16(f32x2 &z, float &v, f32x2 *ring, r64_lds_p base, f32x2 L, f32x2 U)
+template <int P0>
+__device__ __forceinline__ void r64_steps16(f32x2 &z, f32x2 &b, f32x2 *ring, r64_lds_p base, f32x2 L, f32x2 U)
 {
-#define S4(K) r64_step<K>(z, v, ring, base, L, U); r64_step<K + 1>(z, v, ring, base, L, U); r64_step<K + 2>(z, v, ring, base, L, U); r64_step<K + 3>(z, v, ring, base, L, U);
-  S4(K0) S4(K0 + 4) S4(K0 + 8) S4(K0 + 12)
+#define S4(P) r64_step<P>(z, b, ring, base, L, U); r64_step<P + 1>(z, b, ring, base, L, U); r64_step<P + 2>(z, b, ring, base, L, U); r64_step<P + 3>(z, b, ring, base, L, U);
+  S4(P0) S4(P0 + 4)
 #undef S4
 }
 // z = sum_k W[.][k] a[k] over the 64 activations of the rollout, k ascending; `base` = this lane's column of the layer's image
@@ -146,12 +154,12 @@ __device__ __forceinline__ f32x2 r64_layer(r64_lds_p base, f32x2 a)
   r64_rows(a.y, ly, uy);
   const f32x2 L = {lx, ly}, U = {ux, uy};
   f32x2 z = {0.0f, 0.0f};
-  float v = r64_act<0>(L, U);
+  f32x2 b = r64_pair<0>(L, U);
   __builtin_amdgcn_sched_barrier(0);
-  r64_steps16<0>(z, v, ring, base, L, U);
-  r64_steps16<16>(z, v, ring, base, L, U);
-  r64_steps16<32>(z, v, ring, base, L, U);
-  r64_steps16<48>(z, v, ring, base, L, U);
+  r64_steps16<0>(z, b, ring, base, L, U);   // (16 links each)
+  r64_steps16<8>(z, b, ring, base, L, U);
+  r64_steps16<16>(z, b, ring, base, L, U);
+  r64_steps16<24>(z, b, ring, base, L, U);
   return z;
 }
 
