@@ -35,51 +35,64 @@ namespace mppi {
 // and leaves its stride-slid copy for slideControlSeq; none of that is on the host's critical path.
 // Sums over k are pairwise (LDS tree) instead of the host's sequential loop: same value to ~1e-7.
 // ---------------------------------------------------------------------------------------------
+// Diagnostic build only (-DMPPI_TAIL_STAMPS, tools/tail_stamps.py): s_memrealtime stamps (100 MHz, comparable across CUs) of
+// row workgroup T/2 -- where the time between the tail kernel's first instruction and the publication of a row goes.  The
+// product build has no stamp instruction.
+#ifdef MPPI_TAIL_STAMPS
+__device__ unsigned long long g_tail_stamps[16];
+#define TSTAMP(i)                                                                                   \
+  do {                                                                                              \
+    if (block == (T / 2) * ((K + kRedChunk - 1) / kRedChunk) && threadIdx.x == 0) {                 \
+      unsigned long long t__;                                                                       \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
+      g_tail_stamps[i] = t__;                                                                       \
+    }                                                                                               \
+  } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 constexpr int kTailThreads = 256;
 constexpr int kRedChunk = 4096;  // rollouts staged per pass: 32 KiB of LDS (+ pad)
 
-__device__ __forceinline__ float wave_min(float v)
+// Wave-wide reductions that stay out of the LDS pipeline (ds_bpermute: ~100 cycles a step): two quad_perm steps, then
+// row_half_mirror and row_mirror (after the quad steps a quad's lanes are equal, so the mirrored lane holds "the other quad" /
+// "the other half"), then the two cross-row steps of gfx950: v_permlane16_swap / v_permlane32_swap on two copies of the
+// value leave the even row's (lower half's) value in the first result and the odd row's (upper half's) in the second, in
+// every lane.  Every lane ends with the same bits (each step is one commutative operation on the same two values).
+template <int CTRL>
+__device__ __forceinline__ float tail_dpp(float v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <bool MIN>
+__device__ __forceinline__ float wave_reduce(float v)
+{
+#define MPPI_RED(A, B) (MIN ? fminf((A), (B)) : (A) + (B))
+  v = MPPI_RED(v, tail_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = MPPI_RED(v, tail_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = MPPI_RED(v, tail_dpp<0x141>(v));  // row_half_mirror
+  v = MPPI_RED(v, tail_dpp<0x140>(v));  // row_mirror
+  const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = MPPI_RED(__uint_as_float(x[0]), __uint_as_float(x[1]));
+  const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = MPPI_RED(__uint_as_float(y[0]), __uint_as_float(y[1]));
+#undef MPPI_RED
   return v;
 }
-__device__ __forceinline__ float wave_sum(float v)
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce<true>(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<false>(v); }
+// Workgroup-wide (kTailThreads): ONE barrier -- every wave leaves its result in red4[wave], every thread combines the four
+// in the same order.  red4 must not be reused by a later reduction of the same workgroup (no barrier behind the reads).
+template <bool MIN>
+__device__ __forceinline__ float block_reduce(float v, float *red4)
 {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  v = wave_reduce<MIN>(v);
+  if (lane == 0) red4[wv] = v;
+  __syncthreads();
+  float r = red4[0];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float block_min(float v, float *red, float *bc)
-{
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  v = wave_min(v);
-  if (lane == 0) red[wv] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float m = red[0];
-    for (int i = 1; i < kTailThreads / 64; i++) m = fminf(m, red[i]);
-    *bc = m;
-  }
-  __syncthreads();
-  const float r = *bc;
-  __syncthreads();
-  return r;
-}
-__device__ __forceinline__ float block_sum(float v, float *red, float *bc)
-{
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  v = wave_sum(v);
-  if (lane == 0) red[wv] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float m = red[0];
-    for (int i = 1; i < kTailThreads / 64; i++) m += red[i];
-    *bc = m;
-  }
-  __syncthreads();
-  const float r = *bc;
-  __syncthreads();
+  for (int i = 1; i < kTailThreads / 64; i++) r = MIN ? fminf(r, red4[i]) : r + red4[i];
   return r;
 }
 
@@ -221,30 +234,40 @@ struct TailArgs {
 // K = 16384, measured: K=16384 T=100 23.8 -> 21.3 us, but T=150 30.0 -> 32.2 us -- the longer workgroups cost what the
 // removed kernel saved; so beyond 8192 the weights come from weights_kernel as before.)
 constexpr int kWideK = 8192;
-template <int CV>
-__device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int block)
+// `V`, `costs`, `K`, `T`: the values of a.V, a.costs, a.K, a.T as the kernel received them -- in the single-instance kernels
+// leading scalar parameters.  (Preloading them into scalar registers, -amdgpu-kernarg-preload-count, was measured: the
+// workgroup's first loads go out 0.1 us earlier and the step is unchanged; the same for the row rollout kernel -- its first
+// controls 0.28 us earlier, the STEP 0.3 us longer: the command processor reads the segment before it launches the first
+// wave.  profiles/r04_v_kernarg_preload.txt.  Not used.)
+// PRE: beta, eta, the trajectory cost and w[] were computed by weights_kernel (K > kWideK) -- a template parameter, so that the
+// cost loads of the other path do not wait for the argument segment either
+template <int CV, bool PRE = false>
+__device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int block, const float *V, const float *costs_p, const int K,
+                                                const int T)
 {
-  // chunk rows padded by 2 floats per 64-rollout group: lanes of one wave (m varies) hit
-  // distinct banks when they walk their chains in lock step.
-  __shared__ __attribute__((aligned(16))) float tile[kRedChunk * 2 + (kRedChunk / 64) * 2];
-  __shared__ float wtile[kRedChunk + kRedChunk / 64];  // +1 float per 64-rollout group: see the chain loop
-  __shared__ float red[kTailThreads / 64];
-  __shared__ float bc;
+  // The chunk of the row in LDS, de-interleaved: plane j holds V[t][k][j]; a 64-rollout group takes kGS = 68 floats (64 + 4:
+  // 16-B reads stay aligned and the groups of neighbouring lanes start in different banks), the normalised weights likewise --
+  // a chain reads its 64 values and 64 weights as 2 x 16 ds_read_b128 (interleaved planes and 4-B reads: 128 LDS
+  // instructions per chain, 0.74 us of the 5.6 a row workgroup took from its first instruction to the publication)
+  constexpr int kGS = 68, kPlane = (kRedChunk / 64) * kGS;
+  __shared__ __attribute__((aligned(16))) float tile[2][kPlane];
+  __shared__ __attribute__((aligned(16))) float wtile[kPlane];
+  __shared__ float redm[kTailThreads / 64], reds[kTailThreads / 64], redt[kTailThreads / 64];  // one per reduction (block_reduce)
   __shared__ int is_last;
-  extern __shared__ float dyn[];  // partial[K/64][2], then X[(T+4)*2] for the smoothing
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // partial[2][K/64], then X[(T+4)*2] for the smoothing
   float *partial = dyn;
   const int tid = threadIdx.x;
-  const int K = a.K, T = a.T;
   const int C = (K + kRedChunk - 1) / kRedChunk;  // workgroups per row
   const bool extra = (block == T * C);  // (single-launch form) publishes w[], beta, eta, trajectory cost
   const int t = extra ? 0 : block / C;
   const int base = extra ? 0 : (block % C) * kRedChunk;
   const int n = min(kRedChunk, K - base);  // rollouts of this workgroup's chunk (multiple of 64)
+  TSTAMP(0);  // first instructions
 
   // The chunk of row t is requested NOW, before anything else, so that its HBM latency overlaps the
   // latency of the cost vector and the weight arithmetic below (the row was written by the rollout
   // kernel on other XCDs: it comes from HBM / Infinity Cache, not from this L2).
-  const float *row = a.V + ((size_t)t * K + base) * 2;
+  const float *row = V + ((size_t)t * K + base) * 2;
   constexpr int kPre = kRedChunk / 2 / kTailThreads;  // float4 per thread in a full chunk
   float4 pre[kPre];
   {
@@ -258,7 +281,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   // ---- weights: beta, eta (every workgroup), w[] and the trajectory cost (the extra workgroup) ----
   // Each exp of the workgroup's own chunk is evaluated once and kept in LDS.
   float eta;
-  if (a.pre) {
+  if constexpr (PRE) {
     eta = a.scal[1];
     // the chunk's weights: four 16-B loads per thread, in flight together
     constexpr int kWV = kRedChunk / 4 / kTailThreads;
@@ -274,17 +297,16 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
       const int q = i * kTailThreads + tid;
       if (q < n / 4) {
         const int k = 4 * q;
-        float *wt = &wtile[k + (k >> 6)];
-        // weight = w/normalizer (:244) by the thread that owns the element: the normalising loop below
-        // walks elements other threads wrote and there is no barrier in between on this path
-        wt[0] = wv[i].x / eta; wt[1] = wv[i].y / eta; wt[2] = wv[i].z / eta; wt[3] = wv[i].w / eta;
+        // weight = w/normalizer (:244)
+        *reinterpret_cast<float4 *>(&wtile[(k >> 6) * kGS + (k & 63)]) =
+            make_float4(wv[i].x / eta, wv[i].y / eta, wv[i].z / eta, wv[i].w / eta);
       }
     }
   } else {
     // The K <= kRedChunk costs, 16 per thread, are requested with four 16-B loads that are in flight
     // together (and together with the row above): one memory round trip for the min and the exp pass.
     constexpr int kCostV = CV;
-    const float4 *c4 = reinterpret_cast<const float4 *>(a.costs);
+    const float4 *c4 = reinterpret_cast<const float4 *>(costs_p);
     const int K4 = K / 4;
     float4 cv[kCostV];
 #pragma unroll
@@ -293,51 +315,44 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
       cv[i] = (q < K4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     }
     float m = INFINITY;
+    TSTAMP(1);  // loads requested
 #pragma unroll
     for (int i = 0; i < kCostV; i++) m = fminf(fminf(m, fminf(cv[i].x, cv[i].y)), fminf(cv[i].z, cv[i].w));
-    const float beta = block_min(m, red, &bc);
+    TSTAMP(2);  // costs arrived, thread minimum
+    const float beta = block_reduce<true>(m, redm);
+    TSTAMP(3);  // beta
+    // the exps stay in this thread's registers: they are normalised and staged once eta is known (the chunk's), and the
+    // extra workgroup publishes all of them
     float part = 0.0f;
 #pragma unroll
     for (int i = 0; i < kCostV; i++) {
       const int q = i * kTailThreads + tid;
       if (q < K4) {
-        const int k = 4 * q;  // k .. k+3 lie in one 64-rollout group
         const float e0 = expf(-a.gamma * (cv[i].x - beta));  // normExpKernel :201
         const float e1 = expf(-a.gamma * (cv[i].y - beta));
         const float e2 = expf(-a.gamma * (cv[i].z - beta));
         const float e3 = expf(-a.gamma * (cv[i].w - beta));
-        if (CV == kRedChunk / 4 / kTailThreads || (k >= base && k < base + n)) {  // (wide: only this workgroup's chunk is staged)
-          const int kl = k - base;
-          float *wt = &wtile[kl + (kl >> 6)];
-          wt[0] = e0; wt[1] = e1; wt[2] = e2; wt[3] = e3;
-        }
-        if (CV != kRedChunk / 4 / kTailThreads) cv[i] = make_float4(e0, e1, e2, e3);  // kept for the extra workgroup below
+        cv[i] = make_float4(e0, e1, e2, e3);
         part += (e0 + e1) + (e2 + e3);
       }
     }
-    eta = block_sum(part, red, &bc);
+    TSTAMP(4);  // exps
+    eta = block_reduce<false>(part, reds);
+    TSTAMP(5);  // eta
     if (extra) {
       float tc = 0.0f;
-      if (CV == kRedChunk / 4 / kTailThreads) {
-        for (int k = tid; k < K; k += kTailThreads) {
-          const float e = wtile[k + (k >> 6)];
-          a.w[k] = e;
-          tc += e * e / eta;  // :651 (Q8)
-        }
-      } else {  // wide: the weights are in this thread's registers
 #pragma unroll
-        for (int i = 0; i < kCostV; i++) {
-          const int q = i * kTailThreads + tid;
-          if (q < K4) {
-            reinterpret_cast<float4 *>(a.w)[q] = cv[i];
-            tc += cv[i].x * cv[i].x / eta;
-            tc += cv[i].y * cv[i].y / eta;
-            tc += cv[i].z * cv[i].z / eta;
-            tc += cv[i].w * cv[i].w / eta;
-          }
+      for (int i = 0; i < kCostV; i++) {
+        const int q = i * kTailThreads + tid;
+        if (q < K4) {
+          reinterpret_cast<float4 *>(a.w)[q] = cv[i];
+          tc += cv[i].x * cv[i].x / eta;  // :651 (Q8)
+          tc += cv[i].y * cv[i].y / eta;
+          tc += cv[i].z * cv[i].z / eta;
+          tc += cv[i].w * cv[i].w / eta;
         }
       }
-      const float traj = block_sum(tc, red, &bc);
+      const float traj = block_reduce<false>(tc, redt);
       if (tid == 0) {
         __hip_atomic_store(&a.scal[0], beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.scal[1], eta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -347,34 +362,53 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
           publish_entry(a.res, T + 1, traj, 0.0f, a.seq);
         }
       }
+    } else {
+      // weight = w/normalizer (:244) of this workgroup's chunk, straight from the registers into LDS
+#pragma unroll
+      for (int i = 0; i < kCostV; i++) {
+        const int q = i * kTailThreads + tid;
+        const int kl = 4 * q - base;  // k .. k+3 lie in one 64-rollout group
+        if (q < K4 && kl >= 0 && kl < n)
+          *reinterpret_cast<float4 *>(&wtile[(kl >> 6) * kGS + (kl & 63)]) =
+              make_float4(cv[i].x / eta, cv[i].y / eta, cv[i].z / eta, cv[i].w / eta);
+      }
     }
   }
 
   // ---- weighted reduction of the chunk ----
+  const int G = K / 64;  // 64-rollout groups of a row
   if (!extra) {
 #pragma unroll
     for (int i = 0; i < kPre; i++) {
       const int q = tid + i * kTailThreads;
       if (q < n / 2) {
         const int kk = 2 * q;  // rollouts base+2q, base+2q+1
-        const int o = kk * 2 + (kk >> 6) * 2;
-        tile[o + 0] = pre[i].x; tile[o + 1] = pre[i].y; tile[o + 2] = pre[i].z; tile[o + 3] = pre[i].w;
+        const int o = (kk >> 6) * kGS + (kk & 63);
+        *reinterpret_cast<float2 *>(&tile[0][o]) = make_float2(pre[i].x, pre[i].z);
+        *reinterpret_cast<float2 *>(&tile[1][o]) = make_float2(pre[i].y, pre[i].w);
       }
     }
-    if (!a.pre)  // (block_sum above put a barrier between the exp pass and this one)
-      for (int q = tid; q < n; q += kTailThreads) wtile[q + (q >> 6)] = wtile[q + (q >> 6)] / eta;  // weight = w/normalizer, :244
+    TSTAMP(6);  // row staged (its loads arrived)
     __syncthreads();
+    TSTAMP(7);  // barrier
     for (int c = tid; c < (n / 64) * 2; c += kTailThreads) {
       const int ml = c >> 1, j = c & 1;
-      const float *p = tile + ml * 130 + j;
-      const float *wp = wtile + ml * 65;  // row stride 65: the 16 groups of a half-wave hit 16 banks
+      const float4 *p4 = reinterpret_cast<const float4 *>(&tile[j][ml * kGS]);
+      const float4 *w4 = reinterpret_cast<const float4 *>(&wtile[ml * kGS]);
       float acc = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 64; i++) acc = fmaf(wp[i], p[2 * i], acc);  // u_system += weight*u :246
-      if (C == 1) partial[ml * 2 + j] = acc;
-      else __hip_atomic_store(&a.part[((size_t)t * (K / 64) + base / 64 + ml) * 2 + j], acc, __ATOMIC_RELAXED,
+      for (int i = 0; i < 16; i++) {  // u_system += weight*u :246, the 64 rollouts of the group in order
+        const float4 wv = w4[i], pv = p4[i];
+        acc = fmaf(wv.x, pv.x, acc);
+        acc = fmaf(wv.y, pv.y, acc);
+        acc = fmaf(wv.z, pv.z, acc);
+        acc = fmaf(wv.w, pv.w, acc);
+      }
+      if (C == 1) partial[j * G + ml] = acc;
+      else __hip_atomic_store(&a.part[((size_t)t * G + base / 64 + ml) * 2 + j], acc, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_AGENT);
     }
+    TSTAMP(8);  // chains
     if (C > 1) {
       // the row is spread over C workgroups: the last to arrive at the row's counter collects all
       // chain results (same hand-off form as below: write-through stores, drained, then the counter)
@@ -388,23 +422,26 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
       __syncthreads();
       if (!is_last) return;
       last_arriver_acquire();
-      for (int i = tid; i < (K / 64) * 2; i += kTailThreads)
-        partial[i] = __hip_atomic_load(&a.part[(size_t)t * (K / 64) * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = tid; i < G * 2; i += kTailThreads)
+        partial[(i & 1) * G + (i >> 1)] = __hip_atomic_load(&a.part[(size_t)t * G * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
   float u = 0.0f;
   if (tid < 2 && !extra) {
-    const int groups = K / 64;
+    // thread j adds the partials of control j in order (:256-260); fetched 32 at a time as 16-B reads where the plane is aligned
+    const float *pj = partial + tid * G;
     int mm = 0;
-    for (; mm + 16 <= groups; mm += 16) {  // partials fetched 16 at a time, added in order (:256-260)
-      float v[16];
+    if ((G & 3) == 0) {
+      for (; mm + 32 <= G; mm += 32) {
+        float4 v[8];
 #pragma unroll
-      for (int i = 0; i < 16; i++) v[i] = partial[(mm + i) * 2 + tid];
+        for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(pj + mm + 4 * i);
 #pragma unroll
-      for (int i = 0; i < 16; i++) u += v[i];
+        for (int i = 0; i < 8; i++) { u += v[i].x; u += v[i].y; u += v[i].z; u += v[i].w; }
+      }
     }
-    for (; mm < groups; mm++) u += partial[mm * 2 + tid];
+    for (; mm < G; mm++) u += pj[mm];
     // write-through (sc1) store: the hand-off to the last workgroup below needs no L2 write-back
     __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -413,7 +450,9 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
     // soon as all T rows and the scalars carry this solve's sequence number, so nothing below -- the
     // arrival counter, the device-side smoothing for the next solve -- is on its critical path.
     const float u1 = __shfl(u, 1);  // all lanes of wave 0 active
+    TSTAMP(9);  // partials added
     if (tid == 0 && !extra && a.last_iter) publish_entry(a.res, t, u, u1, a.seq);
+    TSTAMP(10);  // row published (store issued)
   }
   // ---- arrival: the last workgroup smooths and publishes.  Hand-off form R1 of the MI355X guide
   // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
@@ -427,7 +466,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   if (tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (ticket == (unsigned)(a.pre ? T - 1 : T)) ? 1 : 0;  // T rows (+ the extra workgroup)
+    is_last = (ticket == (unsigned)(PRE ? T - 1 : T)) ? 1 : 0;  // T rows (+ the extra workgroup)
   }
   __syncthreads();
   if (!is_last) return;
@@ -486,13 +525,16 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   }
 }
 
-__global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const TailArgs a)
+template <bool PRE>
+__global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const float *V, const float *costs, const int K, const int T,
+                                                                  const TailArgs a)
 {
-  solve_tail_body<kRedChunk / 4 / kTailThreads>(a, (int)blockIdx.x);
+  solve_tail_body<kRedChunk / 4 / kTailThreads, PRE>(a, (int)blockIdx.x, V, costs, K, T);
 }
-__global__ __launch_bounds__(kTailThreads) void solve_tail_wide_kernel(const TailArgs a)  // kRedChunk < K <= kWideK, a.pre == 0
+__global__ __launch_bounds__(kTailThreads) void solve_tail_wide_kernel(const float *V, const float *costs, const int K, const int T,
+                                                                       const TailArgs a)  // kRedChunk < K <= kWideK, a.pre == 0
 {
-  solve_tail_body<kWideK / 4 / kTailThreads>(a, (int)blockIdx.x);
+  solve_tail_body<kWideK / 4 / kTailThreads>(a, (int)blockIdx.x, V, costs, K, T);
 }
 
 // The tails of several instances (K <= kRedChunk each: T + 1 workgroups per instance) in one launch, behind
@@ -509,7 +551,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const Ta
 #define MPPI_TAIL_BODY(A)                                                   \
   do {                                                                      \
     if ((int)blockIdx.x > (A).T) return;                                    \
-    solve_tail_body<kRedChunk / 4 / kTailThreads>((A), (int)blockIdx.x);    \
+    solve_tail_body<kRedChunk / 4 / kTailThreads>((A), (int)blockIdx.x, (A).V, (A).costs, (A).K, (A).T);    \
   } while (0)
   MPPI_BATCH_DISPATCH(NB, b, MPPI_TAIL_BODY);
 #undef MPPI_TAIL_BODY
@@ -642,9 +684,11 @@ hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
     hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, l.costs, l.w, l.scal, K, l.gamma,
                        l.last_iter ? l.res : nullptr, T, l.seq);
   if (K > kRedChunk && !a.pre)
-    hipLaunchKernelGGL(solve_tail_wide_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a);
+    hipLaunchKernelGGL(solve_tail_wide_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
+  else if (a.pre)
+    hipLaunchKernelGGL(solve_tail_kernel<true>, dim3(T * C), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
   else
-    hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + (a.pre ? 0 : 1)), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a);
+    hipLaunchKernelGGL(solve_tail_kernel<false>, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
   return hipGetLastError();
 }
 
@@ -694,3 +738,10 @@ hipError_t launch_tk_to_kt(const float *src, float *dst, int K, int T, hipStream
 }
 
 }  // namespace mppi
+
+#ifdef MPPI_TAIL_STAMPS
+extern "C" int mppi_debug_read_tail_stamps(unsigned long long *out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mppi::g_tail_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
