@@ -51,7 +51,14 @@ __device__ unsigned long long g_tail_stamps[16];
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
-constexpr int kTailThreads = 256;
+// Eight waves per workgroup: a lone wave issues a vector instruction every ~5.4 cycles whatever the SIMD could take
+// (tools/ub/valu_issue_ub.hip), so the 4 096 exps and divisions of a workgroup run on two waves per SIMD in half the time of
+// one -- a row is published 3.49 us after the first instruction instead of 3.98 (256 threads), 1 024 threads measure the same
+// (profiles/r04_v_tail_threads_ab.txt)
+#ifndef MPPI_TAIL_THREADS
+#define MPPI_TAIL_THREADS 512
+#endif
+constexpr int kTailThreads = MPPI_TAIL_THREADS;
 constexpr int kRedChunk = 4096;  // rollouts staged per pass: 32 KiB of LDS (+ pad)
 
 // Wave-wide reductions that stay out of the LDS pipeline (ds_bpermute: ~100 cycles a step): two quad_perm steps, then
