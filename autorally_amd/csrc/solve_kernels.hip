@@ -139,21 +139,17 @@ __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__
                                                                  int K, float gamma, float *res, int res_entry,
                                                                  unsigned seq)
 {
-  __shared__ float red[kWeightThreads / 64];
-  __shared__ float bc;
+  // one array per reduction and ONE barrier each: every wave leaves its result, every thread combines the sixteen in the same
+  // order (solve_tail_body: block_reduce)
+  __shared__ __attribute__((aligned(16))) float red3[3][kWeightThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  auto bcast = [&](float v, bool is_min) {
+  auto bcast = [&](float v, bool is_min, float *red) {
     v = is_min ? wave_min(v) : wave_sum(v);
     if (lane == 0) red[wv] = v;
     __syncthreads();
-    if (tid == 0) {
-      float r = red[0];
-      for (int i = 1; i < kWeightThreads / 64; i++) r = is_min ? fminf(r, red[i]) : r + red[i];
-      bc = r;
-    }
-    __syncthreads();
-    const float r = bc;
-    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < kWeightThreads / 64; i++) r = is_min ? fminf(r, red[i]) : r + red[i];
     return r;
   };
   // The first kWeightCache*4096 costs stay in registers (one 16-B load per thread and slot, all in
@@ -171,7 +167,7 @@ __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__
 #pragma unroll
   for (int i = 0; i < kWeightCache; i++) m = fminf(fminf(m, fminf(c[i].x, c[i].y)), fminf(c[i].z, c[i].w));
   for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) m = fminf(m, costs[k]);
-  const float beta = bcast(m, true);
+  const float beta = bcast(m, true, red3[0]);
   float part = 0.0f;
 #pragma unroll
   for (int i = 0; i < kWeightCache; i++) {
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__
     w[k] = e;
     part += e;
   }
-  const float eta = bcast(part, false);
+  const float eta = bcast(part, false, red3[1]);
   float tc = 0.0f;
 #pragma unroll
   for (int i = 0; i < kWeightCache; i++) {
@@ -201,7 +197,7 @@ __global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__
     const float e = w[k];  // own store
     tc += e * e / eta;
   }
-  const float traj = bcast(tc, false);
+  const float traj = bcast(tc, false, red3[2]);
   if (tid == 0) {
     scal[0] = beta; scal[1] = eta; scal[2] = traj;
     if (res) {  // last iteration: the host's copy
