@@ -23,7 +23,7 @@ namespace {
 bool form_supported(Form f, int hidden, int n_hidden)
 {
   switch (f) {
-    case Form::M44: return m44_variant_supported(hidden, n_hidden);
+    case Form::M44: case Form::M44Chain: return m44_variant_supported(hidden, n_hidden);
     case Form::Row64R8: case Form::Row64R16: return row64_variant_supported(hidden, n_hidden);
     case Form::Oct: return oct_variant_supported(hidden, n_hidden);
     case Form::Row: case Form::RowTree: return row_variant_supported(hidden, n_hidden);
@@ -46,7 +46,9 @@ struct FormRule {
 };
 const FormRule kFormRules[] = {
     // 64-wide nets in the latency regime: v_mfma_f32_4x4x1 with A-broadcast, every hidden weight in registers, no hand-over
-    // between waves (rollout_m44.hip); output layer as a butterfly, inside the north-star tolerance (tests/test_m44_gpu.py)
+    // between waves (rollout_m44.hip); output layer as a butterfly and -- since the end of round 4 -- the hidden layers as two
+    // accumulation chains (K=1920 6-64x4-4 148.5 -> 119.0 us, K=4096 6-64-64-4 70.3 -> 60.6 us, profiles/r04_x_m44_split_ab.txt),
+    // inside the north-star tolerance (tests/test_m44_gpu.py); "m44_chain" keeps the reference's order in the hidden layers
     {64, 2, 2, Form::M44, false, "profiles/r04_d_m44_first.txt: K=4096 70.5 us (oct 101, row64 107); K=8192 128 us (oct 166): 110 VGPRs, two workgroups per CU"},
     {64, 4, 2, Form::M44, false, "profiles/r04_d_m44_first.txt: 6-64x4-4 K=1920 149 us (oct 181, row64 227); K=4096 150 us (oct 182); 240 VGPRs = one workgroup per CU, so K=8192 runs in two rounds and still leads: T=60 182 us (oct 217), profiles/r04_e_form_selection.txt"},
     // ... in the reference's order: one M tile per dynamics wave, four of them + four riders (rollout_oct.hip)
@@ -104,7 +106,7 @@ bool form_generator_noise(const mppi_handle *h)
 bool has_noise_wave(const mppi_handle *h)
 {
   switch (form_of(h)) {
-    case Form::Bf3: case Form::Quad: case Form::Row: case Form::RowTree: case Form::Row64R8: case Form::Row64R16: case Form::M44:
+    case Form::Bf3: case Form::Quad: case Form::Row: case Form::RowTree: case Form::Row64R8: case Form::Row64R16: case Form::M44: case Form::M44Chain:
       return true;
     case Form::Oct: case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
       return !form_generator_noise(h);
@@ -146,7 +148,8 @@ const char *mppi_rollout_variant(const mppi_handle *h)
     case Form::Row64R8: case Form::Row64R16:
       snprintf(buf, sizeof(buf), "valu_row64_r%d_tree_h%d_l%d", f == Form::Row64R8 ? 8 : 16, h->hidden, h->n_hidden);
       break;
-    case Form::M44: snprintf(buf, sizeof(buf), "mfma4x4x1_h%d_l%d_m44_tree", h->hidden, h->n_hidden); break;
+    case Form::M44: snprintf(buf, sizeof(buf), "mfma4x4x1_h%d_l%d_m44_split_tree", h->hidden, h->n_hidden); break;
+    case Form::M44Chain: snprintf(buf, sizeof(buf), "mfma4x4x1_h%d_l%d_m44_tree", h->hidden, h->n_hidden); break;
     case Form::Oct: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_oct8w%s", h->hidden, h->n_hidden, gen); break;
     case Form::Quad: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_quad4w", h->hidden, h->n_hidden); break;
     case Form::Fused256: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_fused_b256", h->hidden, h->n_hidden); break;
@@ -178,9 +181,9 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     if ((rc = need(h->mfma_ok && row_variant_supported(h->hidden, h->n_hidden), "row form exists for 6-32x2-4"))) return rc;
     h->forced = strcmp(name, "row_tree") == 0 ? Form::RowTree : Form::Row;
   }
-  else if (strcmp(name, "m44") == 0) {
+  else if (strcmp(name, "m44") == 0 || strcmp(name, "m44_chain") == 0) {
     if ((rc = need(h->mfma_ok && m44_variant_supported(h->hidden, h->n_hidden), "m44 form exists for 6-64x2-4 and 6-64x4-4"))) return rc;
-    h->forced = Form::M44;
+    h->forced = name[3] == 0 ? Form::M44 : Form::M44Chain;
   }
   else if (strcmp(name, "row64") == 0 || strcmp(name, "row64_r8") == 0 || strcmp(name, "row64_r16") == 0) {
     if ((rc = need(h->mfma_ok && row64_variant_supported(h->hidden, h->n_hidden), "row64 form exists for 6-64x2-4 and 6-64x4-4"))) return rc;
@@ -233,7 +236,7 @@ int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max
     if ((r.hidden != 0 && r.hidden != h->hidden) || (r.n_hidden != 0 && r.n_hidden != h->n_hidden)) continue;
     if (!form_supported(r.form, h->hidden, h->n_hidden)) continue;
     switch (r.form) {
-      case Form::M44: put("m44"); break;
+      case Form::M44: put("m44"); put("m44_chain"); break;
       case Form::Oct: put("oct"); break;
       case Form::RowTree: put("row_tree"); put("row_exact"); break;
       case Form::Quad: put("quad"); break;

@@ -47,7 +47,8 @@ enum class Form : int {
   Multi4Tree,                       // ... ND = 4 with the output layer as a butterfly over a rollout's four lanes
   Row, RowTree,                     // rollout_row.hip: 6-32-32-4 on the vector ALU; Tree: butterfly output layer
   Row64R8, Row64R16,                // rollout_row64.hip: 64-wide nets on the vector ALU, 8 / 16 rollouts per group
-  M44,                              // rollout_m44.hip: 64-wide nets on v_mfma_f32_4x4x1 with A-broadcast
+  M44, M44Chain,                    // rollout_m44.hip: 64-wide nets on v_mfma_f32_4x4x1 with A-broadcast; hidden layers as two
+                                    // accumulation chains (the automatic form) / Chain: one, the reference's order
   ValuReg, ValuLds,                 // rollout_valu.hip: throughput-style vector kernels (any layer list: ValuLds)
   Bf1, Bf2, Bf3,                    // rollout_bf.hip: basis-function model, waves per 64 rollouts
 };

@@ -58,7 +58,7 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.noise = noise;
   a.costs = h->d_costs;
   const Form f = form_of(h);
-  a.wpack = form_is_row(f) ? h->d_rowpack : form_is_row64(f) ? h->d_row64pack : f == Form::M44 ? h->d_m44pack
+  a.wpack = form_is_row(f) ? h->d_rowpack : form_is_row64(f) ? h->d_row64pack : (f == Form::M44 || f == Form::M44Chain) ? h->d_m44pack
             : f == Form::ValuReg ? h->d_theta_s : (f == Form::ValuLds || h->basis) ? h->d_theta : h->d_wpack;
   a.inv_t = h->d_invt;
   a.K = h->K;
@@ -91,7 +91,8 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
       e = launch_rollout_multi(h->hidden, h->n_hidden, a, form_multi_nd(f), h->stream);
       break;
     case Form::Oct: e = launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream); break;
-    case Form::M44: e = launch_rollout_m44(h->hidden, h->n_hidden, a, h->stream); break;
+    case Form::M44: e = launch_rollout_m44(h->hidden, h->n_hidden, a, true, h->stream); break;
+    case Form::M44Chain: e = launch_rollout_m44(h->hidden, h->n_hidden, a, false, h->stream); break;
     case Form::Row64R8: case Form::Row64R16: e = launch_rollout_row64(h->hidden, h->n_hidden, a, f == Form::Row64R8 ? 8 : 16, h->stream); break;
     case Form::Row: case Form::RowTree: e = launch_rollout_row(h->hidden, h->n_hidden, a, f == Form::RowTree, h->stream); break;
     case Form::Quad: case Form::Fused64: case Form::Fused256:

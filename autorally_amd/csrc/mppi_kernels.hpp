@@ -61,7 +61,7 @@ hipError_t launch_rollout_row64(int hidden, int n_hidden, const RolloutArgs &a, 
 // butterfly (NOT the reference's summation order: opt-in by tolerance); a.wpack = pack_m44_weights (mppi_abi.hip)
 bool m44_variant_supported(int hidden, int n_hidden);
 int m44_pack_floats(int n_hidden);
-hipError_t launch_rollout_m44(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream);
+hipError_t launch_rollout_m44(int hidden, int n_hidden, const RolloutArgs &a, bool split, hipStream_t stream);  // split: two chains per hidden layer
 
 // rollout_valu.hip (generic vector-ALU kernel, any layer list)
 struct NetDesc {

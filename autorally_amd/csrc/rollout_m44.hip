@@ -148,7 +148,7 @@ __device__ __forceinline__ float m44_out_tree(const f32x2 (&q)[4], const f32x2 (
   return v;
 }
 
-template <int NHID>
+template <int NHID, bool SPLIT>
 __device__ __forceinline__ void m44_dynamics(const RolloutArgs &a, M44Shared &sh, const int w)
 {
   constexpr bool OUT_LDS = (NHID > 2);
@@ -242,11 +242,25 @@ __device__ __forceinline__ void m44_dynamics(const RolloutArgs &a, M44Shared &sh
           }
         }
       }
-      d = m44_f4{0.0f, 0.0f, 0.0f, 0.0f};
-      m44_steps16<0>(d, Tr, wh[l - 1]);
-      m44_steps16<16>(d, Tr, wh[l - 1]);
-      m44_steps16<32>(d, Tr, wh[l - 1]);
-      m44_steps16<48>(d, Tr, wh[l - 1]);
+      if constexpr (SPLIT) {
+        // TWO accumulation chains, even / odd k, added at the end: a dependent v_mfma_f32_4x4x1 issues every 12.2 cycles, two
+        // independent ones every ~8 -- a 64-input layer 780 -> ~520 cycles (6-64x4-4, K=1920: rollout 148.5 -> 119.0 us).  NOT the
+        // reference's order (neural_net_model.cu:379-394 sums k ascending): the form's own oracle mode is 5, and it is held
+        // against the nominal oracle at the north-star criteria like the butterfly output layer (tests/test_m44_gpu.py)
+        m44_f4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#define S2(K) m44_step<K>(d0, Tr, wh[l - 1]); m44_step<K + 1>(d1, Tr, wh[l - 1]);
+#define S8(K) S2(K) S2(K + 2) S2(K + 4) S2(K + 6)
+        S8(0) S8(8) S8(16) S8(24) S8(32) S8(40) S8(48) S8(56)
+#undef S8
+#undef S2
+        d = d0 + d1;
+      } else {
+        d = m44_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        m44_steps16<0>(d, Tr, wh[l - 1]);
+        m44_steps16<16>(d, Tr, wh[l - 1]);
+        m44_steps16<32>(d, Tr, wh[l - 1]);
+        m44_steps16<48>(d, Tr, wh[l - 1]);
+      }
       m44_tanh(d, bsv[l], act);
     }
     m44_transpose(act, Tr, hi, od);
@@ -275,7 +289,7 @@ __device__ __forceinline__ void m44_dynamics(const RolloutArgs &a, M44Shared &sh
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
-template <int NHID, bool AFFINE, bool CTRL>
+template <int NHID, bool AFFINE, bool CTRL, bool SPLIT>
 __global__ __launch_bounds__(512) void rollout_m44_kernel(const RolloutArgs a)
 {
   using SH = M44Shared;
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(512) void rollout_m44_kernel(const RolloutArgs a)
     for (int s = 0; s < 4; s++) sh.wo[s][lane] = src[s * 64];
   }
   __syncthreads();  // the only barrier
-  if (role < 4) m44_dynamics<NHID>(a, sh, role);
+  if (role < 4) m44_dynamics<NHID, SPLIT>(a, sh, role);
   else if (role == RO::kCost) group_cost_wave4<SH, CTRL>(a, sh);
   else if (role == RO::kCtl) group_control_wave(a, sh);
   else if (role == RO::kPose) group_pose_wave4<SH, AFFINE>(a, sh);
@@ -311,22 +325,24 @@ __global__ __launch_bounds__(512) void rollout_m44_kernel(const RolloutArgs a)
 bool m44_variant_supported(int hidden, int n_hidden) { return hidden == 64 && (n_hidden == 2 || n_hidden == 4); }
 int m44_pack_floats(int n_hidden) { return (n_hidden == 2 ? m44_q_total<2>() : m44_q_total<4>()) * 64 * 4; }
 
-template <int NHID>
+template <int NHID, bool SPLIT>
 static hipError_t launch_m44(const RolloutArgs &a, hipStream_t stream)
 {
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   const dim3 grid(a.K / kRolloutsPerWave), block(512);
-  if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, false>), grid, block, 0, stream, a);
-  else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, true>), grid, block, 0, stream, a);
-  else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, false>), grid, block, 0, stream, a);
-  else MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, true>), grid, block, 0, stream, a);
+  if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, false, SPLIT>), grid, block, 0, stream, a);
+  else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, true, SPLIT>), grid, block, 0, stream, a);
+  else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, false, SPLIT>), grid, block, 0, stream, a);
+  else MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, true, SPLIT>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_rollout_m44(int hidden, int n_hidden, const RolloutArgs &a, hipStream_t stream)
+// split: the hidden layers as two accumulation chains (the automatic form); false: one chain, the reference's order ("m44_chain")
+hipError_t launch_rollout_m44(int hidden, int n_hidden, const RolloutArgs &a, bool split, hipStream_t stream)
 {
   if (!m44_variant_supported(hidden, n_hidden) || a.K % kRolloutsPerWave != 0) return hipErrorInvalidValue;
-  return n_hidden == 2 ? launch_m44<2>(a, stream) : launch_m44<4>(a, stream);
+  if (n_hidden == 2) return split ? launch_m44<2, true>(a, stream) : launch_m44<2, false>(a, stream);
+  return split ? launch_m44<4, true>(a, stream) : launch_m44<4, false>(a, stream);
 }
 
 }  // namespace mppi

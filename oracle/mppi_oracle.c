@@ -110,6 +110,19 @@ static float out_tree_dot_multi(const float *w, const float *a, int nin)
   return (P[0] + P[2]) + (P[1] + P[3]);
 }
 
+/* fma_mode 5: the 4x4x1-MFMA kernel's automatic form (rollout_m44.hip, SPLIT): as mode 3, and every 64-input HIDDEN layer as two
+ * accumulation chains -- even k and odd k, each a fused multiply-add chain from 0, k ascending -- added at the end (even + odd).
+ * Like modes 2-4 NOT the reference's order: held against the nominal mode at the north-star tolerance. */
+static float hidden_split2_dot(const float *w, const float *a, int nin)
+{
+  float e = 0.0f, o = 0.0f;
+  for (int k = 0; k < nin; k += 2) {
+    e = fmaf(w[k], a[k], e);
+    o = fmaf(w[k + 1], a[k + 1], o);
+  }
+  return e + o;
+}
+
 /* PI/neural_net_model.cu:357-410.  k ascending, bias added after the dot product (:389-394). */
 void orc_nn_forward(const float *theta, const int *layers, int n_layers, const float *in,
                     float *out, int fma_mode)
@@ -125,7 +138,8 @@ void orc_nn_forward(const float *theta, const int *layers, int n_layers, const f
     for (int j = 0; j < nout; j++) {
       float tmp = 0.0f;
       if (fma_mode == 2 && l == n_layers - 2 && (nin == 32 || nin == 64)) tmp = out_tree_dot(W + j * nin, cur, nin);
-      else if (fma_mode == 3 && l == n_layers - 2 && nin == 64) tmp = out_tree_dot_m44(W + j * nin, cur);
+      else if ((fma_mode == 3 || fma_mode == 5) && l == n_layers - 2 && nin == 64) tmp = out_tree_dot_m44(W + j * nin, cur);
+      else if (fma_mode == 5 && l >= 1 && l < n_layers - 2 && nin == 64) tmp = hidden_split2_dot(W + j * nin, cur, nin);
       else if (fma_mode == 4 && l == n_layers - 2 && nin % 4 == 0) tmp = out_tree_dot_multi(W + j * nin, cur, nin);
       else for (int k = 0; k < nin; k++) tmp = mac(W[j * nin + k], cur[k], tmp, fma_mode);
       tmp += b[j];

@@ -71,7 +71,8 @@ typedef struct {
   int fma_mode;       /* 1: nvcc-style FMA contraction (nominal), 0: none,
                          2: as 1 with the output layer summed in the row-tree kernels' order (mppi_oracle.c: out_tree_dot),
                          3: as 1 with the output layer in the 4x4x1-MFMA kernel's order (out_tree_dot_m44),
-                         4: as 1 with the output layer in the multi4-tree kernel's order (out_tree_dot_multi) */
+                         4: as 1 with the output layer in the multi4-tree kernel's order (out_tree_dot_multi),
+                         5: as 3 with every 64-input hidden layer as two accumulation chains, even / odd k (hidden_split2_dot) */
   int nthreads;       /* OpenMP threads for the k loop; <=1 = serial */
   /* Second dynamics family: GeneralizedLinear<CarBasisFuncs,7,2,25,CarKinematics,3>,
    * PI/generalized_linear.cu:169-245 + PI/car_bfs.cuh:44-120.  bf_W != NULL selects it (theta/layers

@@ -8,7 +8,10 @@ from oracle import oracle as O
 def oracle_mode_for(variant_name):
     """The oracle's arithmetic mode (orc_problem.fma_mode) that states the summation order of a kernel form, by the name
     mppi_rollout_variant gives it: 1 = the reference's order in every layer (every "exact" form); the tree forms re-associate
-    the OUTPUT layer only -- 2: row-tree / row64 butterflies, 3: the 4x4x1-MFMA form, 4: the multi4-tree form."""
+    the OUTPUT layer only -- 2: row-tree / row64 butterflies, 3: the 4x4x1-MFMA form with one chain per hidden layer ("m44_chain"),
+    4: the multi4-tree form; 5: the automatic 4x4x1-MFMA form, whose hidden layers are two accumulation chains as well."""
+    if "m44_split" in variant_name:
+        return 5
     if "m44" in variant_name:
         return 3
     if "multi4_tree" in variant_name:

@@ -1,9 +1,9 @@
 """The latency form of 64-wide nets on v_mfma_f32_4x4x1 with A-matrix broadcast (rollout_m44.hip): four rollouts per wave, all
-hidden weights in registers, hidden layers in the reference's k-ascending order (one MFMA per k), the OUTPUT layer as a
-butterfly over the lanes (oracle fma_mode 3).
+hidden weights in registers, the OUTPUT layer as a butterfly over the lanes; the hidden layers as TWO accumulation chains (even /
+odd k: the automatic form "m44", oracle fma_mode 5) or as one chain in the reference's k-ascending order ("m44_chain", fma_mode 3).
 
 Like the row-tree form of 32-wide nets (tests/test_row_tree_gpu.py) it is held to two bars:
-  * its own oracle mode (fma_mode 3: the butterfly's summation order): applied controls bit for bit, costs p99 < 5e-6,
+  * its own oracle mode (tests/helpers.py: oracle_mode_for): applied controls bit for bit, costs p99 < 5e-6,
     flipped rollouts <= K/200, U <= 1e-4;
   * the NOMINAL oracle (fma_mode 1, the reference's order): U L-inf <= 1e-4, trajectory cost rel <= 1e-4, flipped <= K/200.
 Models: 6-64-64-4 (synthetic weights, BASELINE config 4's shape) and the reference's shipped 6-64-64-64-64-4
@@ -18,7 +18,7 @@ from autorally_amd import capi
 from autorally_amd import params as P
 from autorally_amd import synthetic as S
 from oracle import oracle as O
-from tests.helpers import noise_for, rel_err, warm_U
+from tests.helpers import noise_for, oracle_mode_for, rel_err, warm_U
 
 pytestmark = pytest.mark.gpu
 
@@ -52,8 +52,9 @@ def _gpu(cfg, U0, eps, variant):
     return got
 
 
-CASES = [("h64", 64, 7, "m44"), ("h64", 256, 40, "m44"), ("h64", 4096, 100, "m44"), ("h64", 2048, 100, "m44"),
-         ("wd", 1920, 100, "m44"), ("wd", 192, 37, "m44"), ("wd", 4096, 60, "m44")]
+CASES = [(m, K, T, v) for v in ("m44", "m44_chain")
+         for (m, K, T) in (("h64", 64, 7), ("h64", 256, 40), ("h64", 4096, 100), ("h64", 2048, 100),
+                           ("wd", 1920, 100), ("wd", 192, 37), ("wd", 4096, 60))]
 
 
 @pytest.mark.parametrize("model,K,T,variant", CASES)
@@ -63,9 +64,9 @@ def test_m44_form_against_its_mode_and_the_nominal_oracle(golden_dir, model, K, 
     eps = noise_for(cfg, 1234)
     hist = np.zeros(4, np.float32)
     got = _gpu(cfg, U0, eps, variant)
-    assert "m44" in got["variant"]
+    assert "m44" in got["variant"] and ("m44_split" in got["variant"]) == (variant == "m44")
     exact = _gpu(cfg, U0, eps, "oct")
-    ref2 = O.Oracle(cfg, fma_mode=3, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps)
+    ref2 = O.Oracle(cfg, fma_mode=oracle_mode_for(got["variant"]), nthreads=8).compute_control(cfg["start_state"], U0, hist, eps)
     ref1 = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps)
     # ---- its own mode
     np.testing.assert_array_equal(got["V"].view(np.uint32), ref2["V"][-1].view(np.uint32))
@@ -107,14 +108,14 @@ def test_m44_generator_mode_equals_explicit_noise(golden_dir, model):
     sol.close()
 
 
-def test_m44_hidden_layers_keep_the_reference_order(golden_dir):
-    """Only the output layer is re-associated: against the row64 form (the same hidden chains on the vector ALU, another
+def test_m44_chain_hidden_layers_keep_the_reference_order(golden_dir):
+    """"m44_chain": only the output layer is re-associated: against the row64 form (the same hidden chains on the vector ALU, another
     output butterfly) and the oct form (everything in the reference's order) the costs agree to the last digits on all
     but the threshold-grazing rollouts."""
     cfg = _cfg(golden_dir, "wd", 512, 60)
     U0 = warm_U(cfg)
     eps = noise_for(cfg, 1234)
-    a, b, c = _gpu(cfg, U0, eps, "m44"), _gpu(cfg, U0, eps, "row64"), _gpu(cfg, U0, eps, "oct")
+    a, b, c = _gpu(cfg, U0, eps, "m44_chain"), _gpu(cfg, U0, eps, "row64"), _gpu(cfg, U0, eps, "oct")
     for other in (b, c):
         assert float(np.percentile(rel_err(a["costs"], other["costs"]), 99)) < 5e-6
         assert np.max(np.abs(a["U"] - other["U"])) <= 1e-4

@@ -136,6 +136,34 @@ def test_tree_mode_of_the_output_layer(golden_dir, name):
     assert worst21 <= max(2 * worst01, 4e-6), (worst21, worst01)  # ... by no more than FMA contraction does
 
 
+@pytest.mark.parametrize("name", [m for m in MODELS if "wider" in m])
+def test_split_hidden_mode_of_the_64_wide_net(golden_dir, name):
+    """fma_mode 5 -- the 4x4x1-MFMA kernel's automatic form: every 64-input hidden layer as two accumulation chains (even / odd
+    k) added at the end, the output layer as in mode 3 -- is pinned by the same reference-Python vectors of the shipped
+    6-64-64-64-64-4 model at the same 1e-5, stays within the spread the FMA / no-FMA modes have between themselves, leaves the
+    kinematics alone and within 2e-5 of the one-chain mode 3 (the order itself is pinned bit for bit on the GPU,
+    tests/test_m44_gpu.py)."""
+    g = load_nn_golden(golden_dir)
+    o0, o1, o3, o5 = (_oracle_for(golden_dir, name, g, m) for m in (0, 1, 3, 5))
+    states, ctrls, ders = g[name + "/states"], g[name + "/controls"], g[name + "/state_ders"]
+    layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", name + ".npz"))
+    assert list(layers) == [6, 64, 64, 64, 64, 4]
+    worst51 = worst01 = 0.0
+    differs = 0
+    for s, u, d in zip(states, ctrls, ders):
+        sd5, sd3, sd1, sd0 = o5.state_deriv(s, u), o3.state_deriv(s, u), o1.state_deriv(s, u), o0.state_deriv(s, u)
+        assert float(np.max(np.abs(sd5 - d) / np.maximum(1.0, np.abs(d)))) < 1e-5
+        np.testing.assert_array_equal(sd5[:3], sd1[:3])  # kinematics untouched
+        worst51 = max(worst51, float(np.max(np.abs(sd5 - sd1))))
+        worst01 = max(worst01, float(np.max(np.abs(sd0 - sd1))))
+        differs += int(np.any(sd5 != sd3))
+        # against the one-chain form of the same kernel (mode 3): a re-association of 3 x 64 x 64 products per step
+        out3 = o3.state_deriv(s, u)[3:]
+        assert float(np.max(np.abs(sd5[3:] - out3))) < 2e-5
+    assert differs > 0
+    assert worst51 <= max(2 * worst01, 8e-6), (worst51, worst01)
+
+
 # ---------------- MRG32k3a known answers ----------------
 # L'Ecuyer, Simard, Chen, Kelton, "An object-oriented random-number package with many long
 # streams and substreams" (RngStreams): A1p76, A2p76, A1p127, A2p127.
