@@ -33,7 +33,7 @@ extern "C" {
  *    four-wavefront workgroups; variant names "_fused_b256", "_3w", "_multiN", "_oct8w", "valu_row8w_*"; variants "row", "multi4u". */
 /* 3: + mppi_set_host_threads, mppi_compute_feedback_gains_pair. */
 /* 4: + mppi_debug_capture_iterations, mppi_debug_get_iterations, mppi_set_wait_timeout, mppi_debug_form_candidates; variants
- *    "row_tree", "row_exact", "row64[_r8|_r16]", "m44"; names "valu_row8w_tree_*", "valu_row64_r*_tree_*", "mfma4x4x1_*_m44_tree". */
+ *    "row_tree", "row_exact", "row64[_r8|_r16]", "m44"; names "valu_row8w_tree_*", "valu_row64_r*_tree_*", "mfma4x4x1_*_m44_split_tree" (automatic), "mfma4x4x1_*_m44_tree" ("m44_chain"). */
 #define MPPI_ABI_VERSION 4
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
@@ -254,13 +254,14 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
  * "_fused_b64", "valu_row8w_h32_l2" (row form, exact output chain), "valu_reg_lds", "valu_lds",
  * "basis_funcs25_valu[_2w|_3w]".  Forms whose OUTPUT layer is summed as a butterfly over lanes (hidden layers unchanged; inside
  * the 1e-4 tolerance on the controls, not bit-identical to the former): "valu_row8w_tree_h32_l2" (6-32-32-4 up to 8192
- * rollouts: the automatic choice), "mfma4x4x1_h64_l<N>_m44_tree" (64-wide nets up to 8192 rollouts: automatic),
+ * rollouts: the automatic choice), "mfma4x4x1_h64_l<N>_m44_split_tree" (64-wide nets up to 8192 rollouts: automatic; its 64-input
+ * HIDDEN layers are summed as two chains, even and odd k; "mfma4x4x1_h64_l<N>_m44_tree" = variant "m44_chain": one chain),
  * "mfma16x16x4_h<H>_l<N>_multi4_tree[_gen]" (beyond: automatic), "valu_row64_r{8,16}_tree_h64_l<N>" (opt-in). */
 const char *mppi_rollout_variant(const mppi_handle *h);
 /* Force a form (A/B of SURVEY cfg 4 and of the kernel forms): "auto" (the selection table of csrc/abi_forms.hip);
  * "mfma" (the table restricted to forms that keep the reference's summation order in every layer) | "valu" | "valu_lds" (the
- * throughput-style vector kernels); by name: "row" = "row_exact" | "row_tree" (6-32-32-4 on the vector ALU), "m44" (64-wide
- * nets on v_mfma_f32_4x4x1), "row64" | "row64_r8" | "row64_r16" (64-wide nets on the vector ALU, weights from LDS), "quad",
+ * throughput-style vector kernels); by name: "row" = "row_exact" | "row_tree" (6-32-32-4 on the vector ALU), "m44" | "m44_chain" (64-wide
+ * nets on v_mfma_f32_4x4x1; hidden layers as two accumulation chains | one, the reference's order), "row64" | "row64_r8" | "row64_r16" (64-wide nets on the vector ALU, weights from LDS), "quad",
  * "oct" | "oct_gen", "multi4" | "multi2" | "multi1" ("_gen" appended: eps from the stand-alone generator kernel),
  * "multi4_tree[_gen]", "multi4u[_gen]", "fused" = "block256" | "block64".  Basis-function model: "bf3" (dynamics + cost +
  * control wavefront per 64 rollouts) | "quad" (dynamics + cost) | "fused" (one).  MPPI_ERR_UNSUPPORTED if the handle's model
