@@ -75,8 +75,9 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.rng_in = nullptr;
   a.rng_out = nullptr;
   a.inline_noise = 0;
-  a.spin_budget = h->spin_budget;
-  a.fault_wave = h->fault_wave;
+  // roles 32-34 are waits of the streaming tail kernel (tail_launch): the rollout runs with its defaults
+  a.spin_budget = h->fault_wave >= 32 ? 0 : h->spin_budget;
+  a.fault_wave = h->fault_wave >= 32 ? 0 : h->fault_wave;
   fill_cost_args(h, a.cost);
 }
 
@@ -275,6 +276,13 @@ int wait_pending(mppi_handle *h)
   // Anything else means a rollout wavefront gave up on a hand-over (its spin budget) and poisoned
   // its costs: report it instead of returning a NaN control sequence.
   if (!(h->eta >= 1.0f)) return fail(h, MPPI_ERR_HIP, "solve produced a non-finite normaliser (device hand-over failed)");
+  if (tail_is_stream(h->K)) {
+    // the one-launch tail of many-chunk solves: a row workgroup whose wait for another workgroup's granule ran out of time
+    // published NaN in place of what it waited for
+    bool finite = std::isfinite(h->traj_cost);
+    for (size_t i = 0; i < h->U.size() && finite; i++) finite = std::isfinite(h->U[i]);
+    if (!finite) return fail(h, MPPI_ERR_HIP, "solve produced non-finite controls (device hand-over failed)");
+  }
   if (h->pending_timed) {
     h->pending_timed = false;
     for (size_t it = 0; it < h->ev.size(); it++) {
@@ -317,6 +325,12 @@ TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last)
   l.slid = (last && wants_slid_copy(h)) ? h->d_in_buf[1 - h->in_cur] : nullptr;
   l.slide_stride = h->cfg.optimization_stride;
   l.init0 = h->cfg.init_control[0]; l.init1 = h->cfg.init_control[1];
+  // the one-launch streaming tail (K > 8192): granule buffers, this launch's tag (the caller advanced it), wait deadline; the
+  // tests' fault roles 32-34 shorten the deadline to spin_budget x 1 us
+  l.gx = h->d_gx; l.gpart = reinterpret_cast<unsigned long long *>(h->d_part);
+  l.epoch = h->tail_epoch;
+  l.fault = h->fault_wave >= 32 ? h->fault_wave : 0;
+  l.poll_ticks = (l.fault && h->spin_budget > 0) ? (unsigned)h->spin_budget * 100u : h->tail_poll_ticks;
   return l;
 }
 
@@ -381,6 +395,7 @@ int enqueue_solve(mppi_handle *h, const float *state)
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], h->stream));
     const bool last = (it == iters - 1);
     const bool want_slid = last && wants_slid_copy(h);
+    if (++h->tail_epoch == 0) h->tail_epoch = 1;  // the tag of this launch's granules
     HIPCHK(h, launch_solve_tail(tail_launch(h, noise, last), h->stream));
     if (last) h->slid_valid = want_slid;
     if (h->capture) {  // test hook: what this iteration left (the last iteration's raw U is in the result block)

@@ -49,6 +49,7 @@ void free_all(mppi_handle *h)
     if (p) (void)hipFree(p);
   if (h->d_invt) (void)hipFree(h->d_invt);
   if (h->d_counter) (void)hipFree(h->d_counter);
+  if (h->d_gx) (void)hipFree(h->d_gx);
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
   for (uint32_t *p : up)
     if (p) (void)hipFree(p);
@@ -194,7 +195,15 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   h->gen_async = (size_t)h->K * (size_t)h->T >= ((size_t)1 << 20);
   CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
   CR(hipMemset(h->d_counter, 0, sizeof(unsigned) * (1 + (size_t)h->T)));
-  if (h->K > 4096) CR(hipMalloc(&h->d_part, sizeof(float) * (size_t)h->T * (h->K / 64) * 2));
+  if (h->K > 4096) {
+    // chain results of a row spread over several workgroups: floats (K <= 8192, counter hand-off), 8-byte granules beyond
+    // (solve_tail_stream_kernel); zeroed once -- a granule counts only with the tag of the launch that reads it
+    const size_t part_bytes = sizeof(unsigned long long) * (size_t)h->T * (h->K / 64) * 2;
+    CR(hipMalloc(&h->d_part, part_bytes));
+    CR(hipMemset(h->d_part, 0, part_bytes));
+    CR(hipMalloc(&h->d_gx, sizeof(unsigned long long) * kTailExchangeGranules));
+    CR(hipMemset(h->d_gx, 0, sizeof(unsigned long long) * kTailExchangeGranules));
+  }
   CR(hipMalloc(&h->d_stage, sizeof(float) * KT2));
   CR(hipMalloc(&h->d_costs, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_w, sizeof(float) * h->K));
@@ -638,7 +647,7 @@ int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out)
  * it is -- turns into MPPI_ERR_HIP and not into finite, wrong costs. */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget)
 {
-  if (!h || wave < 0 || wave > 12 || spin_budget < 0) return MPPI_ERR_INVALID;
+  if (!h || wave < 0 || (wave > 12 && (wave < 32 || wave > 34)) || spin_budget < 0) return MPPI_ERR_INVALID;
   h->fault_wave = wave;
   h->spin_budget = spin_budget;
   return MPPI_OK;

@@ -95,7 +95,17 @@ struct TailLaunch {
   int K, T, last_iter, slide_stride;
   unsigned seq;
   float gamma, init0, init1;
+  // K > 8192 (solve_tail_stream_kernel): granule buffers (gx: 3 x 64 exchange granules; gpart: [T][K/64][2] chain results,
+  // 8 B each, zero when allocated), the tag of this launch's granules (never 0, never the tag of an earlier launch on these
+  // buffers), the deadline of every in-launch wait in 100 MHz ticks, and the tests' fault role (0: none)
+  unsigned long long *gx = nullptr, *gpart = nullptr;
+  unsigned epoch = 0, poll_ticks = 0;
+  int fault = 0;
 };
+// does a solve of K rollouts run the one-launch streaming tail (in-launch column exchanges; wait_pending then also checks the
+// published rows for the NaN a timed-out wait leaves)?
+bool tail_is_stream(int K);
+constexpr int kTailExchangeGranules = 3 * 64 + 32 * 16;  // solve_kernels.hip: 3 x kMaxChunks + kBcastReplicas lines
 hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream);
 // the tails of n <= kMaxBatch instances (K <= 4096 each) in one launch
 hipError_t launch_solve_tail_batch(const TailLaunch *l, int n, hipStream_t stream);

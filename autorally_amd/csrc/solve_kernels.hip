@@ -4,6 +4,7 @@
 #include "mppi_device.hpp"
 #include "mppi_kernels.hpp"
 
+
 namespace mppi {
 
 
@@ -19,17 +20,16 @@ namespace mppi {
 //       here, so U is bit-identical to the reference order given the same weights.
 //   U = SavitzkyGolay([hist | Unew | pad])   (last iteration only), mppi_controller.cu:468-499
 //
-// Grid = T*C workgroups (one per timestep and chunk of kRedChunk rollouts; C = 1 up to K = 4096) +
-// one that publishes the weights and scalars.  Every workgroup recomputes beta and eta from the K
+// K <= 8192 (solve_tail_kernel, solve_tail_wide_kernel; beyond: solve_tail_stream_kernel below):
+// Grid = T*C workgroups (one per timestep and chunk of kRedChunk rollouts; C = 1 up to K = 4096, 2 up to
+// 8192) + one that publishes the weights and scalars.  Every workgroup recomputes beta and eta from the K
 // costs (16 KB at K=4096, L2 resident; same code in every workgroup => the same bits), stages its
 // piece of row V[t][*][*] (contiguous bytes of the time-major buffer) through LDS with 16-B loads and
-// runs the (m, j) chains.  With C > 1 the chain results go to a global scratch and the workgroup that
-// arrives last at the row's counter adds them in order; beta, eta and the weights then come from
-// weights_kernel (one launch more, but no K exps per workgroup -- the single-launch form is the
-// latency path of K <= 4096).  On the last iteration every row workgroup writes its raw weighted mean
-// straight into host-mapped memory (16-B entries carrying the solve's sequence number; the extra
-// workgroup / weights_kernel does the same for beta, eta and the trajectory cost): the host needs no D2H
-// copy and no stream synchronise, it polls the T+1 entries and applies the 5-tap smoothing itself.
+// runs the (m, j) chains.  With C = 2 the chain results go to a global scratch and the workgroup that
+// arrives last at the row's counter adds them in order.  On the last iteration every row workgroup writes
+// its raw weighted mean straight into host-mapped memory (16-B entries carrying the solve's sequence
+// number; the extra workgroup does the same for beta, eta and the trajectory cost): the host needs no D2H
+// copy and no stream synchronise, it polls the T+2 entries and applies the 5-tap smoothing itself.
 // The workgroup that finishes last (agent-scope arrival counter, MI355X guide G16) smooths the DEVICE
 // copy of the sequence -- the one the next solve perturbs; same operations as the host, bit-identical --
 // and leaves its stride-slid copy for slideControlSeq; none of that is on the host's critical path.
@@ -130,83 +130,6 @@ __device__ __forceinline__ void publish_entry(float *res, int entry, float v0, f
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-// weights_kernel (K > kRedChunk only): beta, w_k = expf(-gamma (J_k - beta)), eta, trajectory cost --
-// once, in one workgroup, instead of once per workgroup of the tail kernel.
-constexpr int kWeightThreads = 1024;
-constexpr int kWeightCache = 16;  // float4 per thread held in registers: 65536 costs
-__global__ __launch_bounds__(kWeightThreads) void weights_kernel(const float *__restrict__ costs,
-                                                                 float *__restrict__ w, float *__restrict__ scal,
-                                                                 int K, float gamma, float *res, int res_entry,
-                                                                 unsigned seq)
-{
-  // one array per reduction and ONE barrier each: every wave leaves its result, every thread combines the sixteen in the same
-  // order (solve_tail_body: block_reduce)
-  __shared__ __attribute__((aligned(16))) float red3[3][kWeightThreads / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  auto bcast = [&](float v, bool is_min, float *red) {
-    v = is_min ? wave_min(v) : wave_sum(v);
-    if (lane == 0) red[wv] = v;
-    __syncthreads();
-    float r = red[0];
-#pragma unroll
-    for (int i = 1; i < kWeightThreads / 64; i++) r = is_min ? fminf(r, red[i]) : r + red[i];
-    return r;
-  };
-  // The first kWeightCache*4096 costs stay in registers (one 16-B load per thread and slot, all in
-  // flight together); anything beyond is re-read from memory.
-  const float4 *c4 = reinterpret_cast<const float4 *>(costs);
-  float4 *w4 = reinterpret_cast<float4 *>(w);
-  const int K4 = K / 4;
-  float4 c[kWeightCache];
-#pragma unroll
-  for (int i = 0; i < kWeightCache; i++) {
-    const int q = i * kWeightThreads + tid;
-    c[i] = (q < K4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-  }
-  float m = INFINITY;
-#pragma unroll
-  for (int i = 0; i < kWeightCache; i++) m = fminf(fminf(m, fminf(c[i].x, c[i].y)), fminf(c[i].z, c[i].w));
-  for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) m = fminf(m, costs[k]);
-  const float beta = bcast(m, true, red3[0]);
-  float part = 0.0f;
-#pragma unroll
-  for (int i = 0; i < kWeightCache; i++) {
-    const int q = i * kWeightThreads + tid;
-    if (q < K4) {
-      c[i].x = expf(-gamma * (c[i].x - beta));  // normExpKernel :201
-      c[i].y = expf(-gamma * (c[i].y - beta));
-      c[i].z = expf(-gamma * (c[i].z - beta));
-      c[i].w = expf(-gamma * (c[i].w - beta));
-      w4[q] = c[i];
-      part += (c[i].x + c[i].y) + (c[i].z + c[i].w);
-    }
-  }
-  for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) {
-    const float e = expf(-gamma * (costs[k] - beta));
-    w[k] = e;
-    part += e;
-  }
-  const float eta = bcast(part, false, red3[1]);
-  float tc = 0.0f;
-#pragma unroll
-  for (int i = 0; i < kWeightCache; i++) {
-    const int q = i * kWeightThreads + tid;
-    if (q < K4) tc += (c[i].x * c[i].x / eta + c[i].y * c[i].y / eta) + (c[i].z * c[i].z / eta + c[i].w * c[i].w / eta);  // :651 (Q8)
-  }
-  for (int k = kWeightCache * kWeightThreads * 4 + tid; k < K; k += kWeightThreads) {
-    const float e = w[k];  // own store
-    tc += e * e / eta;
-  }
-  const float traj = bcast(tc, false, red3[2]);
-  if (tid == 0) {
-    scal[0] = beta; scal[1] = eta; scal[2] = traj;
-    if (res) {  // last iteration: the host's copy
-      publish_entry(res, res_entry, beta, eta, seq);
-      publish_entry(res, res_entry + 1, traj, 0.0f, seq);
-    }
-  }
-}
-
 struct TailArgs {
   const float *costs;   // [K]
   const float *V;       // [T][K][2] applied controls of this iteration
@@ -218,7 +141,6 @@ struct TailArgs {
                         // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq]
   unsigned *counter;    // [1 + T] arrival counters (all rows, then per row), zero on entry, reset by the last arriver
   float *part;          // [T][K/64][2] chain results when a row is spread over several workgroups (K > kRedChunk)
-  int pre;              // K > kRedChunk: beta, eta, trajectory cost and w[] were computed by weights_kernel
   int K, T;
   float gamma;
   float *slid;          // optional [2T + 4]: receives [U | hist] slid by slide_stride (or nullptr)
@@ -228,23 +150,96 @@ struct TailArgs {
   unsigned seq;         // sequence number published in res[3] once everything else is visible
 };
 
+// The end of every tail kernel: the workgroups that closed a row (and, single-launch forms, the extra one) meet at the arrival
+// counter; the last one smooths the DEVICE copy of the sequence and leaves its stride-slid copy.  Hand-off form R1 of the
+// MI355X guide (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores (s_waitcnt vmcnt(0)) and
+// only then one lane bumps the agent-scope counter; the last arriver runs one agent-scope acquire (last_arriver_acquire) and
+// reads every handed-off word with sc1 loads.  No buffer_wbl2 on this path.
+__device__ __forceinline__ void tail_arrive_and_smooth(const TailArgs &a, const int K, const int T, const unsigned n_arrivers, int &is_last,
+                                                       float *dyn)
+{
+  const int tid = threadIdx.x;
+#ifdef MPPI_DIAG_TAIL_NOARRIVE  // diagnostic build: what do the arrival counter and the last workgroup's smoothing cost?
+  return;
+#endif
+  __syncthreads();  // is_last may still be read from the row hand-off above
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (ticket == n_arrivers - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+  if (!a.last_iter) return;       // more iterations follow: U stays the raw weighted mean
+  last_arriver_acquire();
+  float *X = dyn + (K / 64) * 2;  // [(T+4)][2]
+  float *Y = X + (T + 4) * 2;     // [T][2] smoothed sequence
+  for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
+    const int r = i >> 1, j = i & 1;
+    float v;
+    if (r < 2) v = a.hist[2 * r + j];
+    else if (r < T + 2) v = __hip_atomic_load(&a.U[2 * (r - 2) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else v = __hip_atomic_load(&a.U[2 * (T - 1) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    X[i] = v;
+  }
+  __syncthreads();
+  {
+    const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
+    for (int i = tid; i < T * 2; i += kTailThreads) {
+      float acc = f0 * X[i];
+      float p = f1 * X[i + 2];
+      acc = acc + p;
+      p = f2 * X[i + 4];
+      acc = acc + p;
+      p = f1 * X[i + 6];
+      acc = acc + p;
+      p = f0 * X[i + 8];
+      acc = acc + p;
+      a.U[i] = acc;  // the device copy the next solve perturbs (the host computes the same values itself)
+      Y[i] = acc;    // and in LDS for the slid copy below
+    }
+  }
+  __syncthreads();
+
+  // Leave a copy of [U | hist]
+  // slid by the controller's optimization stride (slideControlSeq, mppi_controller.cu:527-554) in
+  // the other buffer, so that the control loop's slide -> solve costs no kernel and no upload.
+  if (a.slid != nullptr) {
+    const int st = a.slide_stride;
+    // (i & 1 == tid & 1: the value is picked HERE, between two scalar registers -- written as `j ? a.init1 : a.init0` inside
+    // the loop's conditional the compiler made it a load from a two-element private array, i.e. two scratch stores in every
+    // workgroup's prologue and flat loads in this loop)
+    const float init_j = (tid & 1) ? a.init1 : a.init0;
+    // hist rows sit in X[0..3] (the smoothing's left padding)
+    for (int i = tid; i < 2 * T; i += kTailThreads) {
+      const int r = i >> 1, j = i & 1;
+      a.slid[i] = (r < T - st) ? Y[(r + st) * 2 + j] : init_j;
+    }
+    if (tid < 4) {
+      float hv;
+      if (st == 1) hv = (tid < 2) ? X[tid + 2] : Y[tid - 2];
+      else hv = Y[(st - 2) + tid];  // flat-index quirk (Q15)
+      a.slid[2 * T + tid] = hv;
+    }
+  }
+}
+
 // body of solve_tail_kernel for workgroup `block` of the instance `a` (the batched kernel passes blockIdx.x minus
 // the instance's first workgroup)
-// CV: float4 of the cost vector a thread holds when the workgroup computes beta and eta itself (a.pre == 0): 4 covers
-// K <= 4096 (one chunk per row: the latency path, untouched since round 2), 8 covers K <= 8192 ("wide": rows of two chunks,
-// every workgroup still recomputes beta and eta from all K costs -- 32 KB of L2 reads and 32 exps per thread -- which saves
-// the one-workgroup weights_kernel in front: K = 8192 19.3 -> 15 us behind the rollout kernel.  With 16 float4 it would reach
-// K = 16384, measured: K=16384 T=100 23.8 -> 21.3 us, but T=150 30.0 -> 32.2 us -- the longer workgroups cost what the
-// removed kernel saved; so beyond 8192 the weights come from weights_kernel as before.)
+// CV: float4 of the cost vector a thread holds (every workgroup computes beta and eta itself): 4 covers K <= 4096 (one chunk per
+// row: the latency path, untouched since round 2), 8 covers K <= 8192 ("wide": rows of two chunks, every workgroup still
+// recomputes beta and eta from all K costs -- 32 KB of L2 reads and 32 exps per thread; round 4: K = 8192 19.3 -> 15 us behind
+// the rollout kernel against a one-workgroup weights pass in front).  With 16 float4 it would reach K = 16384, measured in round
+// 4: T=100 23.8 -> 21.3 us, but T=150 30.0 -> 32.2 us -- beyond 8192 the weights come from the weights workgroups of
+// solve_tail_stream_kernel.
 constexpr int kWideK = 8192;
 // `V`, `costs`, `K`, `T`: the values of a.V, a.costs, a.K, a.T as the kernel received them -- in the single-instance kernels
 // leading scalar parameters.  (Preloading them into scalar registers, -amdgpu-kernarg-preload-count, was measured: the
 // workgroup's first loads go out 0.1 us earlier and the step is unchanged; the same for the row rollout kernel -- its first
 // controls 0.28 us earlier, the STEP 0.3 us longer: the command processor reads the segment before it launches the first
 // wave.  profiles/r04_v_kernarg_preload.txt.  Not used.)
-// PRE: beta, eta, the trajectory cost and w[] were computed by weights_kernel (K > kWideK) -- a template parameter, so that the
-// cost loads of the other path do not wait for the argument segment either
-template <int CV, bool PRE = false>
+template <int CV>
 __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int block, const float *V, const float *costs_p, const int K,
                                                 const int T)
 {
@@ -284,28 +279,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   // ---- weights: beta, eta (every workgroup), w[] and the trajectory cost (the extra workgroup) ----
   // Each exp of the workgroup's own chunk is evaluated once and kept in LDS.
   float eta;
-  if constexpr (PRE) {
-    eta = a.scal[1];
-    // the chunk's weights: four 16-B loads per thread, in flight together
-    constexpr int kWV = kRedChunk / 4 / kTailThreads;
-    const float4 *w4 = reinterpret_cast<const float4 *>(a.w + base);
-    float4 wv[kWV];
-#pragma unroll
-    for (int i = 0; i < kWV; i++) {
-      const int q = i * kTailThreads + tid;
-      wv[i] = (q < n / 4) ? w4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-#pragma unroll
-    for (int i = 0; i < kWV; i++) {
-      const int q = i * kTailThreads + tid;
-      if (q < n / 4) {
-        const int k = 4 * q;
-        // weight = w/normalizer (:244)
-        *reinterpret_cast<float4 *>(&wtile[(k >> 6) * kGS + (k & 63)]) =
-            make_float4(wv[i].x / eta, wv[i].y / eta, wv[i].z / eta, wv[i].w / eta);
-      }
-    }
-  } else {
+  {
     // The K <= kRedChunk costs, 16 per thread, are requested with four 16-B loads that are in flight
     // together (and together with the row above): one memory round trip for the min and the exp pass.
     constexpr int kCostV = CV;
@@ -462,80 +436,457 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   // (s_waitcnt vmcnt(0)) and only then one lane bumps the agent-scope counter; the last arriver
   // runs one agent-scope acquire (last_arriver_acquire) and reads every handed-off word with sc1
   // loads.  No buffer_wbl2 on this path. ----
-#ifdef MPPI_DIAG_TAIL_NOARRIVE  // diagnostic build: what do the arrival counter and the last workgroup's smoothing cost?
-  return;
-#endif
-  __syncthreads();  // is_last may still be read from the row hand-off above
-  if (tid == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (ticket == (unsigned)(PRE ? T - 1 : T)) ? 1 : 0;  // T rows (+ the extra workgroup)
-  }
-  __syncthreads();
-  if (!is_last) return;
-  if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-  if (!a.last_iter) return;       // more iterations follow: U stays the raw weighted mean
-  last_arriver_acquire();
-  float *X = dyn + (K / 64) * 2;  // [(T+4)][2]
-  float *Y = X + (T + 4) * 2;     // [T][2] smoothed sequence
-  for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
-    const int r = i >> 1, j = i & 1;
-    float v;
-    if (r < 2) v = a.hist[2 * r + j];
-    else if (r < T + 2) v = __hip_atomic_load(&a.U[2 * (r - 2) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else v = __hip_atomic_load(&a.U[2 * (T - 1) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    X[i] = v;
-  }
-  __syncthreads();
-  {
-    const float f0 = -3.0f / 35.0f, f1 = 12.0f / 35.0f, f2 = 17.0f / 35.0f;
-    for (int i = tid; i < T * 2; i += kTailThreads) {
-      float acc = f0 * X[i];
-      float p = f1 * X[i + 2];
-      acc = acc + p;
-      p = f2 * X[i + 4];
-      acc = acc + p;
-      p = f1 * X[i + 6];
-      acc = acc + p;
-      p = f0 * X[i + 8];
-      acc = acc + p;
-      a.U[i] = acc;  // the device copy the next solve perturbs (the host computes the same values itself)
-      Y[i] = acc;    // and in LDS for the slid copy below
-    }
-  }
-  __syncthreads();
+  tail_arrive_and_smooth(a, K, T, (unsigned)(T + 1), is_last, dyn);  // T rows + the extra workgroup
+}
 
-  // Leave a copy of [U | hist]
-  // slid by the controller's optimization stride (slideControlSeq, mppi_controller.cu:527-554) in
-  // the other buffer, so that the control loop's slide -> solve costs no kernel and no upload.
-  if (a.slid != nullptr) {
-    const int st = a.slide_stride;
-    // (i & 1 == tid & 1: the value is picked HERE, between two scalar registers -- written as `j ? a.init1 : a.init0` inside
-    // the loop's conditional the compiler made it a load from a two-element private array, i.e. two scratch stores in every
-    // workgroup's prologue and flat loads in this loop)
-    const float init_j = (tid & 1) ? a.init1 : a.init0;
-    // hist rows sit in X[0..3] (the smoothing's left padding)
-    for (int i = tid; i < 2 * T; i += kTailThreads) {
-      const int r = i >> 1, j = i & 1;
-      a.slid[i] = (r < T - st) ? Y[(r + st) * 2 + j] : init_j;
+// ---------------------------------------------------------------------------------------------
+// solve_tail_stream_kernel (K > kWideK, round 5): the whole tail stage of a many-chunk solve in ONE launch.
+//
+// Before (round 4: weights_kernel + solve_tail_kernel<PRE>): beta, the exps, eta and the trajectory cost of all K rollouts in
+// ONE 1 024-thread workgroup (8.7 us at K = 16 384, 23.6 us at 65 536), a kernel boundary, then T*C row workgroups whose
+// chain results met at a per-row arrival counter (drain, barrier, atomic, agent acquire, re-read), two workgroups per CU:
+// 21.5 us at K = 16 384 / T = 100, 28 us for config 4 -- a chain of latencies.  Now 14.5 / 17 us (profiles/r05_a_*).
+//
+// Grid: C weights workgroups (one per chunk of kRedChunk rollouts; they stream no row, so their polls do not queue behind
+// their own loads), then the row workgroups (t, c) -- row t, chunk c -- dealt so that all chunks of a row run on ONE XCD.
+//  * Weights workgroup c: beta = the minimum of ALL costs where one load batch covers them (K <= 16 384), else the chunk minima
+//    exchanged among the C weights workgroups (exact, order-free); {beta} into its share of kBcastReplicas replica lines;
+//    w_k = expf(-gamma (J_k - beta)) of its chunk; the chunk sums exchanged, eta = their sum in chunk order (a fixed order: the
+//    same bits in every workgroup and every run; the reference's host loop is sequential over k, :641-652 -- the pairwise /
+//    chunked order differs from it by ~1e-7 relative, as the tree of the old weights pass did); {eta} into the replicas; w[]
+//    and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares in chunk order and
+//    publishes beta, eta and the trajectory cost.
+//  * Row workgroup (t, c) requests its chunk of the costs and its piece of V[t] at once, polls ONE replica line for beta
+//    (its block index picks the line: ~grid / kBcastReplicas pollers each), evaluates the exps of its chunk while the weights
+//    workgroups exchange their sums, polls eta, and keeps the chunk's weights w_k / eta (:244: a division per rollout, then
+//    the fma) to itself.  The (m, j) chains of 64 rollouts and the in-order sum of their results (:246, :256-260) are the
+//    reference's, untouched: the chain results of chunks 0 .. C-2 travel as granules, and the workgroup of the row's LAST chunk
+//    -- started right behind the others -- polls them, adds all K/64 results in order and publishes the row.  The T
+//    row-closing workgroups then meet at the arrival counter for the device-side smoothing, as in the one-chunk form.
+// Every value that crosses workgroups is ONE 8-byte {value, epoch} granule (MI355X guide G16, form R2: the data is the flag;
+// sc1 store, sc1 load poll, no fence, no counter to reset).  What the first versions of this kernel taught (stamps in
+// profiles/r05_a_*): (1) with EVERY row workgroup publishing its column's granule and polling all C -- 400 stores and 400
+// pollers on the same few lines -- an exchange took 6 us: same-line requests are served one after another, so the exchanges
+// are among C workgroups and the fan-out goes through replica lines; (2) dealt by plain index, chunk c of every row ran on
+// XCD c % 8, and with more workgroups than slots the XCDs drift apart: a row-closing workgroup was stamped starting 7 us
+// BEFORE chunk 0 of its row and holding its slot for 9 us of polling; (3) the padded chunk image of solve_tail_body allows two
+// workgroups per CU, the swizzled one three.
+// Waits are for workgroups that start earlier on the same XCD (a row's earlier chunks) or first of all (the weights
+// workgroups).  Every poll is bounded by a deadline on the 100 MHz real-time counter (poll_ticks); a workgroup that gives up
+// stores NaN in place of what it waited for, NaN reaches eta or a published row, and the host reports MPPI_ERR_HIP -- never a
+// hang, never finite wrong controls (mppi_debug_inject_handover_fault, roles 32-34).  The tag is a kernel argument: a captured
+// graph would replay it -- this launch is not capturable as it stands.
+// ---------------------------------------------------------------------------------------------
+#ifdef MPPI_TAIL_STAMPS
+__device__ unsigned long long g_stream_stamps[2][16];  // [0]: the row-closing workgroup of row T/2, [1]: workgroup (T/2, 0)
+#define SSTAMP(i)                                                                                   \
+  do {                                                                                              \
+    if (t == T / 2 && (closer || c == 0) && threadIdx.x == 0) {                                     \
+      unsigned long long t__;                                                                       \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
+      g_stream_stamps[closer ? 0 : 1][i] = t__;                                                     \
+    }                                                                                               \
+  } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+#ifndef MPPI_STREAM_SLEEP
+#define MPPI_STREAM_SLEEP 1
+#endif
+constexpr int kMaxChunks = 64;  // one wave polls a column exchange: K <= 64 * kRedChunk = 262 144
+constexpr int kBcastReplicas = 32;  // lines (128 B each) that carry {beta, eta} to the workgroups of rows 1 .. T-1
+static_assert(kTailExchangeGranules == 3 * kMaxChunks + kBcastReplicas * 16, "mppi_kernels.hpp");
+static_assert(2 * kBcastReplicas <= kTailThreads, "one lane per replica granule");
+struct StreamTailArgs {
+  TailArgs a;                // a.part is unused; a.counter[0] is the arrival counter of the T row-closing workgroups
+  unsigned long long *gx;    // [3][kMaxChunks] exchange granules: chunk minima, chunk sums, chunk shares of the trajectory cost;
+                             // then [kBcastReplicas][16]: {beta, eta} for the rows that do not take part in the exchanges
+  unsigned long long *gpart; // [T][K/64][2] chain-result granules
+  unsigned epoch;            // tag of this launch's granules (never 0, differs from every earlier launch on these buffers)
+  unsigned poll_ticks;       // deadline of every wait, in ticks of s_memrealtime (100 MHz)
+  int fault;                 // tests only: 32 = leader 0 never publishes its chunk sum, 33 = chunk 0 of every row never publishes
+                             // its chain results, 34 = no leader publishes {beta, eta}
+};
+
+__device__ __forceinline__ unsigned long long make_granule(unsigned epoch, float v)
+{
+  return ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+}
+__device__ __forceinline__ void store_granule(unsigned long long *g, unsigned epoch, float v)
+{
+  __hip_atomic_store(g, make_granule(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 sc1
+}
+
+// One granule of a replica line, polled by wave 0 (lane 0 loads): its value into *out (LDS); the caller's barrier follows.
+// NaN when the wait ran out of time.
+__device__ __forceinline__ void poll_replica(const unsigned long long *g, const unsigned epoch, const unsigned long long t0,
+                                             const unsigned poll_ticks, float *out)
+{
+  if (threadIdx.x < 64) {
+    float v = 0.0f;
+    bool ok = threadIdx.x != 0;
+    for (;;) {
+      if (!ok) {
+        const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 load
+        if ((unsigned)(x >> 32) == epoch) { v = __uint_as_float((unsigned)x); ok = true; }
+      }
+      if (__all(ok)) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)poll_ticks) {
+        if (!ok) v = __builtin_nanf("");
+        break;
+      }
+      __builtin_amdgcn_s_sleep(MPPI_STREAM_SLEEP);
     }
-    if (tid < 4) {
-      float hv;
-      if (st == 1) hv = (tid < 2) ? X[tid + 2] : Y[tid - 2];
-      else hv = Y[(st - 2) + tid];  // flat-index quirk (Q15)
-      a.slid[2 * T + tid] = hv;
+    if (threadIdx.x == 0) *out = v;
+  }
+}
+
+// Column exchange: column c's value `mine` (the same bits in every workgroup of the column) out, all C values in (xv[0 .. C-1],
+// LDS).  Wave 0 polls, lane i column i; the caller's barrier follows.  A lane that runs out of time leaves NaN.
+__device__ __forceinline__ void column_exchange(unsigned long long *g, const int C, const int c, const float mine, const unsigned epoch,
+                                                const bool publish, const unsigned long long t0, const unsigned poll_ticks, float *xv)
+{
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    if (tid == 0 && publish) store_granule(g + c, epoch, mine);
+    float v = mine;
+    bool ok = (tid >= C) || (tid == c && publish);  // the own value needs no round trip
+    for (;;) {
+      if (!ok) {
+        const unsigned long long x = __hip_atomic_load(g + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 load
+        if ((unsigned)(x >> 32) == epoch) { v = __uint_as_float((unsigned)x); ok = true; }
+      }
+      if (__all(ok)) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)poll_ticks) {
+        if (!ok) v = __builtin_nanf("");
+        break;
+      }
+      __builtin_amdgcn_s_sleep(MPPI_STREAM_SLEEP);
+    }
+    if (tid < C) xv[tid] = v;
+  }
+}
+
+// LDS image of a chunk, 48 KB with no padding (three workgroups per CU; the padded image of solve_tail_body: two): plane j
+// of the piece of V and the weights, a 64-rollout group = 16 slots of 16 B; slot s of group g sits at s ^ ((2g + j) & 15)
+// (V) / s ^ (g & 7) (weights).  A wave's chain read i then takes, in each of ds_read_b128's 16-lane groups, 16 different
+// slots (V: lane = 2 ml + j, and the lanes of a group differ in lane & 15) / 8 different slots read by two lanes each.
+__device__ __forceinline__ int img_v(int g, int j, int e) { return g * 64 + ((((e >> 2) ^ (2 * g + j)) & 15) << 2) + (e & 3); }
+__device__ __forceinline__ int img_w(int g, int e) { return g * 64 + ((((e >> 2) ^ (g & 7)) & 15) << 2) + (e & 3); }
+
+// The weights workgroups of solve_tail_stream_kernel (blocks 0 .. C-1 of the grid, one per chunk; they stream no row, so
+// their polls do not queue behind 48 KB of their own loads): beta, the chunk's exps, eta, {beta, eta} into the replica
+// lines, w[] and the trajectory cost.
+__device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, const float *costs_p, const int K, const int T, const int c,
+                                                    float *redm, float *reds, float *redt, float *xmin, float *xsum, float *xtc)
+{
+  const TailArgs &a = sa.a;
+  const int tid = threadIdx.x;
+  const int C = (K + kRedChunk - 1) / kRedChunk;
+  const int base = c * kRedChunk;
+  const int n = min(kRedChunk, K - base);
+  const unsigned epoch = sa.epoch;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long *const bcast = sa.gx + 3 * kMaxChunks;
+  constexpr int kCostV = kRedChunk / 4 / kTailThreads;
+  constexpr int kAllV = 8;  // float4 per thread that cover all costs of K <= 16 384
+  const bool full_min = K <= kAllV * 4 * kTailThreads;
+  float4 cv[kCostV];
+  {
+    const float4 *c4 = reinterpret_cast<const float4 *>(costs_p + base);
+#pragma unroll
+    for (int i = 0; i < kCostV; i++) {
+      const int q = i * kTailThreads + tid;
+      cv[i] = (q < n / 4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    }
+  }
+  // ---- beta: the minimum of ALL costs where one load batch covers them (no exchange), else the chunk minima exchanged ----
+  float m = INFINITY, beta;
+  if (full_min) {
+    float4 call[kAllV];
+    const float4 *c4 = reinterpret_cast<const float4 *>(costs_p);
+#pragma unroll
+    for (int i = 0; i < kAllV; i++) {
+      const int q = i * kTailThreads + tid;
+      call[i] = (q < K / 4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    }
+#pragma unroll
+    for (int i = 0; i < kAllV; i++) m = fminf(fminf(m, fminf(call[i].x, call[i].y)), fminf(call[i].z, call[i].w));
+    beta = block_reduce<true>(m, redm);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kCostV; i++) m = fminf(fminf(m, fminf(cv[i].x, cv[i].y)), fminf(cv[i].z, cv[i].w));
+    const float cmin = block_reduce<true>(m, redm);
+    column_exchange(sa.gx, C, c, cmin, epoch, true, t0, sa.poll_ticks, xmin);
+    __syncthreads();
+    beta = xmin[0];
+    for (int i = 1; i < C; i++) {
+      const float x = xmin[i];
+      beta = (x != x) ? x : fminf(beta, x);  // a wait that ran out of time left NaN: keep it
+    }
+  }
+  // {beta} goes out in this workgroup's share of the replica lines at once: the row workgroups evaluate their exps while the
+  // chunk sums are exchanged
+#ifndef MPPI_STREAM_LATE_BETA
+  if (tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) store_granule(bcast + (size_t)tid * 16, epoch, beta);
+#endif
+  // ---- w_k, eta ----
+  float part = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kCostV; i++) {
+    const int q = i * kTailThreads + tid;
+    if (q < n / 4) {
+      const float e0 = expf(-a.gamma * (cv[i].x - beta));  // normExpKernel :201
+      const float e1 = expf(-a.gamma * (cv[i].y - beta));
+      const float e2 = expf(-a.gamma * (cv[i].z - beta));
+      const float e3 = expf(-a.gamma * (cv[i].w - beta));
+      cv[i] = make_float4(e0, e1, e2, e3);
+      part += (e0 + e1) + (e2 + e3);
+    }
+  }
+  const float csum = block_reduce<false>(part, reds);
+  column_exchange(sa.gx + kMaxChunks, C, c, csum, epoch, !(sa.fault == 32 && c == 0), t0, sa.poll_ticks, xsum);
+  __syncthreads();
+  float eta = xsum[0];
+  for (int i = 1; i < C; i++) eta += xsum[i];  // chunk order
+  if (tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) {
+#ifdef MPPI_STREAM_LATE_BETA
+    store_granule(bcast + (size_t)tid * 16, epoch, beta);
+#endif
+    store_granule(bcast + (size_t)tid * 16 + 1, epoch, eta);
+  }
+  // ---- w[] and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares in chunk order ----
+  float tc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kCostV; i++) {
+    const int q = i * kTailThreads + tid;
+    if (q < n / 4) {
+      reinterpret_cast<float4 *>(a.w + base)[q] = cv[i];
+      tc += (cv[i].x * cv[i].x / eta + cv[i].y * cv[i].y / eta) + (cv[i].z * cv[i].z / eta + cv[i].w * cv[i].w / eta);
+    }
+  }
+  const float ctc = block_reduce<false>(tc, redt);
+  if (c != 0) {
+    if (tid == 0) store_granule(sa.gx + 2 * kMaxChunks + c, epoch, ctc);
+    return;
+  }
+  column_exchange(sa.gx + 2 * kMaxChunks, C, 0, ctc, epoch, true, t0, sa.poll_ticks, xtc);
+  __syncthreads();
+  if (tid == 0) {
+    float traj = xtc[0];
+    for (int i = 1; i < C; i++) traj += xtc[i];  // chunk order
+    a.scal[0] = beta; a.scal[1] = eta; a.scal[2] = traj;
+    if (a.last_iter) {
+      publish_entry(a.res, T, beta, eta, a.seq);
+      publish_entry(a.res, T + 1, traj, 0.0f, a.seq);
     }
   }
 }
 
-template <bool PRE>
+__global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(const float *V, const float *costs_p, const int K, const int T,
+                                                                            const StreamTailArgs sa)
+{
+  const TailArgs &a = sa.a;
+  __shared__ __attribute__((aligned(16))) float img[3 * kRedChunk];  // V plane 0 | V plane 1 | weights; later partial | X | Y
+  float *const tile0 = img, *const tile1 = img + kRedChunk, *const wtile = img + 2 * kRedChunk;
+  __shared__ float redm[kTailThreads / 64], reds[kTailThreads / 64], redt[kTailThreads / 64];
+  __shared__ float xmin[kMaxChunks], xsum[kMaxChunks], xtc[kMaxChunks];
+  __shared__ float bc[2];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  const int C = (K + kRedChunk - 1) / kRedChunk;
+  const int block = (int)blockIdx.x;
+  // Blocks 0 .. C-1: the weights workgroups.  From block Cpad = C rounded up to 8 on: the row workgroups, dealt so that ALL
+  // chunks of a row run on ONE XCD (blocks b and b + 8 share an XCD and every XCD starts its blocks in index order): a row's
+  // last chunk then starts right behind the row's other chunks.  Dealt by plain index, chunk c of every row ran on XCD c % 8;
+  // with more workgroups than slots the XCDs drift apart, and a row-closing workgroup was stamped starting 7 us BEFORE chunk 0
+  // of its row and holding its slot for 9 us of polling.
+  if (block < C) {
+    stream_weights_body(sa, costs_p, K, T, block, redm, reds, redt, xmin, xsum, xtc);
+    return;
+  }
+  const int Cpad = (C + 7) & ~7;
+  if (block < Cpad) return;
+  const int bx = (block - Cpad) & 7, bi = (block - Cpad) >> 3;
+  const int t = (bi / C) * 8 + bx, c = bi % C;
+  if (t >= T) return;
+  const int base = c * kRedChunk;
+  const int n = min(kRedChunk, K - base);  // multiple of 64
+  const int G = K / 64;
+  const bool closer = (c == C - 1);        // adds the row's K/64 chain results and publishes the row
+  const unsigned epoch = sa.epoch;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  SSTAMP(0);
+  const unsigned long long *const bcast = sa.gx + 3 * kMaxChunks + (size_t)(block % kBcastReplicas) * 16;  // {beta, epoch}, {eta, epoch}
+
+  // the chunk of the costs, then the piece of row t: requested together, before anything else; a wave's loads return in issue
+  // order -- the costs, which the weights wait for, first
+  constexpr int kCostV = kRedChunk / 4 / kTailThreads;
+  float4 cv[kCostV];
+  {
+    const float4 *c4 = reinterpret_cast<const float4 *>(costs_p + base);
+#pragma unroll
+    for (int i = 0; i < kCostV; i++) {
+      const int q = i * kTailThreads + tid;
+      cv[i] = (q < n / 4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    }
+  }
+  const float *row = V + ((size_t)t * K + base) * 2;
+  constexpr int kPre = kRedChunk / 2 / kTailThreads;
+  float4 pre[kPre];
+  {
+    const float4 *src0 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+    for (int i = 0; i < kPre; i++) {
+      const int q = tid + i * kTailThreads;
+      pre[i] = (q < n / 2) ? src0[q] : make_float4(0, 0, 0, 0);
+    }
+  }
+  SSTAMP(1);  // loads requested
+  // ---- beta from the replica line this block's index picks (~grid / kBcastReplicas pollers per line), the chunk's exps, eta ----
+  SSTAMP(2);
+  poll_replica(bcast, epoch, t0, sa.poll_ticks, &bc[0]);
+  __syncthreads();
+  const float beta = bc[0];
+  SSTAMP(3);
+#pragma unroll
+  for (int i = 0; i < kCostV; i++) {
+    const int q = i * kTailThreads + tid;
+    if (q < n / 4) {
+      const float e0 = expf(-a.gamma * (cv[i].x - beta));  // normExpKernel :201
+      const float e1 = expf(-a.gamma * (cv[i].y - beta));
+      const float e2 = expf(-a.gamma * (cv[i].z - beta));
+      const float e3 = expf(-a.gamma * (cv[i].w - beta));
+      cv[i] = make_float4(e0, e1, e2, e3);
+    }
+  }
+  SSTAMP(4);
+  poll_replica(bcast + 1, epoch, t0, sa.poll_ticks, &bc[1]);
+  __syncthreads();
+  const float eta = bc[1];
+  SSTAMP(5);
+  // ---- weight = w/normalizer (:244), the piece of the row: into LDS ----
+#pragma unroll
+  for (int i = 0; i < kCostV; i++) {
+    const int q = i * kTailThreads + tid;
+    if (q < n / 4) {
+      const int k = 4 * q;
+      *reinterpret_cast<float4 *>(&wtile[img_w(k >> 6, k & 63)]) =
+          make_float4(cv[i].x / eta, cv[i].y / eta, cv[i].z / eta, cv[i].w / eta);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPre; i++) {
+    const int q = tid + i * kTailThreads;
+    if (q < n / 2) {
+      const int kk = 2 * q;  // rollouts base + kk, base + kk + 1
+      *reinterpret_cast<float2 *>(&tile0[img_v(kk >> 6, 0, kk & 63)]) = make_float2(pre[i].x, pre[i].z);
+      *reinterpret_cast<float2 *>(&tile1[img_v(kk >> 6, 1, kk & 63)]) = make_float2(pre[i].y, pre[i].w);
+    }
+  }
+  SSTAMP(6);  // weights and row staged
+  __syncthreads();
+  SSTAMP(7);
+  // ---- the (m, j) chains of this chunk: one per thread (at most 128 of them) ----
+  float acc = 0.0f;
+  const int ml = tid >> 1, j = tid & 1;
+  const int mg = base / 64 + ml;
+  const bool has_chain = tid < (n / 64) * 2;
+  if (has_chain) {
+    const float4 *p4 = reinterpret_cast<const float4 *>((j ? tile1 : tile0) + ml * 64);
+    const float4 *w4 = reinterpret_cast<const float4 *>(wtile + ml * 64);
+    const int sv = (2 * ml + j) & 15, sw = ml & 7;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {  // u_system += weight*u :246, the 64 rollouts of the group in order
+      const float4 wv = w4[i ^ sw], pv = p4[i ^ sv];
+      acc = fmaf(wv.x, pv.x, acc);
+      acc = fmaf(wv.y, pv.y, acc);
+      acc = fmaf(wv.z, pv.z, acc);
+      acc = fmaf(wv.w, pv.w, acc);
+    }
+    if (!closer && !(sa.fault == 33 && c == 0)) store_granule(sa.gpart + ((size_t)t * G + mg) * 2 + j, epoch, acc);
+  }
+  SSTAMP(8);  // chains
+  if (!closer) return;  // a granule is data and flag in one store: nothing to drain, no counter to bump
+
+  // ---- the row's last chunk: all K/64 chain results of the row into LDS (over the image: every chain has read it) ----
+  float *partial = img;  // [2][G]
+  __syncthreads();
+  if (has_chain) partial[j * G + mg] = acc;
+  {
+    const int ng = (C - 1) * (kRedChunk / 64) * 2;
+    const unsigned long long *gp = sa.gpart + (size_t)t * G * 2;
+    for (int i0 = 0; i0 < ng; i0 += 4 * kTailThreads) {
+      unsigned long long x[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { ok[u] = (i0 + u * kTailThreads + tid) >= ng; x[u] = 0; }
+      for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (!ok[u]) x[u] = __hip_atomic_load(gp + i0 + u * kTailThreads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (!ok[u]) ok[u] = ((unsigned)(x[u] >> 32) == epoch);
+          all = all && ok[u];
+        }
+        if (__all(all)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)sa.poll_ticks) {
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (!ok[u]) x[u] = (unsigned long long)__float_as_uint(__builtin_nanf(""));
+          break;
+        }
+        __builtin_amdgcn_s_sleep(MPPI_STREAM_SLEEP);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * kTailThreads + tid;
+        if (i < ng) partial[(i & 1) * G + (i >> 1)] = __uint_as_float((unsigned)x[u]);
+      }
+    }
+  }
+  SSTAMP(9);  // the other chunks' chain results collected
+  __syncthreads();
+  float u = 0.0f;
+  if (tid < 2) {
+    // thread j adds the partials of control j in order (:256-260): K/64 dependent adds, the next 32 partials on their way
+    // from LDS while these 32 are added
+    const float *pj = partial + tid * G;
+    int mm = 0;
+    if ((G & 3) == 0 && G >= 32) {
+      float4 v[8], w[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(pj + 4 * i);
+      for (; mm + 32 <= G; mm += 32) {
+        const int nx = (mm + 64 <= G) ? mm + 32 : mm;  // the last full batch re-reads itself
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = *reinterpret_cast<const float4 *>(pj + nx + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { u += v[i].x; u += v[i].y; u += v[i].z; u += v[i].w; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = w[i];
+      }
+    }
+    for (; mm < G; mm++) u += pj[mm];
+    __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by the last row-closing workgroup
+  }
+  if (tid < 64) {
+    const float u1 = __shfl(u, 1);
+    if (tid == 0 && a.last_iter) publish_entry(a.res, t, u, u1, a.seq);
+    SSTAMP(10);  // row published (store issued)
+  }
+  tail_arrive_and_smooth(a, K, T, (unsigned)T, is_last, img);  // its X | Y follow the row's K/64 x 2 partials in img
+}
+
 __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const float *V, const float *costs, const int K, const int T,
                                                                   const TailArgs a)
 {
-  solve_tail_body<kRedChunk / 4 / kTailThreads, PRE>(a, (int)blockIdx.x, V, costs, K, T);
+  solve_tail_body<kRedChunk / 4 / kTailThreads>(a, (int)blockIdx.x, V, costs, K, T);
 }
 __global__ __launch_bounds__(kTailThreads) void solve_tail_wide_kernel(const float *V, const float *costs, const int K, const int T,
-                                                                       const TailArgs a)  // kRedChunk < K <= kWideK, a.pre == 0
+                                                                       const TailArgs a)  // kRedChunk < K <= kWideK
 {
   solve_tail_body<kWideK / 4 / kTailThreads>(a, (int)blockIdx.x, V, costs, K, T);
 }
@@ -673,9 +1024,10 @@ static TailArgs fill_tail(const TailLaunch &l)
   a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res;
   a.counter = l.counter; a.part = l.part;
   a.K = l.K; a.T = l.T; a.gamma = l.gamma; a.last_iter = l.last_iter; a.seq = l.seq;
-  a.pre = (l.K > kWideK) ? 1 : 0;  // beyond: beta, eta and w[] from weights_kernel
   return a;
 }
+
+bool tail_is_stream(int K) { return K > kWideK; }
 
 hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
 {
@@ -683,15 +1035,22 @@ hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
   const int K = l.K, T = l.T;
   const int C = (K + kRedChunk - 1) / kRedChunk;
   if (C > 1 && l.part == nullptr) return hipErrorInvalidValue;
-  if (a.pre)
-    hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(kWeightThreads), 0, stream, l.costs, l.w, l.scal, K, l.gamma,
-                       l.last_iter ? l.res : nullptr, T, l.seq);
-  if (K > kRedChunk && !a.pre)
+  if (tail_is_stream(K)) {
+    if (C > kMaxChunks || !l.gx || !l.gpart || l.epoch == 0 || l.poll_ticks == 0) return hipErrorInvalidValue;
+    StreamTailArgs sa;
+    sa.a = a;
+    sa.gx = l.gx; sa.gpart = l.gpart; sa.epoch = l.epoch; sa.poll_ticks = l.poll_ticks; sa.fault = l.fault;
+    // the row's K/64 x 2 chain results and the smoothing's X | Y live in the 48 KB chunk image once the chains have read it
+    if ((size_t)(K / 64) * 2 + (size_t)(T + 4) * 2 + (size_t)T * 2 > (size_t)3 * kRedChunk) return hipErrorInvalidValue;
+    // C weights workgroups, padded to a multiple of 8, then 8 x ceil(T / 8) x C row workgroups (all chunks of a row on one XCD)
+    const int grid = ((C + 7) & ~7) + 8 * ((T + 7) / 8) * C;
+    hipLaunchKernelGGL(solve_tail_stream_kernel, dim3(grid), dim3(kTailThreads), 0, stream, a.V, a.costs, K, T, sa);
+    return hipGetLastError();
+  }
+  if (K > kRedChunk)
     hipLaunchKernelGGL(solve_tail_wide_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
-  else if (a.pre)
-    hipLaunchKernelGGL(solve_tail_kernel<true>, dim3(T * C), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
   else
-    hipLaunchKernelGGL(solve_tail_kernel<false>, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
+    hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
   return hipGetLastError();
 }
 
@@ -746,5 +1105,9 @@ hipError_t launch_tk_to_kt(const float *src, float *dst, int K, int T, hipStream
 extern "C" int mppi_debug_read_tail_stamps(unsigned long long *out)
 {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mppi::g_tail_stamps), sizeof(unsigned long long) * 16);
+}
+extern "C" int mppi_debug_read_stream_stamps(unsigned long long *out)  // [2][16]
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mppi::g_stream_stamps), sizeof(unsigned long long) * 32);
 }
 #endif

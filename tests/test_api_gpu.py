@@ -374,6 +374,33 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
     sol.close()
 
 
+@pytest.mark.parametrize("K", [12288 + 64, 20480 + 64])  # the leaders take beta from all costs / exchange chunk minima
+@pytest.mark.parametrize("role", [32, 33, 34])
+def test_stream_tail_wait_that_runs_out_of_time_is_an_error(role, K):
+    """K > 8192: the tail stage is ONE launch whose workgroups exchange chunk minima, chunk sums and chain results as
+    {value, epoch} granules (solve_kernels.hip: solve_tail_stream_kernel).  A workgroup that never publishes -- column 0's
+    sum of weights (32), chunk 0's chain results (33), the leaders' {beta, eta} for the other rows (34) -- must end the solve in MPPI_ERR_HIP within the
+    deadline, never in a hang and never in finite controls; the handle keeps working afterwards, bit for bit."""
+    cfg = S.make_config(K, 30, track="oval")  # four / six chunks, the last one ragged
+    sol = capi.Solver(cfg)
+    sol.compute_control(cfg["start_state"])
+    good = sol.get_results()
+    assert np.all(np.isfinite(good["U"])) and np.isfinite(good["traj_cost"])
+    sol.debug_inject_handover_fault(role, 200)  # every wait gives up after 200 us
+    with pytest.raises(capi.MppiError) as e:
+        sol.compute_control(cfg["start_state"])
+    assert e.value.status == capi.ERR_HIP and "hand-over" in str(e.value)
+    sol.debug_inject_handover_fault(0, 0)
+    sol.reset_controls()
+    sol.seed(cfg.get("seed", 1234), 0)
+    sol.compute_control(cfg["start_state"])
+    again = sol.get_results()
+    np.testing.assert_array_equal(again["U"].view(np.uint32), good["U"].view(np.uint32))
+    assert again["traj_cost"] == good["traj_cost"]
+    np.testing.assert_array_equal(again["w"].view(np.uint32), good["w"].view(np.uint32))
+    sol.close()
+
+
 def test_slide_by_zero_is_a_no_op_and_hist_waits_for_a_pending_solve():
     """stride 0 (a tick without a new pose, run_control_loop.cuh:208-216) changes nothing; set_control_hist
     during an asynchronous solve waits for it, so that solve is still smoothed with the history it ran with."""
