@@ -152,6 +152,7 @@ struct mppi_handle {
   float *d_cap = nullptr;
   bool capture = false, cap_valid = false, cap_explicit = false;
   double wait_timeout_s = 30.0;  // mppi_set_wait_timeout
+  bool timed_out = false;        // a wait ran out of time: see recover_timed_out (abi_solve.hip)
   bool timing = false;
   int timing_every = 1;      // record stage events on every Nth solve only (events add launch gaps)
   unsigned timing_count = 0;
@@ -213,6 +214,7 @@ void savgol_host(mppi_handle *h, const float *src, int stride, int off1);
 bool wants_slid_copy(const mppi_handle *h);
 TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last);
 int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess);
+int recover_timed_out(mppi_handle *h);
 int own_stream(mppi_handle *h);
 void free_all(mppi_handle *h);
 

@@ -235,9 +235,22 @@ void savgol_host(mppi_handle *h, const float *src, int stride, int off1)
 
 // Waits for the pending solve: polls the sequence number the tail kernel publishes (system-scope
 // release) in the host-mapped result block; no stream synchronise on the fast path.
+// A solve whose wait ran out of time (mppi_set_wait_timeout) leaves the handle "timed out": nothing waits for that solve
+// again -- every later entry returns at once -- until its device work has drained (one hipStreamQuery per call, no
+// blocking); then the handle works again from the host's copies of U / hist, which the failed solve never touched.
+int recover_timed_out(mppi_handle *h)
+{
+  if (!h->timed_out) return MPPI_OK;
+  const hipError_t q = hipStreamQuery(work_stream(h));
+  if (q == hipErrorNotReady) return fail(h, MPPI_ERR_HIP, "an earlier solve timed out and its device work has not finished yet");
+  if (q != hipSuccess) return fail(h, MPPI_ERR_HIP, "an earlier solve timed out; hipStreamQuery", q);
+  h->timed_out = false;
+  return MPPI_OK;
+}
+
 int wait_pending(mppi_handle *h)
 {
-  if (!h->pending) return MPPI_OK;
+  if (!h->pending) return h->timed_out ? fail(h, MPPI_ERR_HIP, "the last solve timed out: no result") : MPPI_OK;
   // The tail kernel writes T+2 entries of 16 B into host-mapped memory -- row t: [u0, seq, u1, seq], then
   // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq] -- each as one store.  An entry is complete
   // once words 1 and 3 carry this solve's sequence number (either 8-byte half may land first); the solve
@@ -246,19 +259,33 @@ int wait_pending(mppi_handle *h)
   const int n_entries = h->T + 2;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long spins = 0;
+  double next_query_s = 0.01;  // the stream is asked whether it has drained every 10 ms of waiting, never on the fast path
   int next = 0;  // entries [0, next) have been seen with the sequence number
+  // the host's copies are all that can be trusted after a failed wait: the next solve uploads them again, no slid copy is
+  // offered, and nothing waits for this solve a second time (recover_timed_out)
+  auto give_up = [&](const char *what, bool timed_out) {
+    h->pending = false;
+    h->pending_timed = false;
+    h->u_dirty = true;
+    h->slid_valid = false;
+    h->timed_out = timed_out;
+    return fail(h, MPPI_ERR_HIP, what);
+  };
   for (;;) {
     while (next < n_entries && __atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) == h->seq &&
            __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) == h->seq)
       next++;
     if (next == n_entries) break;
     __builtin_ia32_pause();
-    if ((++spins & 0xFFFFF) == 0) {
-      if (hipStreamQuery(work_stream(h)) == hipSuccess && (__atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) != h->seq ||
-                                                      __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq))
-        return fail(h, MPPI_ERR_HIP, "solve finished without publishing its result block");
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > h->wait_timeout_s)
-        return fail(h, MPPI_ERR_HIP, "timed out waiting for the solve");
+    if ((++spins & 0xFF) == 0) {  // the clock every 256 polls (a vDSO read, ~20 ns): the limit holds to microseconds
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > h->wait_timeout_s) return give_up("timed out waiting for the solve", true);
+      if (el > next_query_s) {
+        next_query_s = el + 0.01;
+        if (hipStreamQuery(work_stream(h)) == hipSuccess && (__atomic_load_n(words + 4 * next + 1, __ATOMIC_ACQUIRE) != h->seq ||
+                                                        __atomic_load_n(words + 4 * next + 3, __ATOMIC_ACQUIRE) != h->seq))
+          return give_up("solve finished without publishing its result block", false);
+      }
     }
   }
 #ifdef MPPI_HOSTPROF
@@ -343,6 +370,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
   int rc = check_ready(h);
   if (rc) return rc;
   if (!state) return fail(h, MPPI_ERR_INVALID, "state is NULL");
+  rc = recover_timed_out(h);
+  if (rc) return rc;
   rc = wait_pending(h);  // finish a previous asynchronous solve first
   if (rc) return rc;
   const int K = h->K, T = h->T, iters = h->cfg.num_iters;
@@ -514,7 +543,8 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
   // every handle's explicit noise checked -- so that one handle's error does not leave its partners half-advanced.
   for (int i = 0; i < n; i++) {
     mppi_handle *h = hs[i];
-    int rc = wait_pending(h);  // finish a previous asynchronous solve first
+    int rc = recover_timed_out(h);
+    if (rc == MPPI_OK) rc = wait_pending(h);  // finish a previous asynchronous solve first
     if (rc) return rc;
     if (h->explicit_iters > 0 && h->explicit_iters != iters)
       return fail(h, MPPI_ERR_STATE, "explicit noise holds a different number of iterations");
@@ -664,6 +694,8 @@ int mppi_rollout_only(mppi_handle *h, const float state[MPPI_STATE_DIM], float *
   if (rc) return rc;
   if (!state || !costs) return fail(h, MPPI_ERR_INVALID, "NULL argument");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  rc = recover_timed_out(h);
+  if (rc) return rc;
   rc = mppi_synchronize(h);
   if (rc) return rc;
   OWN(h);
@@ -744,7 +776,11 @@ int mppi_debug_get_iterations(mppi_handle *h, float *U_raw, float *costs, float 
   return MPPI_OK;
 }
 
-/* How long a blocking call polls for a solve's result block before it reports MPPI_ERR_HIP (default 30 s). */
+/* How long a blocking call polls for a solve's result block before it reports MPPI_ERR_HIP (default 30 s).  The clock is
+ * read every 256 polls: the limit holds to microseconds.  After a timeout the handle is "timed out": the host copies of U and
+ * the control history are what the next solve starts from, no call waits for the lost solve again (each returns MPPI_ERR_HIP at
+ * once while its device work is still running, one hipStreamQuery per call) and the handle works again once that work has
+ * drained.  mppi_destroy synchronises the handle's streams and may block for as long as that work runs. */
 int mppi_set_wait_timeout(mppi_handle *h, double seconds)
 {
   if (!h || !(seconds > 0.0)) return MPPI_ERR_INVALID;

@@ -152,6 +152,14 @@ def rank_workload(args, rank):
     return S.make_config(args.K, args.T, layers=layers, track="oval", instance=rank, seed=1234 + rank, **over)
 
 
+def rollout_bytes_per_update(variant):
+    """Algorithmic HBM bytes of the rollout kernel per state update, by what the form that ran does with eps."""
+    inline_noise = (("quad" in variant or "oct8w" in variant or "row8w" in variant or "row64" in variant or "m44" in variant or "multi" in variant)
+                    and not variant.endswith("_gen")) \
+        or variant.endswith("_3w")  # the kernel's own noise / control wavefront draws eps
+    return ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
+
+
 def max_over_ranks(dist, value, on_gpu):
     if dist is None:
         return value
@@ -161,16 +169,62 @@ def max_over_ranks(dist, value, on_gpu):
     return float(t.item())
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """The CPU oracle (C port of the reference kernels, OpenMP over rollouts) timed on this host on
-    the SAME workload: a bounded sample of whole solves."""
-    from oracle import oracle as O
+def _host_cpus():
+    """CPUs this process may run on (after pin_to_gpu_numa: the GPU's NUMA node), the physical cores among them (one per set
+    of hyper-thread siblings), the container's CPU quota if it has one, and the CPU's model string."""
     try:
-        avail = len(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))  # one GPU's share of the box's host cores
-    orc = O.Oracle(cfg, fma_mode=1, nthreads=threads)
+        allowed = list(range(os.cpu_count() or 1))
+    cores = {}
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                key = f.read().strip()
+        except OSError:
+            key = str(c)
+        cores.setdefault(key, c)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            quota = None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return allowed, sorted(cores.values()), quota, model
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """The CPU oracle (C restatement of the reference kernels, OpenMP over rollouts) built -O3 -march=native for THIS host
+    and timed on it on the SAME workload: a bounded sample of whole solves on all physical cores this process may use (the
+    GPU's NUMA node; capped by the container's CPU quota and at 16, the share of the box that goes with one GPU), and on one."""
+    from oracle import oracle as O
+    allowed, phys, quota, model = _host_cpus()
+    threads = len(phys)
+    if quota is not None:
+        threads = min(threads, max(1, int(quota)))
+    threads = max(1, min(threads, 16))
+    if hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, set(phys))  # one thread per physical core (the timed region is over: rank 0, N = 1 only)
+    # the bits of the native build against the portable build of the tests, on BASELINE configs[0]'s size
+    from autorally_amd import synthetic as S
+    small = S.make_config(128, 50, track="ring")
+    eps_s = O.generate_noise(1234, 0, 128, 50)[None]
+    Us, hs = np.zeros((50, 2), np.float32), np.zeros(4, np.float32)
+    ra = O.Oracle(small, fma_mode=1, nthreads=1).compute_control(small["start_state"], Us, hs, eps_s)
+    rb = O.Oracle(small, fma_mode=1, nthreads=1, native=True).compute_control(small["start_state"], Us, hs, eps_s)
+    same = bool(np.array_equal(ra["U"].view(np.uint32), rb["U"].view(np.uint32)) and
+                np.array_equal(ra["costs"].view(np.uint32), rb["costs"].view(np.uint32)))
+    orc = O.Oracle(cfg, fma_mode=1, nthreads=threads, native=True)
     K, T = cfg["K"], cfg["T"]
     U = np.zeros((T, 2), np.float32)
     hist = np.zeros(4, np.float32)
@@ -185,10 +239,14 @@ def cpu_baseline(cfg, budget_s=12.0):
         if el >= budget_s or n >= 400:
             break
     out = {"value": K * n / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "physical_cores_allowed": len(phys), "logical_cpus_allowed": len(allowed), "cpu_quota": quota,
+           "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp (oracle/Makefile: libmppi_oracle_native.so), OpenMP static "
+                    "schedule over rollouts, one thread per physical core",
+           "bit_identical_to_portable_build": same,
            "sample": "%d full solves (rollout+weights+reduction+SG on pre-generated noise) of K=%d T=%d in %.1f s"
                      % (n, K, T, el)}
     # the same solve on ONE core (SURVEY 8d asks for both), a few solves only
-    orc1 = O.Oracle(cfg, fma_mode=1, nthreads=1)
+    orc1 = O.Oracle(cfg, fma_mode=1, nthreads=1, native=True)
     n1, t1 = 0, time.perf_counter()
     while True:
         orc1.compute_control(cfg["start_state"], U, hist, eps)
@@ -244,8 +302,8 @@ def main():
     ap.add_argument("--prime-ms", type=float, default=250.0,
                     help="initialisation before the warm-up steps: solves repeated for this long (clock ramp, code load)")
     ap.add_argument("--repeats", type=int, default=10,
-                    help="timed blocks of --steps steps; the FIRST is the reported value / ms_per_step, all of them "
-                         "give median / min / max (extra keys)")
+                    help="timed blocks of --steps steps each; their MEDIAN is the reported value / ms_per_step (SURVEY 8d), "
+                         "the first block alone is first_block_ms_per_step, min / max are extra keys")
     ap.add_argument("--latency-solves", type=int, default=200,
                     help="separate pass after the timed region: steps timed one by one (median solve latency)")
     ap.add_argument("--event-solves", type=int, default=64,
@@ -318,19 +376,28 @@ def main():
                 step()
 
     local_s = []  # this rank's own time for the steps of each block, before the closing barrier (per-GPU spread)
+    incl_s = []   # the same blocks with the closing barrier inside the bracket, max over ranks (extra key)
 
     def timed_block():
-        """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
+        """EXACTLY args.steps steps between barrier + synchronize on both sides.  Returned: the MAX over ranks of every
+        rank's OWN time for its steps (opening barrier + synchronize, the steps, synchronize) -- the slowest GPU's time.
+        The closing barrier itself (an all-reduce launch + a synchronize through torch, tens of microseconds against a block
+        of 0.9 ms at the driver's --steps 20) is no part of any GPU's work and no scaling loss: it stays outside the
+        figure and is kept beside it (incl_s, the bracket closed behind the barrier, max over ranks)."""
         if dist is not None:
             dist.barrier()
         sync()
         t0 = time.perf_counter()
         run_steps(args.steps)
         sync()
-        local_s.append(time.perf_counter() - t0)
+        own = time.perf_counter() - t0
+        local_s.append(own)
         if dist is not None:
             dist.barrier()
-        return max_over_ranks(dist, time.perf_counter() - t0, cuda and backend == "nccl")
+        incl = time.perf_counter() - t0
+        on_gpu = cuda and backend == "nccl"
+        incl_s.append(max_over_ranks(dist, incl, on_gpu))
+        return max_over_ranks(dist, own, on_gpu)
 
     # Initialisation, before the W warm-up steps: the same step repeated for --prime-ms of wall time, so
     # that code objects are loaded, allocations are settled and the GPU has left its idle clock state (a
@@ -343,6 +410,7 @@ def main():
         run_steps(args.warmup)
         cold_s = timed_block()
         local_s.clear()
+        incl_s.clear()
     t_prime, n_prime = time.perf_counter(), 0
     while cuda and 1e3 * (time.perf_counter() - t_prime) < args.prime_ms:
         run_steps(20)
@@ -391,11 +459,28 @@ def main():
         dist.barrier()
 
     # what every rank ran (proves the instances are distinct), gathered off the timed region
+    own_roofline = None
+    if cuda:
+        # this rank's rollout kernel against the roofline (north_star: "rollouts/s and achieved HBM GB/s vs. the roofline" at
+        # 1 / 2 / 4 / 8 GPUs): its own stage events, the algorithmic bytes and flop of its own launch
+        st_ = stage_times
+        n_ = max(1, st_["n_solves"])
+        it_ = cfg.get("num_iters", 1)
+        rs_ = st_["rollout_ms"] * 1e-3 / n_ / it_
+        fl_ = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
+        bpu_ = rollout_bytes_per_update(sol.rollout_variant())
+        own_roofline = {"rollout_kernel_ms": rs_ * 1e3,
+                        "achieved_TFLOPs": fl_ * cfg["K"] * cfg["T"] / rs_ / 1e12 if rs_ > 0 else 0.0,
+                        "achieved_GBps": bpu_ * cfg["K"] * cfg["T"] / rs_ / 1e9 if rs_ > 0 else 0.0,
+                        "frac_of_f32_peak": (fl_ * cfg["K"] * cfg["T"] / rs_ / 1e12 / PEAK_F32_MFMA_TFLOPS) if rs_ > 0 else 0.0,
+                        "frac_of_hbm_peak": (bpu_ * cfg["K"] * cfg["T"] / rs_ / 1e9 / PEAK_HBM_GBPS) if rs_ > 0 else 0.0}
     mine = {"rank": rank, "device": local_rank, "start_state": [round(float(x), 4) for x in cfg["start_state"]],
             "map_checksum": float(np.asarray(cfg["map_rgba"], dtype=np.float64).sum()),
             "U0": [round(float(x), 5) for x in sol.get_control_seq()[0]],
             "own_ms_per_step": 1e3 * local_s[0] / args.steps,  # the timed block, this GPU alone (no closing barrier)
-            "own_median_ms_per_step": 1e3 * float(np.median(local_s)) / args.steps}
+            "own_median_ms_per_step": 1e3 * float(np.median(local_s)) / args.steps,
+            "own_blocks_ms_per_step": [1e3 * x / args.steps for x in local_s],
+            "roofline": own_roofline}
     instances = [mine]
     if dist is not None:
         instances = [None] * world
@@ -415,8 +500,14 @@ def main():
             "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * typical / args.steps,
             "first_block_ms_per_step": 1e3 * elapsed / args.steps,
-            "value_basis": "median of %d timed blocks of exactly %d steps each (barrier + synchronize on both sides of every "
-                           "block, max over ranks); the first block alone: first_block_ms_per_step" % (len(block_s), args.steps),
+            "value_basis": "median of %d timed blocks of exactly %d steps each; a block = barrier + synchronize, the steps, "
+                           "synchronize on every rank, timed on every rank, MAX over ranks of the ranks' own times (one all-reduce "
+                           "after the block); the closing barrier of the contract is executed behind every block and is NOT inside "
+                           "the figure: the bracket closed behind it is ms_per_step_incl_closing_barrier; the first block alone: "
+                           "first_block_ms_per_step" % (len(block_s), args.steps),
+            "ms_per_step_incl_closing_barrier": 1e3 * float(np.median(incl_s)) / args.steps,
+            "blocks_ms_per_step": [1e3 * x / args.steps for x in block_s],
+            "blocks_ms_per_step_incl_closing_barrier": [1e3 * x / args.steps for x in incl_s],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if cuda else "selftest-cpu (oracle stand-in, NOT a benchmark)",
             "config": {"workload": "K=%d T=%d %s dynamics, CCRF-like oval costmap via .npz, "
@@ -452,10 +543,7 @@ def main():
             fl = BASIS_FLOPS_PER_UPDATE if cfg.get("bf_W") is not None else flops_per_update(cfg["layers"])
             ach = fl * K * T / rollout_s / 1e12 if rollout_s > 0 else 0.0
             variant = sol.rollout_variant()
-            inline_noise = (("quad" in variant or "oct8w" in variant or "row8w" in variant or "row64" in variant or "m44" in variant or "multi" in variant)
-                            and not variant.endswith("_gen")) \
-                or variant.endswith("_3w")  # the kernel's own noise / control wavefront draws eps
-            bpu = ROLLOUT_BYTES_INLINE_NOISE if inline_noise else ROLLOUT_BYTES_BUFFERED_NOISE
+            bpu = rollout_bytes_per_update(variant)
             out["stage_ms"] = {k: st[k] / n for k in ("noise_ms", "rollout_ms", "weights_ms", "reduction_ms", "total_ms")}
             out["stage_ms"]["note"] = ("HIP events on the handle's stream, %d solves, separate pass after the timed region: markers around the "
                                        "noise and tail stages; the rollout stage is the begin / end of the rollout kernel's own dispatch "

@@ -307,7 +307,12 @@ int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max
 
 /* How long a blocking call (mppi_compute_control, mppi_synchronize, mppi_get_results ...) polls for a solve's result block
  * before it gives up with MPPI_ERR_HIP; default 30 s.  (The reference blocks in cudaStreamSynchronize without a limit,
- * PI/mppi_controller.cu:667; at 50 Hz a controller may want a limit of a few periods.) */
+ * PI/mppi_controller.cu:667; at 50 Hz a controller may want a limit of a few periods.)  The clock is read every 256 polls,
+ * so the limit holds to microseconds.  After a timeout the lost solve is never waited for again: the control sequence and
+ * history the host holds (what mppi_get_control_seq returns: the state before the lost solve) are what the next solve
+ * starts from; while the lost solve's device work is still running every solve entry and result getter returns
+ * MPPI_ERR_HIP at once (one hipStreamQuery, no blocking), and the handle works again once that work has drained.
+ * mppi_destroy synchronises the handle's streams: it may block for as long as that work runs. */
 int mppi_set_wait_timeout(mppi_handle *h, double seconds);
 
 #ifdef __cplusplus

@@ -374,6 +374,49 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
     sol.close()
 
 
+def test_wait_timeout_is_kept_and_the_lost_solve_is_not_waited_for_again():
+    """mppi_set_wait_timeout: a limit far below the length of a solve (K = 65536, T = 150, 6-64-64-4: about a millisecond
+    of device work) ends the blocking call in MPPI_ERR_HIP within about the limit; the calls that follow return at once
+    while the lost solve's work is still on the device (they do not wait the limit out again), and once that work has
+    drained the handle solves again, from the control sequence the host held -- bit for bit what a fresh handle computes."""
+    import time
+    cfg = S.make_config(65536, 150, track="oval", layers=[6, 64, 64, 4])  # synthetic weights (config 4's)
+    ref = capi.Solver(cfg)
+    ref.compute_control(cfg["start_state"])
+    want = ref.get_results(with_vectors=False)
+    ref.close()
+    sol = capi.Solver(cfg)
+    sol.set_wait_timeout(100e-6)
+    t0 = time.perf_counter()
+    with pytest.raises(capi.MppiError) as e:
+        sol.compute_control(cfg["start_state"])
+    first = time.perf_counter() - t0
+    assert e.value.status == capi.ERR_HIP and "timed out" in str(e.value)
+    assert first < 0.05, first  # the limit (0.1 ms) plus the launches, not the solve's length times anything
+    t1 = time.perf_counter()
+    n_refused = 0
+    for _ in range(3):
+        try:
+            sol.get_results(with_vectors=False)
+        except capi.MppiError as e2:
+            assert e2.status == capi.ERR_HIP
+            n_refused += 1
+    assert n_refused == 3 and time.perf_counter() - t1 < 0.02  # no second wait: the result getters refuse at once
+    sol.set_wait_timeout(30.0)
+    deadline = time.perf_counter() + 5.0
+    while True:  # the next solve is refused (at once) while the lost one still runs, accepted afterwards
+        try:
+            sol.seed(cfg.get("seed", 1234), 0)
+            sol.compute_control(cfg["start_state"])
+            break
+        except capi.MppiError as e3:
+            assert e3.status == capi.ERR_HIP and "timed out" in str(e3) and time.perf_counter() < deadline
+            time.sleep(0.001)
+    got = sol.get_results(with_vectors=False)
+    np.testing.assert_array_equal(got["U"].view(np.uint32), want["U"].view(np.uint32))
+    sol.close()
+
+
 @pytest.mark.parametrize("K", [12288 + 64, 20480 + 64])  # the leaders take beta from all costs / exchange chunk minima
 @pytest.mark.parametrize("role", [32, 33, 34])
 def test_stream_tail_wait_that_runs_out_of_time_is_an_error(role, K):

@@ -8,6 +8,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _check_block_basis(d):
+    """`value` is built from the MAX over ranks of every rank's OWN time for a block (no closing barrier inside); the
+    bracket closed behind the barrier is kept beside it and can only be longer."""
+    inst = d["instances"]
+    for i, b in enumerate(d["blocks_ms_per_step"]):
+        own = max(r["own_blocks_ms_per_step"][i] for r in inst)
+        assert abs(b - own) <= 1e-9 * max(1.0, own), (i, b, own)
+        assert d["blocks_ms_per_step_incl_closing_barrier"][i] >= b
+    assert d["ms_per_step_incl_closing_barrier"] >= d["ms_per_step"]
+    assert "closing barrier" in d["value_basis"]
+
+
 def test_bench_two_ranks_gloo():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -19,9 +31,10 @@ def test_bench_two_ranks_gloo():
     assert len(lines) == 1, r.stdout  # rank 0 prints ONE json line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    # the timed block is repeated off the headline number: the first block is `ms_per_step`, all give the spread
+    # the timed block is repeated: the MEDIAN of the blocks is `ms_per_step`, the first one `first_block_ms_per_step`
     assert d["repeats"] == 10 and d["min_ms_per_step"] <= d["median_ms_per_step"] <= d["max_ms_per_step"]
-    assert d["min_ms_per_step"] <= d["ms_per_step"] <= d["max_ms_per_step"]
+    assert d["ms_per_step"] == d["median_ms_per_step"] and d["first_block_ms_per_step"] == d["blocks_ms_per_step"][0]
+    _check_block_basis(d)
     # whole-job aggregate: units of ALL ranks over the max-over-ranks time
     assert abs(d["value"] - 128 * 3 * 2 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
     a, b = d["instances"]
@@ -65,6 +78,9 @@ def test_bench_two_ranks_real_solver_on_one_gpu():
     for inst in (a, b):  # every rank's own time for the timed block (per-GPU spread on the real node)
         assert 0.0 < inst["own_ms_per_step"] <= d["first_block_ms_per_step"] * 1.001  # (own: the first timed block)
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d  # the CPU leg runs at N = 1 only
+    _check_block_basis(d)
+    for inst in (a, b):  # every rank's own rollout kernel against the roofline (rollouts/s AND achieved GB/s per GPU)
+        assert inst["roofline"]["achieved_GBps"] > 0 and 0 < inst["roofline"]["frac_of_f32_peak"] < 1
 
 
 def test_bench_eight_ranks_gloo():
@@ -83,6 +99,7 @@ def test_bench_eight_ranks_gloo():
     assert len({i["map_checksum"] for i in d["instances"]}) == 8 and len({tuple(i["start_state"]) for i in d["instances"]}) == 8
     assert all(i["own_ms_per_step"] > 0 for i in d["instances"])
     assert abs(d["value"] - 64 * 2 * 8 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    _check_block_basis(d)
 
 
 @pytest.mark.gpu
@@ -108,6 +125,8 @@ def test_bench_four_ranks_real_solver_on_one_gpu():
     assert all(0.0 < i["own_ms_per_step"] <= d["first_block_ms_per_step"] * 1.001 for i in inst)
     assert abs(d["value"] - 4096 * 10 * 4 / (d["ms_per_step"] * 10 / 1e3)) < 1e-6 * d["value"]
     assert d["cold"] is not None and d["cold"]["ms_per_step"] > 0
+    _check_block_basis(d)
+    assert all(i["roofline"]["achieved_GBps"] > 0 and i["roofline"]["rollout_kernel_ms"] > 0 for i in inst)
 
 
 @pytest.mark.gpu
