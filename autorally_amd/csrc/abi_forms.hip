@@ -24,10 +24,10 @@ bool form_supported(Form f, int hidden, int n_hidden)
 {
   switch (f) {
     case Form::M44: case Form::M44Chain: return m44_variant_supported(hidden, n_hidden);
-    case Form::Row64R8: case Form::Row64R16: return row64_variant_supported(hidden, n_hidden);
+    case Form::Row64R16: return row64_variant_supported(hidden, n_hidden);
     case Form::Oct: return oct_variant_supported(hidden, n_hidden);
     case Form::Row: case Form::RowTree: return row_variant_supported(hidden, n_hidden);
-    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
+    case Form::Multi2: case Form::Multi4: case Form::Multi4Tree:
       return multi_variant_supported(hidden, n_hidden);
     case Form::Quad: case Form::Fused64: case Form::Fused256: return mfma_variant_supported(hidden, n_hidden);
     default: return false;
@@ -99,16 +99,16 @@ bool form_generator_noise(const mppi_handle *h)
 {
   if (h->forced != Form::Auto) return h->multi_standalone_noise;
   const Form f = form_of(h);
-  return f == Form::Multi4 || f == Form::Multi4U || f == Form::Multi4Tree;
+  return f == Form::Multi4 || f == Form::Multi4Tree;
 }
 
 // does the rollout kernel draw eps itself (a control / noise wavefront with the in-kernel MRG32k3a)?
 bool has_noise_wave(const mppi_handle *h)
 {
   switch (form_of(h)) {
-    case Form::Bf3: case Form::Quad: case Form::Row: case Form::RowTree: case Form::Row64R8: case Form::Row64R16: case Form::M44: case Form::M44Chain:
+    case Form::Bf3: case Form::Quad: case Form::Row: case Form::RowTree: case Form::Row64R16: case Form::M44: case Form::M44Chain:
       return true;
-    case Form::Oct: case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
+    case Form::Oct: case Form::Multi2: case Form::Multi4: case Form::Multi4Tree:
       return !form_generator_noise(h);
     default:
       return false;
@@ -116,9 +116,9 @@ bool has_noise_wave(const mppi_handle *h)
 }
 
 int form_bf_waves(Form f) { return f == Form::Bf3 ? 3 : f == Form::Bf2 ? 2 : 1; }
-int form_multi_nd(Form f)  // launch_rollout_multi's code: 40 = multi4u, 44 = multi4 with the tree output layer
+int form_multi_nd(Form f)  // launch_rollout_multi's code: 44 = multi4 with the tree output layer
 {
-  return f == Form::Multi1 ? 1 : f == Form::Multi2 ? 2 : f == Form::Multi4 ? 4 : f == Form::Multi4Tree ? 44 : 40;
+  return f == Form::Multi2 ? 2 : f == Form::Multi4 ? 4 : 44;
 }
 int form_fused_threads(Form f) { return f == Form::Quad ? 512 : f == Form::Fused256 ? 256 : 64; }
 
@@ -138,16 +138,13 @@ const char *mppi_rollout_variant(const mppi_handle *h)
     case Form::Bf1: return "basis_funcs25_valu";
     case Form::ValuReg: return "valu_reg_lds";
     case Form::ValuLds: return "valu_lds";
-    case Form::Multi4U: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi4u%s", h->hidden, h->n_hidden, gen); break;
     case Form::Multi4Tree: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi4_tree%s", h->hidden, h->n_hidden, gen); break;
-    case Form::Multi1: case Form::Multi2: case Form::Multi4:
+    case Form::Multi2: case Form::Multi4:
       snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_multi%d%s", h->hidden, h->n_hidden, form_multi_nd(f), gen);
       break;
     case Form::Row: snprintf(buf, sizeof(buf), "valu_row8w_h%d_l%d", h->hidden, h->n_hidden); break;
     case Form::RowTree: snprintf(buf, sizeof(buf), "valu_row8w_tree_h%d_l%d", h->hidden, h->n_hidden); break;
-    case Form::Row64R8: case Form::Row64R16:
-      snprintf(buf, sizeof(buf), "valu_row64_r%d_tree_h%d_l%d", f == Form::Row64R8 ? 8 : 16, h->hidden, h->n_hidden);
-      break;
+    case Form::Row64R16: snprintf(buf, sizeof(buf), "valu_row64_r16_tree_h%d_l%d", h->hidden, h->n_hidden); break;
     case Form::M44: snprintf(buf, sizeof(buf), "mfma4x4x1_h%d_l%d_m44_split_tree", h->hidden, h->n_hidden); break;
     case Form::M44Chain: snprintf(buf, sizeof(buf), "mfma4x4x1_h%d_l%d_m44_tree", h->hidden, h->n_hidden); break;
     case Form::Oct: snprintf(buf, sizeof(buf), "mfma16x16x4_h%d_l%d_oct8w%s", h->hidden, h->n_hidden, gen); break;
@@ -170,8 +167,9 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
   else if (strcmp(name, "mfma") == 0) {
     if ((rc = need(h->mfma_ok, "MFMA variant needs 6-HxN-4 with H in {32,64}, N in {2,4}"))) return rc;
     h->pref = Pref::Mfma;
-  } else if (strcmp(name, "valu") == 0) h->pref = Pref::Valu;
-  else if (strcmp(name, "valu_lds") == 0) h->pref = Pref::ValuLds;
+    h->forced = Form::Auto;  // the table again, restricted to the forms in the reference's order: a form forced earlier does not stick
+  } else if (strcmp(name, "valu") == 0) { h->pref = Pref::Valu; h->forced = Form::Auto; }
+  else if (strcmp(name, "valu_lds") == 0) { h->pref = Pref::ValuLds; h->forced = Form::Auto; }
   else if (strcmp(name, "quad") == 0) h->forced = h->basis ? Form::Bf2 : Form::Quad;
   else if (strcmp(name, "bf3") == 0) {
     if ((rc = need(h->basis, "bf3 is a form of the basis-function model"))) return rc;
@@ -185,11 +183,9 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     if ((rc = need(h->mfma_ok && m44_variant_supported(h->hidden, h->n_hidden), "m44 form exists for 6-64x2-4 and 6-64x4-4"))) return rc;
     h->forced = name[3] == 0 ? Form::M44 : Form::M44Chain;
   }
-  else if (strcmp(name, "row64") == 0 || strcmp(name, "row64_r8") == 0 || strcmp(name, "row64_r16") == 0) {
+  else if (strcmp(name, "row64") == 0 || strcmp(name, "row64_r16") == 0) {  // the vector-ALU arm of the 64-wide A/B
     if ((rc = need(h->mfma_ok && row64_variant_supported(h->hidden, h->n_hidden), "row64 form exists for 6-64x2-4 and 6-64x4-4"))) return rc;
-    // 8 rollouts per group (one dynamics wave per SIMD) while every such group has a CU of its own, else 16
-    const int r = name[5] == 0 ? ((h->K / 8 <= h->num_simds / 4) ? 8 : 16) : (name[7] == '8' ? 8 : 16);
-    h->forced = r == 8 ? Form::Row64R8 : Form::Row64R16;
+    h->forced = Form::Row64R16;
   }
   else if (strcmp(name, "oct") == 0 || strcmp(name, "oct_gen") == 0) {
     if ((rc = need(h->mfma_ok && oct_variant_supported(h->hidden, h->n_hidden), "oct form exists for 6-64x2-4 and 6-64x4-4"))) return rc;
@@ -202,19 +198,13 @@ int mppi_set_rollout_variant(mppi_handle *h, const char *name)
     h->forced = Form::Multi4Tree;
     h->multi_standalone_noise = name[11] != 0;
   }
-  else if (strcmp(name, "multi4u") == 0 || strcmp(name, "multi4u_gen") == 0) {  // ND = 4, six waves (one cost wave)
-    if ((rc = need(h->K % 64 == 0, "multi form needs K to be a multiple of 16 ND"))) return rc;
-    if ((rc = need(h->mfma_ok && multi_variant_supported(h->hidden, h->n_hidden), "multi form exists for 6-32x2-4, 6-32x4-4 and 6-64x2-4"))) return rc;
-    h->forced = Form::Multi4U;
-    h->multi_standalone_noise = name[7] != 0;
-  }
   else if (strncmp(name, "multi", 5) == 0) {
     const int nd = name[5] - '0';
     const bool gen = strcmp(name + 6, "_gen") == 0;
-    if ((nd != 1 && nd != 2 && nd != 4) || (name[6] != 0 && !gen)) return fail(h, MPPI_ERR_INVALID, "unknown variant");
+    if ((nd != 2 && nd != 4) || (name[6] != 0 && !gen)) return fail(h, MPPI_ERR_INVALID, "unknown variant");
     if ((rc = need(h->K % (16 * nd) == 0, "multi form needs K to be a multiple of 16 ND"))) return rc;
     if ((rc = need(h->mfma_ok && multi_variant_supported(h->hidden, h->n_hidden), "multi form exists for 6-32x2-4, 6-32x4-4 and 6-64x2-4"))) return rc;
-    h->forced = nd == 1 ? Form::Multi1 : nd == 2 ? Form::Multi2 : Form::Multi4;
+    h->forced = nd == 2 ? Form::Multi2 : Form::Multi4;
     h->multi_standalone_noise = gen;
   }
   else if (strcmp(name, "fused") == 0 || strcmp(name, "block256") == 0) h->forced = h->basis ? Form::Bf1 : Form::Fused256;

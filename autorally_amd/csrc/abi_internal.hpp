@@ -43,10 +43,10 @@ enum class Form : int {
   Fused64, Fused256,                // rollout_mfma.hip: one wave per 16 rollouts does everything (workgroups of 1 / 4 waves)
   Quad,                             // rollout_mfma.hip: network split over two waves + cost + control wave per 16 rollouts
   Oct,                              // rollout_oct.hip: 64-wide nets, four dynamics waves (one M tile each) + four riders
-  Multi1, Multi2, Multi4, Multi4U,  // rollout_multi.hip: ND dynamics waves of 16 rollouts + riders (4U: six waves)
+  Multi2, Multi4,                   // rollout_multi.hip: ND dynamics waves of 16 rollouts + riders
   Multi4Tree,                       // ... ND = 4 with the output layer as a butterfly over a rollout's four lanes
   Row, RowTree,                     // rollout_row.hip: 6-32-32-4 on the vector ALU; Tree: butterfly output layer
-  Row64R8, Row64R16,                // rollout_row64.hip: 64-wide nets on the vector ALU, 8 / 16 rollouts per group
+  Row64R16,                         // rollout_row64.hip: 64-wide nets on the vector ALU, 16 rollouts per group
   M44, M44Chain,                    // rollout_m44.hip: 64-wide nets on v_mfma_f32_4x4x1 with A-broadcast; hidden layers as two
                                     // accumulation chains (the automatic form) / Chain: one, the reference's order
   ValuReg, ValuLds,                 // rollout_valu.hip: throughput-style vector kernels (any layer list: ValuLds)
@@ -152,7 +152,8 @@ struct mppi_handle {
   float *d_cap = nullptr;
   bool capture = false, cap_valid = false, cap_explicit = false;
   double wait_timeout_s = 30.0;  // mppi_set_wait_timeout
-  bool timed_out = false;        // a wait ran out of time: see recover_timed_out (abi_solve.hip)
+  bool timed_out = false;        // a wait ran out of time and that solve's device work may still run: recover_timed_out (abi_solve.hip)
+  bool no_result = false;        // the last solve was lost (timeout): mppi_get_results refuses until a solve completes
   bool timing = false;
   int timing_every = 1;      // record stage events on every Nth solve only (events add launch gaps)
   unsigned timing_count = 0;
@@ -200,7 +201,7 @@ int form_bf_waves(Form f);
 int form_multi_nd(Form f);
 int form_fused_threads(Form f);
 inline bool form_is_row(Form f) { return f == Form::Row || f == Form::RowTree; }
-inline bool form_is_row64(Form f) { return f == Form::Row64R8 || f == Form::Row64R16; }
+inline bool form_is_row64(Form f) { return f == Form::Row64R16; }
 hipStream_t batch_stream(int device);
 void fill_cost_args(const mppi_handle *h, CostArgs &c);
 void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, RolloutArgs &a);

@@ -88,13 +88,13 @@ int launch_rollout(mppi_handle *h, const RolloutArgs &a)
   hipError_t e = hipSuccess;
   switch (f) {
     case Form::Bf1: case Form::Bf2: case Form::Bf3: e = launch_rollout_bf(a, form_bf_waves(f), h->stream); break;
-    case Form::Multi1: case Form::Multi2: case Form::Multi4: case Form::Multi4U: case Form::Multi4Tree:
+    case Form::Multi2: case Form::Multi4: case Form::Multi4Tree:
       e = launch_rollout_multi(h->hidden, h->n_hidden, a, form_multi_nd(f), h->stream);
       break;
     case Form::Oct: e = launch_rollout_oct(h->hidden, h->n_hidden, a, h->stream); break;
     case Form::M44: e = launch_rollout_m44(h->hidden, h->n_hidden, a, true, h->stream); break;
     case Form::M44Chain: e = launch_rollout_m44(h->hidden, h->n_hidden, a, false, h->stream); break;
-    case Form::Row64R8: case Form::Row64R16: e = launch_rollout_row64(h->hidden, h->n_hidden, a, f == Form::Row64R8 ? 8 : 16, h->stream); break;
+    case Form::Row64R16: e = launch_rollout_row64(h->hidden, h->n_hidden, a, 16, h->stream); break;
     case Form::Row: case Form::RowTree: e = launch_rollout_row(h->hidden, h->n_hidden, a, f == Form::RowTree, h->stream); break;
     case Form::Quad: case Form::Fused64: case Form::Fused256:
       e = launch_rollout_mfma(h->hidden, h->n_hidden, a, form_fused_threads(f), h->stream);
@@ -250,7 +250,7 @@ int recover_timed_out(mppi_handle *h)
 
 int wait_pending(mppi_handle *h)
 {
-  if (!h->pending) return h->timed_out ? fail(h, MPPI_ERR_HIP, "the last solve timed out: no result") : MPPI_OK;
+  if (!h->pending) return recover_timed_out(h);  // nothing to wait for; a lost solve's device work must have drained
   // The tail kernel writes T+2 entries of 16 B into host-mapped memory -- row t: [u0, seq, u1, seq], then
   // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq] -- each as one store.  An entry is complete
   // once words 1 and 3 carry this solve's sequence number (either 8-byte half may land first); the solve
@@ -269,6 +269,7 @@ int wait_pending(mppi_handle *h)
     h->u_dirty = true;
     h->slid_valid = false;
     h->timed_out = timed_out;
+    h->no_result = true;  // until the next solve completes: the result getters refuse
     return fail(h, MPPI_ERR_HIP, what);
   };
   for (;;) {
@@ -292,6 +293,7 @@ int wait_pending(mppi_handle *h)
   hp_seen = std::chrono::steady_clock::now();
 #endif
   h->pending = false;
+  h->no_result = false;
   h->baseline = h->h_res[4 * h->T + 0];
   h->eta = h->h_res[4 * h->T + 2];
   h->traj_cost = h->h_res[4 * (h->T + 1) + 0];
@@ -661,6 +663,7 @@ int mppi_get_results(mppi_handle *h, float *U, float *traj_cost, float *costs, f
   if (!h) return MPPI_ERR_INVALID;
   int rc = mppi_synchronize(h);
   if (rc) return rc;
+  if (h->no_result) return fail(h, MPPI_ERR_HIP, "the last solve timed out: no result");
   if (U) memcpy(U, h->U.data(), sizeof(float) * 2 * (size_t)h->T);
   if (traj_cost) *traj_cost = h->traj_cost;
   if (costs || weights) {
@@ -680,6 +683,7 @@ int mppi_get_applied_controls(mppi_handle *h, float *V, size_t n)
   if (n != slot) return fail(h, MPPI_ERR_INVALID, "n != K*T*2");
   int rc = mppi_synchronize(h);
   if (rc) return rc;
+  if (h->no_result) return fail(h, MPPI_ERR_HIP, "the last solve timed out: no result");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   OWN(h);
   HIPCHK(h, launch_tk_to_kt(h->v_buf, h->d_stage, h->K, h->T, h->stream));

@@ -45,20 +45,23 @@ hipError_t launch_rollout_oct(int hidden, int n_hidden, const RolloutArgs &a, hi
 // control and noise wave per 16 rollouts; a.wpack = the weights in register order (pack_row_weights, mppi_abi.hip)
 bool row_variant_supported(int hidden, int n_hidden);
 int row_pack_floats();
-// tree: the output layer as own-activation partials + a DPP butterfly (NOT the reference's summation order: opt-in by tolerance)
+// tree: the output layer as own-activation partials + a DPP butterfly (NOT the reference's summation order; the AUTOMATIC form
+// for 6-32-32-4 up to 8192 rollouts: "row_exact" / "mfma" restore the order)
 hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, bool tree, hipStream_t stream);
 hipError_t launch_rollout_row_batch(const QuadBatchArgs &b, bool tree, hipStream_t stream);  // grid (groups, instances)
 
 // rollout_row64.hip: latency form of 64-wide nets on the vector ALU -- r / 2 dynamics waves (two rollouts of 32 lanes each) +
-// pose, cost, control and noise wave per r = 8 or 16 rollouts; hidden layers' weights from LDS, output layer as a butterfly
-// (NOT the reference's summation order: opt-in by tolerance); a.wpack = pack_row64_weights (mppi_abi.hip)
+// pose, cost, control and noise wave per r = 16 rollouts; hidden layers' weights from LDS, output layer as a butterfly
+// (NOT the reference's summation order; never chosen automatically: config 4's vector-ALU A/B arm); a.wpack = pack_row64_weights (mppi_abi.hip)
 bool row64_variant_supported(int hidden, int n_hidden);
 int row64_pack_floats(int n_hidden);
 hipError_t launch_rollout_row64(int hidden, int n_hidden, const RolloutArgs &a, int r, hipStream_t stream);
 
 // rollout_m44.hip: latency form of 64-wide nets on v_mfma_f32_4x4x1 with A-matrix broadcast -- four dynamics waves (four
 // rollouts each, all hidden weights in registers) + pose, cost, control and noise wave per 16 rollouts; output layer as a
-// butterfly (NOT the reference's summation order: opt-in by tolerance); a.wpack = pack_m44_weights (mppi_abi.hip)
+// butterfly, hidden layers (split) as two accumulation chains -- NOT the reference's summation order, and the AUTOMATIC form
+// for 64-wide nets up to 8192 rollouts ("m44_chain": hidden layers in the reference's order; "mfma": every layer);
+// a.wpack = pack_m44_weights (mppi_abi.hip)
 bool m44_variant_supported(int hidden, int n_hidden);
 int m44_pack_floats(int n_hidden);
 hipError_t launch_rollout_m44(int hidden, int n_hidden, const RolloutArgs &a, bool split, hipStream_t stream);  // split: two chains per hidden layer
@@ -87,7 +90,7 @@ hipError_t launch_dynamics_bf(const float *W, const float *states, const float *
                               hipStream_t stream);
 
 // solve_kernels.hip
-// everything of one solve iteration after the rollout (solve_tail_kernel; preceded by weights_kernel for K > 4096)
+// everything of one solve iteration after the rollout (solve_tail_kernel / _wide_kernel up to 8192 rollouts, solve_tail_stream_kernel beyond)
 struct TailLaunch {
   const float *costs, *V, *hist;
   float *U, *w, *scal, *res, *part, *slid;

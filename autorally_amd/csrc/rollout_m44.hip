@@ -22,9 +22,17 @@
 //     rollout i -- it multiplies them into the four outputs (a product and three fused multiply-adds each, packed) and the 16
 //     blocks are summed by a butterfly that halves the live values: v_permlane32_swap (lower half-wave keeps outputs {0,1}),
 //     v_permlane16_swap (even rows keep the first of the pair), row_ror:8, row_ror:4.  Row c ends with output c.  NOT the
-//     reference's summation order: like the tree forms of rollout_row.hip / rollout_row64.hip it is checked bit for bit
-//     against the test oracle's own mode (3) and against the nominal oracle at the north-star tolerance
-//     (tests/test_m44_gpu.py).  The hidden layers keep the reference's order.
+//     reference's summation order;
+//   * the HIDDEN layers: template parameter SPLIT.  SPLIT (the AUTOMATIC form for 64-wide nets up to 8192 rollouts since the
+//     end of round 4, variant "m44", name "..._m44_split_tree"): the even-k and the odd-k matrix instructions accumulate
+//     into two registers that are added at the end -- two independent chains issue at the pipe's 8 cycles instead of one
+//     dependent chain's 12.2.  NOT the reference's order either: the test oracle states it as mode 5.  !SPLIT (variant
+//     "m44_chain", name "..._m44_tree", oracle mode 3): one chain per hidden layer, the reference's k-ascending order --
+//     a maintainer comparing bits of hidden-layer activations with the CUDA binary wants this one, or "mfma" (the oct form:
+//     the reference's order in EVERY layer).
+//     Both are checked bit for bit against their oracle mode and against the NOMINAL oracle at the north-star tolerance
+//     (tests/test_m44_gpu.py); what the re-association costs at the 1e-4 mark, at the launch defaults:
+//     profiles/r05_b_nominal_margin_wd.txt (no more draws beyond 1e-4 than the exact oct form).
 #include "group_roles.hpp"
 #include "mppi_kernels.hpp"
 

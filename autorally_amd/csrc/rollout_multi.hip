@@ -200,11 +200,8 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
-// SPLIT_ = false at ND = 4 ("multi4u"): six waves per workgroup -- four dynamics waves, ONE cost wave, one control
-// wave -- compiled for THREE waves per SIMD (<= 168 VGPRs), so that two workgroups share a CU: two dynamics waves
-// and one rider per SIMD.  For 64-wide nets beyond one group per SIMD (K > 16384): the eight-wave form needs 172
-// VGPRs = two waves per SIMD = ONE workgroup per CU, and a second round of workgroups simply doubles the time
-// (K=32768, T=150, 6-64-64-4: 0.547 ms = 2 x 0.272).
+// SPLIT_: the pose and fetch riders of the ND = 4 form (eight waves per workgroup); ND = 2 runs one cost wave.  (Round 3's
+// six-wave ND = 4 form, "multi4u", never won a bucket of the selection table and was removed in round 5.)
 template <int H, int NHID, int ND, bool SPLIT_ = (ND == 4), bool TREE = false>
 __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLIT_) ? 3 : 1) void rollout_multi_kernel(const RolloutArgs a)
 {
@@ -520,10 +517,8 @@ template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
   if (nd == 44) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, true, true>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);  // tree output layer
-  else if (nd == 40) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, false>), dim3(a.K / 64), dim3(6 * 64), 0, stream, a);
   else if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
   else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);
-  else if (nd == 1) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 1>), dim3(a.K / 16), dim3(3 * 64), 0, stream, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -537,7 +532,8 @@ bool multi_variant_supported(int hidden, int n_hidden)
 
 hipError_t launch_rollout_multi(int hidden, int n_hidden, const RolloutArgs &a, int nd, hipStream_t stream)
 {
-  if (a.K % (16 * (nd >= 40 ? 4 : nd)) != 0) return hipErrorInvalidValue;  // nd = 40: ND = 4, six-wave form; 44: ND = 4, tree output layer
+  if (nd != 2 && nd != 4 && nd != 44) return hipErrorInvalidValue;  // 44: ND = 4 with the tree output layer
+  if (a.K % (16 * (nd == 44 ? 4 : nd)) != 0) return hipErrorInvalidValue;
   if (hidden == 32 && n_hidden == 2) return launch_multi_t<32, 2>(a, nd, stream);
   if (hidden == 64 && n_hidden == 2) return launch_multi_t<64, 2>(a, nd, stream);
   if (hidden == 32 && n_hidden == 4) return launch_multi_t<32, 4>(a, nd, stream);

@@ -350,8 +350,8 @@ static hipError_t launch_row64(const RolloutArgs &a, hipStream_t stream)
 hipError_t launch_rollout_row64(int hidden, int n_hidden, const RolloutArgs &a, int r, hipStream_t stream)
 {
   if (!row64_variant_supported(hidden, n_hidden) || (r != 8 && r != 16) || a.K % r != 0) return hipErrorInvalidValue;
-  if (n_hidden == 2) return r == 8 ? launch_row64<2, 8>(a, stream) : launch_row64<2, 16>(a, stream);
-  return r == 8 ? launch_row64<4, 8>(a, stream) : launch_row64<4, 16>(a, stream);
+  if (r != 16) return hipErrorInvalidValue;  // (round 4 also built groups of 8 rollouts: never faster than the oct / m44 forms, removed)
+  return n_hidden == 2 ? launch_row64<2, 16>(a, stream) : launch_row64<4, 16>(a, stream);
 }
 
 }  // namespace mppi

@@ -34,7 +34,10 @@ extern "C" {
 /* 3: + mppi_set_host_threads, mppi_compute_feedback_gains_pair. */
 /* 4: + mppi_debug_capture_iterations, mppi_debug_get_iterations, mppi_set_wait_timeout, mppi_debug_form_candidates; variants
  *    "row_tree", "row_exact", "row64[_r8|_r16]", "m44"; names "valu_row8w_tree_*", "valu_row64_r*_tree_*", "mfma4x4x1_*_m44_split_tree" (automatic), "mfma4x4x1_*_m44_tree" ("m44_chain"). */
-#define MPPI_ABI_VERSION 4
+/* 5: solves of more than 8192 rollouts run a one-launch tail (in-launch hand-overs with a deadline: fault roles 32-34 of
+ *    mppi_debug_inject_handover_fault); after a wait timeout the lost solve is not waited for again (mppi_set_wait_timeout);
+ *    "mfma" / "valu" / "valu_lds" drop a form forced by name; variants "multi1", "multi4u[_gen]", "row64_r8" removed. */
+#define MPPI_ABI_VERSION 5
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
 #define MPPI_MAX_LAYERS 8
@@ -249,23 +252,30 @@ int mppi_debug_cost_raster(mppi_handle *h, float x, float y, float heading, int 
 int mppi_enable_stage_timing(mppi_handle *h, int on);
 int mppi_reset_stage_times(mppi_handle *h);
 int mppi_get_stage_times(mppi_handle *h, mppi_stage_times *out);
-/* Name of the rollout kernel form in use.  Forms that keep the reference's k-ascending sums in EVERY layer (bit-identical to
- * one another): "mfma16x16x4_h<H>_l<N>_quad4w" | "_oct8w[_gen]" | "_multi{1,2,4}[_gen]" | "_multi4u[_gen]" | "_fused_b256" |
- * "_fused_b64", "valu_row8w_h32_l2" (row form, exact output chain), "valu_reg_lds", "valu_lds",
- * "basis_funcs25_valu[_2w|_3w]".  Forms whose OUTPUT layer is summed as a butterfly over lanes (hidden layers unchanged; inside
- * the 1e-4 tolerance on the controls, not bit-identical to the former): "valu_row8w_tree_h32_l2" (6-32-32-4 up to 8192
- * rollouts: the automatic choice), "mfma4x4x1_h64_l<N>_m44_split_tree" (64-wide nets up to 8192 rollouts: automatic; its 64-input
- * HIDDEN layers are summed as two chains, even and odd k; "mfma4x4x1_h64_l<N>_m44_tree" = variant "m44_chain": one chain),
- * "mfma16x16x4_h<H>_l<N>_multi4_tree[_gen]" (beyond: automatic), "valu_row64_r{8,16}_tree_h64_l<N>" (opt-in). */
+/* Name of the rollout kernel form in use, and mppi_set_rollout_variant's names for forcing one.  What is LOAD-BEARING:
+ *
+ *   automatic choice (csrc/abi_forms.hip: kFormRules, by model shape and 16-rollout groups per CU)
+ *     "row_tree"         valu_row8w_tree_h32_l2             6-32-32-4, K <= 8192: the headline form (vector ALU; output layer a butterfly)
+ *     "m44"              mfma4x4x1_h64_l<N>_m44_split_tree  64-wide nets, K <= 8192 (hidden layers as two chains, output a butterfly)
+ *     "quad"             mfma16x16x4_h<H>_l<N>_quad4w       other shapes up to one group per CU (e.g. 6-32x4-4), and under "mfma"
+ *     "multi2"           ..._multi2                         up to two groups per CU
+ *     "multi4_tree_gen"  ..._multi4_tree_gen                beyond (BASELINE config 4; eps from the stand-alone generator kernel)
+ *     "fused"            ..._fused_b256                     shapes without a multi form beyond two groups per CU (6-64x4-4, K > 8192)
+ *     (generic)          valu_lds                           any other layer list: the only form for non-uniform nets
+ *     basis functions    basis_funcs25_valu[_2w|_3w]        "fused" | "quad" | "bf3"
+ *   the reference's summation order in EVERY layer (bit-identical to one another; "mfma" = the table restricted to them)
+ *     "row_exact" (= "row") valu_row8w_h32_l2, "m44_chain" mfma4x4x1_*_m44_tree (hidden layers one chain; output a butterfly),
+ *     "oct[_gen]" ..._oct8w, "quad", "multi2[_gen]", "multi4[_gen]", "fused" = "block256" | "block64" ..._fused_b256 / _b64
+ *   A/B arms and cross-checks (never chosen automatically)
+ *     "valu" valu_reg_lds (lane = rollout, the independent implementation every parity test also runs; config 4's untuned
+ *     vector-ALU reference), "valu_lds" (the generic kernel on a standard shape), "row64" = "row64_r16"
+ *     valu_row64_r16_tree_h64_l<N> (config 4's hand-scheduled vector-ALU arm), "multi4_tree" (in-kernel generator)
+ *   "auto" restores the table.  "mfma", "valu", "valu_lds" also drop a form forced by name earlier.
+ * The re-associated forms ("_tree", "_split") do NOT compute the reference's summation order: inside the 1e-4 tolerance on
+ * the controls (profiles/r05_b_nominal_margin_*.txt), not bit-identical to the exact ones.  Removed in ABI 5 (no table row chose
+ * them, no A/B needed them): "multi1", "multi4u[_gen]", "row64_r8".  MPPI_ERR_UNSUPPORTED if the handle's model has no such
+ * form; a form name given to a handle whose model runs on the generic vector kernel is accepted and ignored. */
 const char *mppi_rollout_variant(const mppi_handle *h);
-/* Force a form (A/B of SURVEY cfg 4 and of the kernel forms): "auto" (the selection table of csrc/abi_forms.hip);
- * "mfma" (the table restricted to forms that keep the reference's summation order in every layer) | "valu" | "valu_lds" (the
- * throughput-style vector kernels); by name: "row" = "row_exact" | "row_tree" (6-32-32-4 on the vector ALU), "m44" | "m44_chain" (64-wide
- * nets on v_mfma_f32_4x4x1; hidden layers as two accumulation chains | one, the reference's order), "row64" | "row64_r8" | "row64_r16" (64-wide nets on the vector ALU, weights from LDS), "quad",
- * "oct" | "oct_gen", "multi4" | "multi2" | "multi1" ("_gen" appended: eps from the stand-alone generator kernel),
- * "multi4_tree[_gen]", "multi4u[_gen]", "fused" = "block256" | "block64".  Basis-function model: "bf3" (dynamics + cost +
- * control wavefront per 64 rollouts) | "quad" (dynamics + cost) | "fused" (one).  MPPI_ERR_UNSUPPORTED if the handle's model
- * has no such form; a form name given to a handle whose model runs on the generic vector kernel is accepted and ignored. */
 int mppi_set_rollout_variant(mppi_handle *h, const char *name);
 
 /* Test hook (not part of the drop-in surface): d/dt of n independent (state[7], control[2])

@@ -31,7 +31,7 @@ def test_header_symbols_exported(L):
 
 
 def test_version_and_strerror(L):
-    assert L.mppi_abi_version() == 4  # include/mppi_hip.h: MPPI_ABI_VERSION
+    assert L.mppi_abi_version() == 5  # include/mppi_hip.h: MPPI_ABI_VERSION
     assert L.mppi_strerror(0) == b"ok"
     assert b"gfx950" in L.mppi_strerror(capi.ERR_NO_DEVICE)
 

@@ -217,7 +217,7 @@ def test_baseline_config4_full_size_parity():
         assert abs(got["traj_cost"] - ref["traj_cost"]) <= 1e-4 * abs(ref["traj_cost"]), what
 
     outs = {}
-    for variant in ("auto", "multi4_gen", "quad", "fused", "multi4", "multi4u_gen"):
+    for variant in ("auto", "multi4_gen", "quad", "fused", "multi4"):
         sol = capi.Solver(cfg)
         sol.set_rollout_variant(variant)
         sol.set_control_seq(U0)
@@ -248,7 +248,7 @@ def test_baseline_config4_full_size_parity():
     check(a, ref, "explicit noise")
     # non-degenerate: most rollouts stay on the track and the weights are spread
     assert float(np.mean(ref["costs"] < 5000.0)) > 0.5 and float(ref["w"].sum()) > 4.0
-    for v in ("quad", "fused", "multi4", "multi4u_gen"):
+    for v in ("quad", "fused", "multi4"):
         np.testing.assert_array_equal(a["costs"].view(np.uint32), outs[v]["costs"].view(np.uint32))
         np.testing.assert_array_equal(a["V"].view(np.uint32), outs[v]["V"].view(np.uint32))
         np.testing.assert_array_equal(a["U"].view(np.uint32), outs[v]["U"].view(np.uint32))
@@ -332,7 +332,6 @@ def test_control_ticks_equals_the_call_by_call_loop():
                                          ("row", 1), ("row", 2), ("row", 3), ("row", 4), ("row", 5), ("row", 6), ("row", 7), ("row", 8), ("row_tree", 1), ("row_tree", 4), ("row_tree", 6), ("bf", 1), ("bf", 2), ("bf", 3), ("bf2", 1), ("bf2", 2),
                                          ("multi4", 1), ("multi4", 4), ("multi4", 5), ("multi4", 6), ("multi4", 7), ("multi4", 8),
                                          ("multi2", 2), ("multi2", 3), ("multi2", 4),
-                                         ("multi4u", 3), ("multi4u", 5), ("multi4u", 6),
                                          ("oct", 1), ("oct", 2), ("oct", 3), ("oct", 4), ("oct", 5), ("oct", 6), ("oct", 7),
                                          ("oct", 8)])
 def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, family, wave):
@@ -410,7 +409,8 @@ def test_wait_timeout_is_kept_and_the_lost_solve_is_not_waited_for_again():
             sol.compute_control(cfg["start_state"])
             break
         except capi.MppiError as e3:
-            assert e3.status == capi.ERR_HIP and "timed out" in str(e3) and time.perf_counter() < deadline
+            assert e3.status == capi.ERR_HIP and "timed out" in str(e3), str(e3)
+            assert time.perf_counter() < deadline, "the lost solve's device work never drained"
             time.sleep(0.001)
     got = sol.get_results(with_vectors=False)
     np.testing.assert_array_equal(got["U"].view(np.uint32), want["U"].view(np.uint32))

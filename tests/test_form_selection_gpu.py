@@ -1,7 +1,10 @@
-"""The selection table of autorally_amd/csrc/abi_forms.hip against the clock: for every bucket (model shape x rollouts per CU)
-the candidates the table knows are timed for a few dozen launches each (the rollout kernel's own dispatch time, HIP events), and
-the automatic choice must be within 10 % of the best of them.  The table's rows cite the profiles they came from; this test
-is what notices when a kernel change moves a crossover."""
+"""The selection table of autorally_amd/csrc/abi_forms.hip.
+(a) By name, in every -m gpu run: "auto" resolves to the form the table's row for the bucket names -- no clock involved.
+(b) Against the clock, only with -m timing (tools/form_selection.sh; a wall-clock assertion does not belong in a correctness
+    run on a shared pool box): for every bucket (model shape x rollouts per CU) the candidates the table knows are timed for a
+    few dozen launches each (the rollout kernel's own dispatch time, HIP events), and the automatic choice must be within 10 %
+    of the best of them.  The table's rows cite the profiles they came from; (b) is what notices when a kernel change moves a
+    crossover."""
 import os
 
 import numpy as np
@@ -13,12 +16,42 @@ from autorally_amd import synthetic as S
 
 pytestmark = pytest.mark.gpu
 
-BUCKETS = [  # (layers or model file, K, T)
-    (None, 1920, 100), (None, 4096, 100), (None, 8192, 100), (None, 16384, 100),
-    ([6, 64, 64, 4], 4096, 100), ([6, 64, 64, 4], 8192, 100), ([6, 64, 64, 4], 16384, 100),
-    ("wider_deeper_network_08_20_2020", 1920, 100), ("wider_deeper_network_08_20_2020", 8192, 60),
-    ([6, 32, 32, 32, 32, 4], 4096, 100),
+BUCKETS = [  # (layers or model file, K, T, what "auto" must resolve to: a piece of the variant name)
+    (None, 1920, 100, "row8w_tree"), (None, 4096, 100, "row8w_tree"), (None, 8192, 100, "row8w_tree"), (None, 16384, 100, "multi4_tree_gen"),
+    ([6, 64, 64, 4], 4096, 100, "m44_split"), ([6, 64, 64, 4], 8192, 100, "m44_split"), ([6, 64, 64, 4], 16384, 100, "multi4_tree_gen"),
+    ("wider_deeper_network_08_20_2020", 1920, 100, "m44_split"), ("wider_deeper_network_08_20_2020", 8192, 60, "m44_split"),
+    ("wider_deeper_network_08_20_2020", 16384, 60, "fused_b256"),
+    ([6, 32, 32, 32, 32, 4], 4096, 100, "quad4w"), ([6, 32, 32, 32, 32, 4], 8192, 100, "multi2"),
 ]
+
+
+def _cfg(golden_dir, model, K, T):
+    if isinstance(model, str):
+        layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", model + ".npz"))
+        return S.make_config(K, T, layers=layers, theta=theta, track="oval", negate_yaw_der=False)
+    if model is None:
+        return S.make_config(K, T, track="oval")
+    layers, theta = P.synthetic_model(model, seed=4)
+    return S.make_config(K, T, layers=layers, theta=theta, track="oval")
+
+
+@pytest.mark.parametrize("model,K,T,want", BUCKETS)
+def test_auto_resolves_to_the_row_of_the_selection_table(golden_dir, model, K, T, want):
+    """No clock: the name of the automatic form per bucket, "mfma" gives a form in the reference's order whatever was forced
+    before (set("row_tree") then set("mfma") kept the tree form), and "auto" comes back."""
+    sol = capi.Solver(_cfg(golden_dir, model, K, T))
+    assert want in sol.rollout_variant(), (sol.rollout_variant(), want)
+    for forced in sol.form_candidates():
+        try:
+            sol.set_rollout_variant(forced)
+        except capi.MppiError:
+            continue
+        sol.set_rollout_variant("mfma")
+        name = sol.rollout_variant()
+        assert "_tree" not in name and "m44_split" not in name and name.startswith(("mfma16x16x4", "valu_row8w_h")), (forced, name)
+    sol.set_rollout_variant("auto")
+    assert want in sol.rollout_variant()
+    sol.close()
 
 
 def _rollout_us(cfg, variant, n=40):
@@ -42,16 +75,10 @@ def _rollout_us(cfg, variant, n=40):
     return min(best), name
 
 
-@pytest.mark.parametrize("model,K,T", BUCKETS)
-def test_automatic_form_is_within_ten_percent_of_the_best_candidate(golden_dir, model, K, T):
-    if isinstance(model, str):
-        layers, theta = P.load_model_npz(os.path.join(golden_dir, "models", model + ".npz"))
-        cfg = S.make_config(K, T, layers=layers, theta=theta, track="oval", negate_yaw_der=False)
-    elif model is None:
-        cfg = S.make_config(K, T, track="oval")
-    else:
-        layers, theta = P.synthetic_model(model, seed=4)
-        cfg = S.make_config(K, T, layers=layers, theta=theta, track="oval")
+@pytest.mark.timing
+@pytest.mark.parametrize("model,K,T,want", BUCKETS)
+def test_automatic_form_is_within_ten_percent_of_the_best_candidate(golden_dir, model, K, T, want):
+    cfg = _cfg(golden_dir, model, K, T)
     probe = capi.Solver(cfg)
     cands = probe.form_candidates()
     probe.close()

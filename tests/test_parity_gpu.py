@@ -218,7 +218,7 @@ def test_quad_and_fused_mfma_kernels_agree_bitwise(K, T, track, layers):
         np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))
         np.testing.assert_array_equal(a["V"].view(np.uint32), m["V"].view(np.uint32))
         np.testing.assert_array_equal(a["U"].view(np.uint32), m["U"].view(np.uint32))
-    for v in ("multi4", "multi2", "multi1", "multi4u", "multi4u_gen"):
+    for v in ("multi4", "multi2", "multi4_gen"):
         _, m = _solve_both(cfg, U0=U0, variant=v)
         assert v in m["variant"]
         np.testing.assert_array_equal(a["costs"].view(np.uint32), m["costs"].view(np.uint32))
@@ -507,7 +507,7 @@ def test_horizon_edge_cases(golden_dir, T, family):
     extra = {}
     if family == "bf":
         extra["bf_W"] = P.load_bf_npz(os.path.join(golden_dir, "models", "basis_function_09_12_2018.npz"))
-    variants = ["row", "quad", "fused", "multi4", "multi1", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
+    variants = ["row", "quad", "fused", "multi4", "multi2", "valu", "valu_lds"] if family == "nn" else ["auto", "fused"]
     for K in (64, 192):
         cfg = S.make_config(K, T, track="oval", **extra)
         U0 = warm_U(cfg)

@@ -51,7 +51,7 @@ def _gpu(cfg, U0, eps, variant):
     return got
 
 
-CASES = [("h64", 64, 7, "row64_r8"), ("h64", 256, 40, "row64_r8"), ("h64", 256, 40, "row64_r16"), ("h64", 4096, 100, "row64"),
+CASES = [("h64", 64, 7, "row64"), ("h64", 256, 40, "row64_r16"), ("h64", 4096, 100, "row64"),
          ("h64", 2048, 100, "row64"), ("wd", 1920, 100, "row64"), ("wd", 192, 37, "row64_r16"), ("wd", 4096, 60, "row64"),
          ("h64", 16384, 150, "row64_r16")]  # BASELINE config 4 at full size: the tuned vector-ALU arm of its MFMA-vs-VALU A/B
 
@@ -63,7 +63,7 @@ def test_row64_form_against_its_mode_and_the_nominal_oracle(golden_dir, model, K
     eps = noise_for(cfg, 1234)
     hist = np.zeros(4, np.float32)
     got = _gpu(cfg, U0, eps, variant)
-    assert "row64_r" in got["variant"] and ("_r8_" in got["variant"]) == (variant == "row64_r8" or (variant == "row64" and K <= 2048))
+    assert "row64_r16" in got["variant"]
     exact = _gpu(cfg, U0, eps, "oct")
     ref2 = O.Oracle(cfg, fma_mode=2, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps)
     ref1 = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps)
@@ -90,15 +90,11 @@ def test_row64_form_against_its_mode_and_the_nominal_oracle(golden_dir, model, K
     assert abs(tc - got["traj_cost"]) <= 1e-5 * abs(tc)
 
 
-@pytest.mark.parametrize("model,variant", [("h64", "row64_r8"), ("wd", "row64_r16")])
-def test_row64_generator_mode_equals_explicit_noise_and_both_group_sizes_agree(golden_dir, model, variant):
+@pytest.mark.parametrize("model,variant", [("h64", "row64"), ("wd", "row64_r16")])
+def test_row64_generator_mode_equals_explicit_noise(golden_dir, model, variant):
     cfg = _cfg(golden_dir, model, 512, 33)
     U0 = warm_U(cfg)
     eps = noise_for(cfg, 1234)
-    one = _gpu(cfg, U0, eps, variant)
-    other = _gpu(cfg, U0, eps, "row64_r16" if variant.endswith("8") else "row64_r8")
-    for key in ("costs", "U", "V"):  # 8 or 16 rollouts per group: the same arithmetic
-        np.testing.assert_array_equal(one[key].view(np.uint32), other[key].view(np.uint32), err_msg=key)
     sol = capi.Solver(cfg)
     sol.set_rollout_variant(variant)
     sol.set_control_seq(U0)
@@ -125,8 +121,7 @@ def test_row64_generator_mode_equals_explicit_noise_and_both_group_sizes_agree(g
         s_.close()
 
 
-@pytest.mark.parametrize("variant,wave", [("row64_r8", 1), ("row64_r8", 4), ("row64_r8", 5), ("row64_r8", 6), ("row64_r8", 7), ("row64_r8", 8),
-                                          ("row64_r16", 2), ("row64_r16", 8), ("row64_r16", 9), ("row64_r16", 10), ("row64_r16", 11), ("row64_r16", 12)])
+@pytest.mark.parametrize("variant,wave", [("row64_r16", 1), ("row64_r16", 2), ("row64_r16", 8), ("row64_r16", 9), ("row64_r16", 10), ("row64_r16", 11), ("row64_r16", 12)])
 def test_row64_starved_wave_fails_the_solve_loudly(golden_dir, variant, wave):
     """Roles: 1 .. R/2 dynamics waves, then pose, cost, control, noise wave (mppi_debug_inject_handover_fault)."""
     cfg = _cfg(golden_dir, "h64", 256, 40)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/multi_stamps.py <lib built with -DMPPI_STAMPS> [--layers ..] [--variant multi1] [--K 4096]: phases of one
+"""tools/multi_stamps.py <lib built with -DMPPI_STAMPS> [--layers ..] [--variant multi2] [--K 4096]: phases of one
 step of dynamics wave 0 of the multi rollout kernel (s_memtime, workgroup 0, averaged over steps 16..T-2 of the
 last solve).  Diagnostic build only: every stamp is an s_memtime + s_waitcnt lgkmcnt(0)."""
 import ctypes as C, json, os, sys
@@ -15,7 +15,7 @@ def opt(name, default):
 
 
 layers = [int(x) for x in opt("--layers", "6-32-32-4").split("-")]
-K, T, variant = int(opt("--K", "4096")), int(opt("--T", "100")), opt("--variant", "multi1")
+K, T, variant = int(opt("--K", "4096")), int(opt("--T", "100")), opt("--variant", "multi2")
 kw = {}
 if layers != [6, 32, 32, 4]:
     l, th = P.synthetic_model(layers, seed=4)

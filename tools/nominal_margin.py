@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""tools/nominal_margin.py <model: nn32 | wd> <draws> [first seed]  |  merge <raw json ...>: what re-association costs at the contract's 1e-4 mark.
+
+Whole solves at the LAUNCH DEFAULTS only (path_integral_nn.launch: gamma 0.15, nu (0.275, 0.3), the cost coefficients, T = 100,
+num_iters 1, opt_stride 1) with the shipped weights -- nn32 = autorally_nnet_09_12_2018 (6-32-32-4), wd =
+wider_deeper_network_08_20_2020 (6-64-64-64-64-4, negate_yaw_der = false) -- K alternating between 1920 (the reference's
+build) and 4096 (BASELINE configs[2]), on the oval track map, from random poses ON the track (a point of the centre line, a
+lateral offset, a heading error, a speed of 3-8 m/s) with the WARM sequence a controller standing there holds (the result of
+a first solve at that pose, slid by one step).  Every kernel form that serves the shape solves the SAME draw (device
+generator, same seed): the forms that keep the reference's summation order and the re-associated ("tree" / "split") ones, each
+against the NOMINAL oracle (fma_mode 1) computed once per draw.  Per form: the histogram of |dU|inf over the smoothed T x 2
+sequence and of the relative trajectory-cost error, the fraction of draws beyond 1e-4, and for those the threshold-flipped
+rollouts (cost differs by more than 1e-4 relative: a texel / crash / slip threshold crossed on an ulp) and their weight mass.
+Prints a summary and writes gpurun_out/nominal_margin_<model>.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from autorally_amd import capi, params as P, synthetic as S  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+def summarize(paths):
+    """Summary over one or several raw files of the same model (chunks of a sweep run in several gpurun calls)."""
+    raws = [json.load(open(p)) for p in paths]
+    model, layers, names = raws[0]["model"], raws[0]["layers"], raws[0]["names"]
+    assert all(r["model"] == model for r in raws)
+    FORMS = list(raws[0]["rec"].keys())
+    rec = {f: {k: sum((r["rec"][f][k] for r in raws), []) for k in raws[0]["rec"][f]} for f in FORMS}
+    n_draws = len(rec[FORMS[0]]["dU"])
+    KS = sorted(set(rec[FORMS[0]]["K"]))
+    T = 100
+    EDGES = [0.0, 1e-5, 2.5e-5, 5e-5, 7.5e-5, 1e-4, 1.5e-4, 2e-4, 5e-4, float("inf")]
+    out = {"model": model, "layers": list(layers), "draws": n_draws, "first_seeds": [r["first_seed"] for r in raws], "K": list(KS), "T": T,
+           "settings": "launch defaults (gamma 0.15, nu (0.275, 0.3), path_integral_nn.launch cost coefficients), shipped weights, "
+                       "oval track map, random poses on the track, warm control sequence, device generator",
+           "oracle": "nominal (fma_mode 1), native -O3 build (bit-identical to the portable build: bench.py checks)",
+           "hist_edges": EDGES[:-1] + ["inf"], "forms": {}}
+    print("model %s (%s), %d draws (K alternating %s), T=%d, against the NOMINAL oracle" % (model, "-".join(map(str, layers)), n_draws, KS, T))
+    for f in FORMS:
+        d = {k: np.asarray(v) for k, v in rec[f].items()}
+        beyond = d["dU"] > 1e-4
+        hU = np.histogram(d["dU"], bins=EDGES)[0]
+        hT = np.histogram(d["dtraj"], bins=EDGES)[0]
+        clean = beyond & (d["flipped"] == 0)
+        out["forms"][f] = {
+            "variant": names[f], "hist_dU": hU.tolist(), "hist_dtraj": hT.tolist(),
+            "max_dU": float(d["dU"].max()), "median_dU": float(np.median(d["dU"])), "p99_dU": float(np.percentile(d["dU"], 99)),
+            "max_dtraj": float(d["dtraj"].max()), "frac_dU_beyond_1e-4": float(beyond.mean()),
+            "frac_dtraj_beyond_1e-4": float((d["dtraj"] > 1e-4).mean()),
+            "beyond_1e-4": {"n": int(beyond.sum()), "with_threshold_flipped_rollouts": int((beyond & (d["flipped"] > 0)).sum()),
+                            "without_any_flipped_rollout": int(clean.sum()),
+                            "max_dU_without_flipped": float(d["dU"][clean].max()) if clean.any() else 0.0,
+                            "seeds_without_flipped": d["seed"][clean][:20].tolist()},
+            "by_K": {str(K): {"n": int((d["K"] == K).sum()), "frac_dU_beyond_1e-4": float(beyond[d["K"] == K].mean()),
+                              "max_dU": float(d["dU"][d["K"] == K].max())} for K in KS},
+        }
+        o = out["forms"][f]
+        print("%-10s %-36s |dU|: median %.2e p99 %.2e max %.2e, beyond 1e-4: %d of %d = %.3f %% (%d with threshold-flipped rollouts, "
+              "%d without: max %.2e) | traj cost rel: max %.2e, beyond 1e-4: %.3f %%" % (
+                  f, names[f], o["median_dU"], o["p99_dU"], o["max_dU"], o["beyond_1e-4"]["n"], n_draws, 100 * o["frac_dU_beyond_1e-4"],
+                  o["beyond_1e-4"]["with_threshold_flipped_rollouts"], o["beyond_1e-4"]["without_any_flipped_rollout"],
+                  o["beyond_1e-4"]["max_dU_without_flipped"], o["max_dtraj"], 100 * o["frac_dtraj_beyond_1e-4"]))
+        print("           histogram of |dU| over %s: %s" % (EDGES, hU.tolist()))
+    with open(os.path.join(ROOT, "gpurun_out", "nominal_margin_%s.json" % model), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
+if sys.argv[1] == "merge":
+    summarize(sys.argv[2:])
+    sys.exit(0)
+
+model = sys.argv[1]
+n_draws = int(sys.argv[2])
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 500000
+assert model in ("nn32", "wd")
+gd = os.path.join(ROOT, "tests", "golden", "models")
+if model == "nn32":
+    layers, theta = P.load_model_npz(os.path.join(gd, "autorally_nnet_09_12_2018.npz"))
+    over = {}
+    FORMS = ["row_exact", "row_tree"]  # "auto" = row_tree
+else:
+    layers, theta = P.load_model_npz(os.path.join(gd, "wider_deeper_network_08_20_2020.npz"))
+    over = {"negate_yaw_der": False}   # params/models/README.md:20
+    FORMS = ["oct", "m44_chain", "m44"]  # "auto" = m44 (two chains per hidden layer)
+T = 100
+KS = (1920, 4096)
+STRAIGHT, RADIUS = 12.0, 10.0  # synthetic.oval_track_map
+
+
+def pose_on_track(r):
+    """A point of the stadium's centre line (counter-clockwise, the direction of BASELINE configs[2]'s start state), then a
+    lateral offset, a heading error, a speed."""
+    per = 4 * STRAIGHT + 2 * np.pi * RADIUS
+    s = r.uniform(0.0, per)
+    if s < 2 * STRAIGHT:
+        x, y, psi = -STRAIGHT + s, -RADIUS, 0.0
+    elif s < 2 * STRAIGHT + np.pi * RADIUS:
+        a = -np.pi / 2 + (s - 2 * STRAIGHT) / RADIUS
+        x, y, psi = STRAIGHT + RADIUS * np.cos(a), RADIUS * np.sin(a), a + np.pi / 2
+    elif s < 4 * STRAIGHT + np.pi * RADIUS:
+        x, y, psi = STRAIGHT - (s - 2 * STRAIGHT - np.pi * RADIUS), RADIUS, np.pi
+    else:
+        a = np.pi / 2 + (s - 4 * STRAIGHT - np.pi * RADIUS) / RADIUS
+        x, y, psi = -STRAIGHT + RADIUS * np.cos(a), RADIUS * np.sin(a), a + np.pi / 2
+    lat = r.normal(0.0, 0.6)
+    x, y = x - lat * np.sin(psi), y + lat * np.cos(psi)
+    psi = psi + r.normal(0.0, 0.12)
+    psi = (psi + np.pi) % (2 * np.pi) - np.pi
+    return np.array([x, y, psi, r.normal(0.0, 0.02), r.uniform(3.0, 8.0), r.normal(0.0, 0.3), r.normal(0.0, 0.25)], np.float32)
+
+
+cfgs = {K: S.make_config(K, T, layers=layers, theta=theta, track="oval", **over) for K in KS}
+sols = {(K, f): capi.Solver(cfgs[K]) for K in KS for f in FORMS}
+names = {}
+for (K, f), sol in sols.items():
+    sol.set_rollout_variant(f)
+    names[f] = sol.rollout_variant()
+orcs = {K: O.Oracle(cfgs[K], fma_mode=1, nthreads=min(16, len(os.sched_getaffinity(0))), native=True) for K in KS}
+rec = {f: {"dU": [], "dtraj": [], "flipped": [], "mass": [], "K": [], "seed": []} for f in FORMS}
+t_start = time.time()
+for i in range(n_draws):
+    seed = first + i
+    r = np.random.RandomState(seed)
+    K = KS[i % 2]
+    state = pose_on_track(r)
+    # the warm sequence: a first solve at this pose on the first (exact) form, slid by one step
+    w = sols[(K, FORMS[0])]
+    w.reset_controls()
+    w.set_control_hist(np.zeros(4, np.float32))
+    w.seed(2 * seed + 1, 0)
+    w.compute_control(state)
+    w.slide_control_seq(1)
+    U0, hist = w.get_control_seq().copy(), w.get_control_hist().copy()
+    eps = O.generate_noise(2 * seed, 0, K, T)[None]
+    ref = orcs[K].compute_control(state, U0, hist, eps)
+    wn = ref["w"] / np.sum(ref["w"], dtype=np.float64)
+    for f in FORMS:
+        sol = sols[(K, f)]
+        sol.set_control_seq(U0)
+        sol.set_control_hist(hist)
+        sol.seed(2 * seed, 0)
+        sol.compute_control(state)
+        got = sol.get_results()
+        dJ = np.abs(got["costs"] - ref["costs"]) / np.maximum(1.0, np.abs(ref["costs"]))
+        fl = dJ > 1e-4
+        rec[f]["dU"].append(float(np.max(np.abs(got["U"] - ref["U"]))))
+        rec[f]["dtraj"].append(float(abs(got["traj_cost"] - ref["traj_cost"]) / abs(ref["traj_cost"])))
+        rec[f]["flipped"].append(int(np.count_nonzero(fl)))
+        rec[f]["mass"].append(float(np.sum(wn[fl])))
+        rec[f]["K"].append(K)
+        rec[f]["seed"].append(seed)
+    if (i + 1) % 250 == 0:
+        print("# %d draws, %.0f s" % (i + 1, time.time() - t_start), file=sys.stderr, flush=True)
+
+raw = {"model": model, "layers": list(layers), "first_seed": first, "draws": n_draws, "names": names,
+       "rec": rec}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+raw_path = os.path.join(ROOT, "gpurun_out", "nominal_margin_%s_%d.json" % (model, first))
+with open(raw_path, "w") as fh:
+    json.dump(raw, fh)
+for sol in sols.values():
+    sol.close()
+summarize([raw_path])
