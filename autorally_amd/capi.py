@@ -64,6 +64,7 @@ SYMBOLS = [
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
     "mppi_debug_inject_handover_fault", "mppi_compute_feedback_gains_pair", "mppi_set_host_threads",
     "mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout", "mppi_debug_form_candidates",
+    "mppi_debug_set_chained_ticks",
 ]
 
 ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
@@ -71,6 +72,7 @@ ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi
                 "mppi_nominal_traj_pair")
 ABI3_SYMBOLS = ("mppi_compute_feedback_gains_pair", "mppi_set_host_threads")
 ABI4_SYMBOLS = ("mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout", "mppi_debug_form_candidates")
+ABI5_SYMBOLS = ("mppi_debug_set_chained_ticks",)
 
 _lib = None
 
@@ -155,8 +157,12 @@ def lib():
             L.mppi_debug_get_iterations.argtypes = [hp, fp, fp, fp]
             L.mppi_set_wait_timeout.argtypes = [hp, C.c_double]
             L.mppi_debug_form_candidates.argtypes = [hp, C.POINTER(C.c_char_p), C.c_int]
+        v5 = L.mppi_abi_version() >= 5
+        if v5:
+            L.mppi_debug_set_chained_ticks.argtypes = [hp, C.c_int]
         for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
-            if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS) and (v4 or s not in ABI4_SYMBOLS):
+            if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS) and (v4 or s not in ABI4_SYMBOLS) and \
+                    (v5 or s not in ABI5_SYMBOLS):
                 getattr(L, s)
         _lib = L
     return _lib
@@ -324,6 +330,9 @@ class Solver:
     def control_ticks(self, state, n_ticks, stride=1):
         """n_ticks x (compute_control + slide_control_seq(stride)) inside one library call."""
         self._ck(self.L.mppi_control_ticks(self.h, _fp(_f32(state, (7,))), int(n_ticks), int(stride)))
+
+    def debug_set_chained_ticks(self, on):
+        self._ck(self.L.mppi_debug_set_chained_ticks(self.h, int(on)))
 
     def compute_control_async(self, state):
         self._ck(self.L.mppi_compute_control_async(self.h, _fp(_f32(state, (7,)))))

@@ -152,6 +152,13 @@ struct mppi_handle {
   float *d_cap = nullptr;
   bool capture = false, cap_valid = false, cap_explicit = false;
   double wait_timeout_s = 30.0;  // mppi_set_wait_timeout
+  // chained control ticks (mppi_control_ticks, abi_solve.hip): the gate block of the solve enqueued one tick ahead --
+  // kGateReplicas copies of [state[7], gate word], device memory the host stores into through the PCIe BAR where the
+  // platform allows it (gate_bar), else host-mapped memory; gate_cpu is the pointer the host writes, d_gate what the kernel reads
+  unsigned *gate_cpu = nullptr, *d_gate = nullptr;
+  bool gate_bar = false;
+  bool chain = true;   // mppi_debug_set_chained_ticks
+  bool ahead = false;  // a gated solve is enqueued behind the pending one
   bool timed_out = false;        // a wait ran out of time and that solve's device work may still run: recover_timed_out (abi_solve.hip)
   bool no_result = false;        // the last solve was lost (timeout): mppi_get_results refuses until a solve completes
   bool timing = false;

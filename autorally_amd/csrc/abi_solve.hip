@@ -75,6 +75,8 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.rng_in = nullptr;
   a.rng_out = nullptr;
   a.inline_noise = 0;
+  a.gate = nullptr;
+  a.gate_seq = 0;
   // roles 32-34 are waits of the streaming tail kernel (tail_launch): the rollout runs with its defaults
   a.spin_budget = h->fault_wave >= 32 ? 0 : h->spin_budget;
   a.fault_wave = h->fault_wave >= 32 ? 0 : h->fault_wave;
@@ -457,6 +459,111 @@ int enqueue_solve(mppi_handle *h, const float *state)
   return MPPI_OK;
 }
 
+// ---- chained control ticks -------------------------------------------------------------------------------------------------
+// mppi_control_ticks knows that solve i+1 follows solve i at once.  Its launches -- 2.8 us of launch call and 1.5 us of
+// dispatch for the rollout kernel alone, on the step's critical path between "result i on the host" and "first instruction of
+// rollout i+1" -- are therefore made one tick AHEAD, while the host would otherwise only poll for result i: rollout i+1 (the
+// gated form of the row kernel, rollout_row.hip) and tail i+1 go onto the handle's stream behind tail i, with the buffers
+// solve i+1 will own after the slide (U: the slid copy tail i leaves; its own slid copy: the buffer solve i read).  The
+// rollout starts as soon as tail i has ended, loads its weights, draws its first noise -- and waits for the host's gate: the
+// state of solve i+1 and its sequence number, written into the gate block AFTER the host has seen, smoothed and slid result
+// i.  The step keeps its meaning: solve i+1 computes nothing from the state before the host has result i in hand.
+// tools/ub/gate_ub.hip (profiles/r05_c_gate_ub.txt): 46.3 -> 43.0 us per step for stand-in kernels of the headline's length
+// with the gate in device memory written through the BAR, 44.5 with a host-mapped gate; two streams with the next rollout
+// resident beside the tail: 54 (the cross-stream events cost more than the launches they hide).
+// Results are bit for bit those of the unchained loop (tests/test_api_gpu.py).  Only for the case that gains: one handle, the
+// row form with its in-kernel generator, one iteration, no stage events, no capture, stride = optimization stride.
+static bool chain_ok(const mppi_handle *h, int n_ticks, int stride)
+{
+  return h->chain && n_ticks >= 2 && h->d_gate != nullptr && stride == h->cfg.optimization_stride && wants_slid_copy(h) &&
+         h->cfg.num_iters == 1 && !h->timing && !h->capture && h->explicit_iters == 0 && !h->prefetch_valid && !h->basis &&
+         h->fault_wave == 0 && h->have_nn && h->have_map && h->have_cost && !h->timed_out && form_is_row(form_of(h)) &&
+         has_noise_wave(h);
+}
+
+// the gate block: the state first, then (fenced) the gate word, in every replica
+static void write_gate(mppi_handle *h, const float *state, unsigned word)
+{
+  volatile unsigned *g = h->gate_cpu;
+  for (int r = 0; r < kGateReplicas; r++)
+    for (int i = 0; i < kStateDim; i++) {
+      unsigned u;
+      memcpy(&u, state + i, sizeof(u));
+      g[16 * r + i] = u;
+    }
+  __builtin_ia32_sfence();
+  for (int r = 0; r < kGateReplicas; r++) g[16 * r + 7] = word;
+  __builtin_ia32_sfence();
+}
+
+// solve (h->seq + 1), gated, behind the pending solve h->seq
+static int enqueue_ahead(mppi_handle *h, const float *state)
+{
+  float *noise = h->d_gen[h->gen_cur];  // the in-kernel generator's solves all leave their applied controls here
+  RolloutArgs a;
+  fill_rollout_args(h, state, noise, a);
+  a.U = h->d_in_buf[1 - h->in_cur];  // the slid copy the pending solve's tail kernel leaves: U of the next solve after the slide
+  a.inline_noise = 1;
+  a.rng_in = h->d_rng[h->rng_cur];
+  a.rng_out = h->d_rng[1 - h->rng_cur];
+  h->rng_cur = 1 - h->rng_cur;
+  a.gate = h->d_gate;
+  a.gate_seq = h->seq + 1;
+  int rc = launch_rollout(h, a);
+  if (rc) return rc;
+  TailLaunch l = tail_launch(h, noise, true);
+  l.U = h->d_in_buf[1 - h->in_cur];
+  l.hist = l.U + 2 * h->T;
+  l.slid = h->d_in_buf[h->in_cur];
+  l.seq = h->seq + 1;
+  HIPCHK(h, launch_solve_tail(l, h->stream));
+  h->ahead = true;
+  return MPPI_OK;
+}
+
+// the solve enqueued ahead is called off: its gate opens with the cancel bit (the kernels run through, poisoned); nothing on
+// the device can be trusted afterwards -- the host copies are uploaded again by the next solve
+static void cancel_ahead(mppi_handle *h, const float *state)
+{
+  write_gate(h, state, (h->seq + 1) | kGateCancel);
+  (void)hipStreamSynchronize(h->stream);
+  h->ahead = false;
+  h->u_dirty = true;
+  h->slid_valid = false;
+}
+
+static int control_ticks_chained(mppi_handle *h, const float *state, int n_ticks, int stride)
+{
+  HIPCHK(h, ensure_device(h->cfg.device));
+  int rc = enqueue_solve(h, state);
+  if (rc) return rc;
+  for (int i = 0; i < n_ticks; i++) {
+    const bool ahead = i + 1 < n_ticks;
+    if (ahead) {
+      rc = enqueue_ahead(h, state);
+      if (rc) {
+        (void)wait_pending(h);
+        return rc;
+      }
+    }
+    rc = wait_pending(h);
+    if (rc == MPPI_OK) rc = mppi_slide_control_seq(h, stride);
+    if (rc) {
+      if (ahead) cancel_ahead(h, state);
+      return rc;
+    }
+    if (ahead) {  // the host has result i: solve i+1 may read its state
+      h->seq++;
+      write_gate(h, state, h->seq);
+      h->ahead = false;
+      h->pending = true;
+      h->pending_timed = false;
+      h->slid_valid = true;  // chain_ok: the tail kernel leaves the slid copy
+    }
+  }
+  return MPPI_OK;
+}
+
 }  // namespace mppi_abi
 
 extern "C" {
@@ -647,6 +754,7 @@ int mppi_control_ticks_batch(mppi_handle *const *hs, const float *states, int n,
 int mppi_control_ticks(mppi_handle *h, const float state[MPPI_STATE_DIM], int n_ticks, int stride)
 {
   if (!h || n_ticks < 0 || stride < 0) return MPPI_ERR_INVALID;
+  if (state && chain_ok(h, n_ticks, stride)) return control_ticks_chained(h, state, n_ticks, stride);
   for (int i = 0; i < n_ticks; i++) {
     int rc = mppi_compute_control(h, state);
     if (rc) return rc;

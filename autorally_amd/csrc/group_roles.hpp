@@ -308,7 +308,18 @@ __device__ __forceinline__ void quad_chain(float v, float d, float dt, int q, fl
   vq = (q < 2) ? lo : hi;
 }
 template <class SH, bool AFFINE>
+__device__ __forceinline__ void group_pose_wave4(const RolloutArgs &a, SH &sh, const float x0, const float y0, const float yaw0,
+                                                 const int budget_cut = 0);
+template <class SH, bool AFFINE>
 __device__ __forceinline__ void group_pose_wave4(const RolloutArgs &a, SH &sh)
+{
+  group_pose_wave4<SH, AFFINE>(a, sh, a.state[0], a.state[1], a.state[2]);
+}
+// x0, y0, yaw0: the pose the rollouts start from (a.state[0..2], or what a gated kernel received through its gate block);
+// budget_cut != 0: a wait in front of this call already ran out -- the wave starts with an exhausted poll budget
+template <class SH, bool AFFINE>
+__device__ __forceinline__ void group_pose_wave4(const RolloutArgs &a, SH &sh, const float x0, const float y0, const float yaw0,
+                                                 const int budget_cut)
 {
   using R = GroupRoles<SH>;
   constexpr int NSW = SH::NSW;
@@ -319,8 +330,8 @@ __device__ __forceinline__ void group_pose_wave4(const RolloutArgs &a, SH &sh)
   const uint32_t a_seq0 = lds_addr(&sh.xseq[0][0]);
   const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
   const uint32_t a_mypub = lds_addr(&sh.pose_pub[lane]);
-  float x = a.state[0], y = a.state[1], yaw = a.state[2];  // the pose before step t0, the same in the four lanes of a rollout
-  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kPose + 1), seen = 0, cdone = 0;
+  float x = x0, y = y0, yaw = yaw0;  // the pose before step t0, the same in the four lanes of a rollout
+  int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kPose + 1 || budget_cut != 0), seen = 0, cdone = 0;
   for (int t0 = 0; t0 < T; t0 += 4) {
     const int t = t0 + q;
     const int tend = min(t0 + 4, T);  // the chunk is steps [t0, tend); lanes of later steps compute on whatever the ring holds

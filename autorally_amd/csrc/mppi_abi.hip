@@ -50,6 +50,7 @@ void free_all(mppi_handle *h)
   if (h->d_invt) (void)hipFree(h->d_invt);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->d_gx) (void)hipFree(h->d_gx);
+  if (h->gate_cpu) { if (h->gate_bar) (void)hipFree(h->gate_cpu); else (void)hipHostFree(h->gate_cpu); }
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
   for (uint32_t *p : up)
     if (p) (void)hipFree(p);
@@ -228,6 +229,24 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     void *dp = nullptr;
     CR(hipHostGetDevicePointer(&dp, h->h_res, 0));
     h->d_res_map = static_cast<float *>(dp);
+  }
+  {
+    // gate block of the chained control ticks: fine-grained device memory the host can store into (large BAR), else host-mapped
+    const size_t gate_bytes = sizeof(unsigned) * 16 * kGateReplicas;
+    void *gp = nullptr;
+    if (prop.isLargeBar && hipExtMallocWithFlags(&gp, gate_bytes, hipDeviceMallocFinegrained) == hipSuccess && gp != nullptr) {
+      h->gate_cpu = h->d_gate = static_cast<unsigned *>(gp);
+      h->gate_bar = true;
+      CR(hipMemset(gp, 0, gate_bytes));
+    } else {
+      (void)hipGetLastError();
+      CR(hipHostMalloc(&gp, gate_bytes, hipHostMallocMapped));
+      h->gate_cpu = static_cast<unsigned *>(gp);
+      memset(gp, 0, gate_bytes);
+      void *dp = nullptr;
+      CR(hipHostGetDevicePointer(&dp, gp, 0));
+      h->d_gate = static_cast<unsigned *>(dp);
+    }
   }
   CR(hipMalloc(&h->d_invt, sizeof(double) * (size_t)h->T));
   {
@@ -650,6 +669,17 @@ int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget)
   if (!h || wave < 0 || (wave > 12 && (wave < 32 || wave > 34)) || spin_budget < 0) return MPPI_ERR_INVALID;
   h->fault_wave = wave;
   h->spin_budget = spin_budget;
+  return MPPI_OK;
+}
+
+/* Test / tooling hook: mppi_control_ticks enqueues every solve but the first one tick ahead, gated on the host (on = 1, the
+ * default) or launches each solve when its turn comes, as n calls of mppi_compute_control + mppi_slide_control_seq would (0). */
+int mppi_debug_set_chained_ticks(mppi_handle *h, int on)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  h->chain = on != 0;
   return MPPI_OK;
 }
 

@@ -53,8 +53,15 @@ struct RolloutArgs {
   // and -- tests only -- the wavefront role (1-based, 0 = none) that starts with that budget exhausted
   // (mppi_debug_inject_handover_fault)
   int spin_budget, fault_wave;
+  // gated launch (rollout_row.hip, the chained control ticks of abi_solve.hip): the kernel was enqueued one solve ahead; its
+  // vehicle state is NOT `state` above but the 7 floats of the gate block, valid once word 7 of the block equals gate_seq
+  // (kGateReplicas copies of 64 B each, written by the host; workgroup b polls copy b % kGateReplicas).  nullptr: not gated.
+  const unsigned *gate;
+  unsigned gate_seq;
   CostArgs cost;
 };
+constexpr int kGateReplicas = 8;
+constexpr unsigned kGateCancel = 0x80000000u;  // gate word = gate_seq | kGateCancel: the solve is called off (costs poisoned)
 
 // Argument block of the batched rollout kernels: grid (groups of the largest instance, instances), workgroup (x, y) runs
 // group x of inst[y]: every kernel indexes an instance's rollouts by blockIdx.x alone.

@@ -61,6 +61,8 @@ struct RowShared {
   int rng_pub[64];
   int fail[4];
   int fin[8];
+  float gstate[8];  // gated launch: the vehicle state the pose wave took from the gate block, then 1 in gate_open[]
+  int gate_open[8];
   float dump[NW][64 * 2 + (kGRing - 1) * kRolloutsPerWave * 4];  // where lanes p >= 2 of a dynamics wave put their copy of the state
                                                                  // pair (never read): 8 B per lane, moved along with the ring slot
 };
@@ -194,7 +196,7 @@ __device__ __forceinline__ float row_out_tree(const f32x2 *w3, f32x2 a)
   return v0;
 }
 
-template <int H, bool TREE>
+template <int H, bool TREE, bool GATED = false>
 __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> &sh, const int w)
 {
   static_assert(H == 32, "row_dot_bc: 32 activations, two per lane of a 16-lane row");
@@ -227,8 +229,17 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   // this lane's pair of the state: (s3, s4) for even p, (s5, s6) for odd p -- every even / odd lane of a rollout computes
   // the same output pair; layer 0 takes the pairs of lanes 0 and 1 of the row
   // (tree form: sp.x = s[3 + (p >> 2)], sp.y unused)
-  f32x2 sp = TREE ? f32x2{a.state[3 + (p >> 2)], 0.0f} : odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
+  f32x2 sp;
+  if constexpr (GATED) {
+    // the state arrives through the gate block: the pose wave has put it into LDS (the weights above were loaded meanwhile)
+    const uint32_t a_go = lds_addr(&sh.gate_open[0]);
+    while (lds_peek(a_go) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    const volatile float *gs = sh.gstate;
+    sp = TREE ? f32x2{gs[3 + (p >> 2)], 0.0f} : odd ? f32x2{gs[5], gs[6]} : f32x2{gs[3], gs[4]};
+  } else {
+    sp = TREE ? f32x2{a.state[3 + (p >> 2)], 0.0f} : odd ? f32x2{a.state[5], a.state[6]} : f32x2{a.state[3], a.state[4]};
+  }
   if (w == 0) RSTAMP(2);  // weights in registers
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   if (w == 0) RSTAMP(3);  // first controls published: the T loop starts
@@ -305,8 +316,34 @@ __device__ __forceinline__ void row_dynamics(const RolloutArgs &a, RowShared<H> 
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
+// Gated launch: the pose wave waits for the host to open the gate -- word 7 of this workgroup's copy of the gate block equal to
+// a.gate_seq -- and hands the block's vehicle state to the dynamics waves through LDS.  The gate word is host-written memory
+// (device memory the host stores into through the PCIe BAR, or host-mapped memory): system-scope loads.  The wait is bounded by
+// the 100 MHz real-time counter (100 ms); a gate that stays shut, or is opened with the cancel bit, leaves the pose wave with an
+// exhausted poll budget: the group's costs are poisoned (NaN) as after any other failed hand-over, the kernel ends.
+template <int H>
+__device__ __forceinline__ int row_gate_wait(const RolloutArgs &a, RowShared<H> &sh)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned *blk = a.gate + (size_t)((int)blockIdx.x % kGateReplicas) * 16;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned v = 0;
+  for (;;) {
+    v = __hip_atomic_load(blk + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((v & ~kGateCancel) == a.gate_seq) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 10000000ull) { v = kGateCancel; break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // the state words were stored before the gate word (the host fences between them): loaded only now
+  asm volatile("" ::: "memory");
+  const float sv = __uint_as_float(__hip_atomic_load(blk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  if (lane < 7) sh.gstate[lane] = sv;
+  lds_publish(lds_addr(&sh.gate_open[0]), 1);
+  return (v & kGateCancel) ? 1 : 0;
+}
+
 // one group (workgroup): the four dynamics waves and the four riders
-template <int H, bool AFFINE, bool CTRL, bool TREE>
+template <int H, bool AFFINE, bool CTRL, bool TREE, bool GATED = false>
 __device__ __forceinline__ void row_group(const RolloutArgs &a, RowShared<H> &sh)
 {
   using SH = RowShared<H>;
@@ -325,16 +362,27 @@ __device__ __forceinline__ void row_group(const RolloutArgs &a, RowShared<H> &sh
     sh.rng_pub[lane] = 0;
     sh.fail[lane & 3] = 0;
     sh.fin[lane & 7] = 0;
+    sh.gate_open[lane & 7] = 0;
   }
   __syncthreads();
   if (role == 0) RSTAMP(1);  // behind the barrier
 #ifdef MPPI_ROW_RIDER_PRIO
   if (role >= 4) __builtin_amdgcn_s_setprio(MPPI_ROW_RIDER_PRIO);
 #endif
-  if (role < 4) row_dynamics<H, TREE>(a, sh, role);
+  if (role < 4) row_dynamics<H, TREE, GATED>(a, sh, role);
   else if (role == R::kCost) { group_cost_wave4<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
   else if (role == R::kCtl) { group_control_wave(a, sh); RSTAMP(6); }
-  else if (role == R::kPose) { group_pose_wave4<SH, AFFINE>(a, sh); RSTAMP(7); }
+  else if (role == R::kPose) {
+    if constexpr (GATED) {
+      const int shut = row_gate_wait<H>(a, sh);
+      const volatile float *gs = sh.gstate;
+      const float x0 = gs[0], y0 = gs[1], yaw0 = gs[2];
+      group_pose_wave4<SH, AFFINE>(a, sh, x0, y0, yaw0, shut);
+    } else {
+      group_pose_wave4<SH, AFFINE>(a, sh);
+    }
+    RSTAMP(7);
+  }
   else { group_rng_wave<SH, true>(a, sh, g0); RSTAMP(8); }
 }
 
@@ -343,6 +391,13 @@ __global__ __launch_bounds__(512) void rollout_row_kernel(const RolloutArgs a)
 {
   __shared__ __attribute__((aligned(16))) RowShared<H> sh;
   row_group<H, AFFINE, CTRL, TREE>(a, sh);
+}
+// the same kernel enqueued one solve ahead (a.gate != nullptr): see row_gate_wait
+template <int H, bool AFFINE, bool CTRL, bool TREE>
+__global__ __launch_bounds__(512) void rollout_row_gated_kernel(const RolloutArgs a)
+{
+  __shared__ __attribute__((aligned(16))) RowShared<H> sh;
+  row_group<H, AFFINE, CTRL, TREE, true>(a, sh);
 }
 
 // several instances in one launch (mppi_compute_control_batch): grid (groups of the largest instance, instances) -- workgroup
@@ -408,6 +463,11 @@ hipError_t launch_rollout_row(int hidden, int n_hidden, const RolloutArgs &a, bo
   if (!row_variant_supported(hidden, n_hidden) || a.K % kRolloutsPerWave != 0) return hipErrorInvalidValue;
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   const dim3 grid(a.K / kRolloutsPerWave), block(512);
+  if (a.gate != nullptr) {
+    if (tree) MPPI_ROW_DISPATCH(MPPI_LAUNCH_ROLLOUT, rollout_row_gated_kernel, true, grid, block, 0, stream, a);
+    else MPPI_ROW_DISPATCH(MPPI_LAUNCH_ROLLOUT, rollout_row_gated_kernel, false, grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   if (tree) MPPI_ROW_DISPATCH(MPPI_LAUNCH_ROLLOUT, rollout_row_kernel, true, grid, block, 0, stream, a);
   else MPPI_ROW_DISPATCH(MPPI_LAUNCH_ROLLOUT, rollout_row_kernel, false, grid, block, 0, stream, a);
   return hipGetLastError();

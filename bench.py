@@ -311,6 +311,9 @@ def main():
     ap.add_argument("--sustained-s", type=float, default=2.0,
                     help="separate pass after the timed region: the step repeated for this many seconds (sustained rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="A/B: mppi_control_ticks launches every solve when its turn comes instead of one tick ahead "
+                         "(mppi_debug_set_chained_ticks(0))")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the multi-process driver with gloo and the CPU oracle (no GPU, not a benchmark)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
@@ -351,6 +354,8 @@ def main():
             sol.set_rollout_variant(args.variant)
         if args.block:
             sol.set_rollout_variant("block%d" % args.block)
+        if args.no_chain:
+            sol.debug_set_chained_ticks(0)
     state = cfg["start_state"].copy()
 
     def sync():
@@ -517,7 +522,8 @@ def main():
                        "K": K, "T": T, "layers": [] if cfg.get("bf_W") is not None else cfg["layers"], "num_iters": iters,
                        "rollout_variant": sol.rollout_variant() if cuda else "none",
                        "step": "computeControl + slideControlSeq(1), result on the host before the next step",
-                       "timed_loop": ("native (mppi_control_ticks)" if native else "python (one ctypes call per ABI call)"),
+                       "timed_loop": (("native (mppi_control_ticks%s)" % ("" if not args.no_chain else ", chain off")) if native
+                                      else "python (one ctypes call per ABI call)"),
                        "host_affinity": affinity if cuda else "unchanged",
                        "priming": "%d untimed solves (%.0f ms) before the %d warm-up steps" % (n_prime, args.prime_ms, args.warmup),
                        "parallelism": "replicas x%d (no collective)" % world,

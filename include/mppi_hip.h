@@ -36,7 +36,8 @@ extern "C" {
  *    "row_tree", "row_exact", "row64[_r8|_r16]", "m44"; names "valu_row8w_tree_*", "valu_row64_r*_tree_*", "mfma4x4x1_*_m44_split_tree" (automatic), "mfma4x4x1_*_m44_tree" ("m44_chain"). */
 /* 5: solves of more than 8192 rollouts run a one-launch tail (in-launch hand-overs with a deadline: fault roles 32-34 of
  *    mppi_debug_inject_handover_fault); after a wait timeout the lost solve is not waited for again (mppi_set_wait_timeout);
- *    "mfma" / "valu" / "valu_lds" drop a form forced by name; variants "multi1", "multi4u[_gen]", "row64_r8" removed. */
+ *    "mfma" / "valu" / "valu_lds" drop a form forced by name; variants "multi1", "multi4u[_gen]", "row64_r8" removed;
+ *    + mppi_debug_set_chained_ticks (mppi_control_ticks enqueues one solve ahead). */
 #define MPPI_ABI_VERSION 5
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
@@ -314,6 +315,12 @@ int mppi_debug_get_iterations(mppi_handle *h, float *U_raw, float *costs, float 
  * handle's model, as names for mppi_set_rollout_variant, the table's order; returns how many were written (<= max_n).
  * tests/test_form_selection_gpu.py times them against the automatic choice. */
 int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max_n);
+
+/* Test / tooling hook (not part of the drop-in surface): mppi_control_ticks on one handle in the row form enqueues every
+ * solve but the first one tick AHEAD, gated on a word the host writes once it holds the previous result (csrc/abi_solve.hip:
+ * chained control ticks; the launch call and the dispatch leave the step's critical path); on = 0 launches every solve when
+ * its turn comes.  The results are bit for bit the same. */
+int mppi_debug_set_chained_ticks(mppi_handle *h, int on);
 
 /* How long a blocking call (mppi_compute_control, mppi_synchronize, mppi_get_results ...) polls for a solve's result block
  * before it gives up with MPPI_ERR_HIP; default 30 s.  (The reference blocks in cudaStreamSynchronize without a limit,

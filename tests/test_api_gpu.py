@@ -373,6 +373,46 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
     sol.close()
 
 
+@pytest.mark.parametrize("K,T,variant,opt", [(4096, 100, "auto", 1), (1920, 100, "row_exact", 1), (256, 40, "auto", 2), (8192, 60, "auto", 1)])
+def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, variant, opt):
+    """mppi_control_ticks on one handle in the row form enqueues every solve but the first one tick AHEAD, gated on a word
+    the host writes once it holds the previous result (csrc/abi_solve.hip).  Same bits as launching every solve when its
+    turn comes, and as a loop of compute_control + slide_control_seq; the handle's device state afterwards is the same too
+    (the next ordinary solve agrees)."""
+    cfg = S.make_config(K, T, track="oval", opt_stride=opt)
+    st = cfg["start_state"]
+    sols = [capi.Solver(cfg) for _ in range(3)]
+    for sol in sols:
+        sol.set_rollout_variant(variant)
+        sol.seed(77, 0)
+    assert "row8w" in sols[0].rollout_variant()
+    sols[1].debug_set_chained_ticks(0)
+    n = 23
+    sols[0].control_ticks(st, n, opt)   # chained
+    sols[1].control_ticks(st, n, opt)   # every solve launched when its turn comes
+    for _ in range(n):                  # one ABI call per step
+        sols[2].compute_control(st)
+        sols[2].slide_control_seq(opt)
+    for other in sols[1:]:
+        np.testing.assert_array_equal(sols[0].get_control_seq().view(np.uint32), other.get_control_seq().view(np.uint32))
+        np.testing.assert_array_equal(sols[0].get_control_hist().view(np.uint32), other.get_control_hist().view(np.uint32))
+    res = []
+    for sol in sols:  # the device copies (U, generator states) are where the unchained loop leaves them
+        sol.compute_control(st)
+        res.append(sol.get_results())
+    for r in res[1:]:
+        for key in ("U", "costs", "w"):
+            np.testing.assert_array_equal(res[0][key].view(np.uint32), r[key].view(np.uint32), err_msg=key)
+        assert res[0]["traj_cost"] == r["traj_cost"]
+    assert np.all(np.isfinite(res[0]["U"]))
+    # a second chained call on the same handle, after an ordinary solve in between
+    sols[0].slide_control_seq(opt); sols[1].slide_control_seq(opt)
+    sols[0].control_ticks(st, 5, opt); sols[1].control_ticks(st, 5, opt)
+    np.testing.assert_array_equal(sols[0].get_control_seq().view(np.uint32), sols[1].get_control_seq().view(np.uint32))
+    for sol in sols:
+        sol.close()
+
+
 def test_wait_timeout_is_kept_and_the_lost_solve_is_not_waited_for_again():
     """mppi_set_wait_timeout: a limit far below the length of a solve (K = 65536, T = 150, 6-64-64-4: about a millisecond
     of device work) ends the blocking call in MPPI_ERR_HIP within about the limit; the calls that follow return at once
