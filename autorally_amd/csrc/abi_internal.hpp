@@ -98,6 +98,7 @@ struct mppi_handle {
   // K > 8192 (one-launch streaming tail): d_part holds 8-byte {value, epoch} granules instead of floats; d_gx the granules of
   // the column exchanges; tail_epoch the tag of the last tail launch; tail_poll_ticks the deadline of its waits (100 MHz ticks)
   unsigned long long *d_gx = nullptr;
+  unsigned long long *d_ug = nullptr;  // [T][2] granules of the raw weighted mean: row workgroups -> the smoothing workgroup
   unsigned tail_epoch = 0, tail_poll_ticks = 2000000;  // 20 ms
   float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
 

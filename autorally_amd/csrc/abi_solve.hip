@@ -358,6 +358,7 @@ TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last)
   l.init0 = h->cfg.init_control[0]; l.init1 = h->cfg.init_control[1];
   // the one-launch streaming tail (K > 8192): granule buffers, this launch's tag (the caller advanced it), wait deadline; the
   // tests' fault roles 32-34 shorten the deadline to spin_budget x 1 us
+  l.ug = h->d_ug;
   l.gx = h->d_gx; l.gpart = reinterpret_cast<unsigned long long *>(h->d_part);
   l.epoch = h->tail_epoch;
   l.fault = h->fault_wave >= 32 ? h->fault_wave : 0;
@@ -481,28 +482,35 @@ static bool chain_ok(const mppi_handle *h, int n_ticks, int stride)
          has_noise_wave(h);
 }
 
-// the gate block: the state first, then (fenced) the gate word, in every replica
+// the gate block of solve `word`: its nominal sequence and history (the host's copies, smoothed and slid), its state in every
+// replica, then (fenced) the gate word in every replica
 static void write_gate(mppi_handle *h, const float *state, unsigned word)
 {
-  volatile unsigned *g = h->gate_cpu;
-  for (int r = 0; r < kGateReplicas; r++)
-    for (int i = 0; i < kStateDim; i++) {
-      unsigned u;
-      memcpy(&u, state + i, sizeof(u));
-      g[16 * r + i] = u;
-    }
+  // (memcpy: wide stores -- the block is write-combining memory behind the PCIe BAR where gate_bar is set; the fences order the
+  // payload before the gate words and push both out)
+  unsigned *g = h->gate_cpu;
+  const int T = h->T;
+  memcpy(g + kGateUOffset, h->U.data(), sizeof(float) * 2 * (size_t)T);
+  memcpy(g + gate_hist_offset(T), h->hist.data(), sizeof(float) * 4);
+  for (int r = 0; r < kGateReplicas; r++) memcpy(g + 16 * r, state, sizeof(float) * kStateDim);
+  asm volatile("" ::: "memory");
   __builtin_ia32_sfence();
-  for (int r = 0; r < kGateReplicas; r++) g[16 * r + 7] = word;
+  for (int r = 0; r < kGateReplicas; r++) __atomic_store_n(g + 16 * r + 7, word, __ATOMIC_RELAXED);
   __builtin_ia32_sfence();
 }
 
-// solve (h->seq + 1), gated, behind the pending solve h->seq
-static int enqueue_ahead(mppi_handle *h, const float *state)
+// solve (h->seq + 1), gated, behind the pending solve h->seq.  Its rollout takes state AND nominal sequence from the gate
+// block (the host has both in hand when it opens the gate: U smoothed and slid, as the reference uploads U_ with every
+// computeControl, mppi_controller.cu:606-612).  Its tail: inside the chain only the publication (no workgroup smooths a device
+// copy nobody reads: the kernel ends 2.5 us earlier, and the next rollout starts when it ends); the LAST solve of the chain
+// smooths and leaves the slid copy as every ordinary solve does, with hist from the gate block, so that the handle's device
+// state after the chain is the unchained loop's.
+static int enqueue_ahead(mppi_handle *h, const float *state, bool last_of_chain)
 {
   float *noise = h->d_gen[h->gen_cur];  // the in-kernel generator's solves all leave their applied controls here
   RolloutArgs a;
   fill_rollout_args(h, state, noise, a);
-  a.U = h->d_in_buf[1 - h->in_cur];  // the slid copy the pending solve's tail kernel leaves: U of the next solve after the slide
+  a.U = reinterpret_cast<const float *>(h->d_gate) + kGateUOffset;
   a.inline_noise = 1;
   a.rng_in = h->d_rng[h->rng_cur];
   a.rng_out = h->d_rng[1 - h->rng_cur];
@@ -512,10 +520,16 @@ static int enqueue_ahead(mppi_handle *h, const float *state)
   int rc = launch_rollout(h, a);
   if (rc) return rc;
   TailLaunch l = tail_launch(h, noise, true);
-  l.U = h->d_in_buf[1 - h->in_cur];
-  l.hist = l.U + 2 * h->T;
-  l.slid = h->d_in_buf[h->in_cur];
   l.seq = h->seq + 1;
+  l.hist = reinterpret_cast<const float *>(h->d_gate) + gate_hist_offset(h->T);
+  if (last_of_chain) {
+    l.U = h->d_in;
+    l.hist_out = h->d_in + 2 * h->T;
+    l.slid = h->d_in_buf[1 - h->in_cur];
+  } else {
+    l.no_device_copy = 1;
+    l.slid = nullptr;
+  }
   HIPCHK(h, launch_solve_tail(l, h->stream));
   h->ahead = true;
   return MPPI_OK;
@@ -538,27 +552,33 @@ static int control_ticks_chained(mppi_handle *h, const float *state, int n_ticks
   int rc = enqueue_solve(h, state);
   if (rc) return rc;
   for (int i = 0; i < n_ticks; i++) {
-    const bool ahead = i + 1 < n_ticks;
+    const bool ahead = i + 1 < n_ticks, ahead_is_last = i + 2 == n_ticks;
     if (ahead) {
-      rc = enqueue_ahead(h, state);
+      rc = enqueue_ahead(h, state, ahead_is_last);
       if (rc) {
         (void)wait_pending(h);
         return rc;
       }
     }
     rc = wait_pending(h);
-    if (rc == MPPI_OK) rc = mppi_slide_control_seq(h, stride);
+    if (rc == MPPI_OK) {
+      // inside the chain the device copy of U is not kept up (the next solve reads the host's through the gate block): the
+      // slide is the host's alone; the last solve's tail restores it, and the slide behind it swaps to its slid copy as usual
+      if (ahead) { h->u_dirty = true; h->slid_valid = false; }
+      rc = mppi_slide_control_seq(h, stride);
+    }
     if (rc) {
       if (ahead) cancel_ahead(h, state);
       return rc;
     }
-    if (ahead) {  // the host has result i: solve i+1 may read its state
+    if (ahead) {  // the host has result i, smoothed and slid: solve i+1 may start
       h->seq++;
       write_gate(h, state, h->seq);
       h->ahead = false;
       h->pending = true;
       h->pending_timed = false;
-      h->slid_valid = true;  // chain_ok: the tail kernel leaves the slid copy
+      h->v_buf = h->d_gen[h->gen_cur];
+      if (ahead_is_last) { h->u_dirty = false; h->slid_valid = true; }  // its tail smooths h->d_in and leaves the slid copy
     }
   }
   return MPPI_OK;

@@ -155,8 +155,10 @@ __device__ __forceinline__ void group_rng_wave(const RolloutArgs &a, SH &sh, con
 // its SIMD's dynamics wave leaves free: with one step per iteration on 16 lanes the Box-Muller chain (a division, a
 // square root, three polynomials: ~100 dependent instructions) made this wave the pace of the whole group (row form,
 // K=4096, T=100: 68.7 us; 55.6 us with the transform removed).  Per step it now issues a quarter of that.
+// a_gate_open != 0 (gated launch, rollout_row.hip): the nominal sequence is in the gate block, host-written: the wave waits for
+// the group's pose wave to have seen the gate open (that LDS word) and reads U with system-scope loads
 template <class SH>
-__device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
+__device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh, const uint32_t a_gate_open = 0)
 {
   using R = GroupRoles<SH>;
   constexpr int NSW = SH::NSW;
@@ -175,6 +177,9 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
   const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
   const uint32_t a_rng = lds_addr(&sh.rng_pub[0]);
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == R::kCtl + 1);
+  const bool gated = a_gate_open != 0;
+  if (gated)
+    while (lds_peek(a_gate_open) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   int seen_x = 0, seen_c = 0, seen_r = 0;  // swaps published by all dynamics waves / steps consumed by the cost wave / pairs drawn
   // The first iteration is ONE step (lanes of q = 0 only), so that the dynamics waves can start as soon as the noise
   // wave has drawn its first pair instead of its first four (~1 us of every launch); four steps from then on.
@@ -183,7 +188,13 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh)
     const bool live = (t < T) & (q < n);
     const int tl = live ? t : T - 1;
     // this lane's nominal control and (explicit noise) eps
-    const float2 Ut = Useq[tl];
+    float2 Ut;
+    if (gated) {
+      const unsigned long long ub = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(Useq + tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      Ut = make_float2(__uint_as_float((unsigned)ub), __uint_as_float((unsigned)(ub >> 32)));
+    } else {
+      Ut = Useq[tl];
+    }
     float2 e = (live && !inl) ? noise[(size_t)tl * K + k] : make_float2(0.0f, 0.0f);
     // the last slot of the chunk: slot t % kGRing held step t - kGRing -- the dynamics waves read it during step
     // t - kGRing - 1 (done once all of them published the first swap of step t - kGRing), the cost wave in step t - kGRing

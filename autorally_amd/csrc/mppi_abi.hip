@@ -50,6 +50,7 @@ void free_all(mppi_handle *h)
   if (h->d_invt) (void)hipFree(h->d_invt);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->d_gx) (void)hipFree(h->d_gx);
+  if (h->d_ug) (void)hipFree(h->d_ug);
   if (h->gate_cpu) { if (h->gate_bar) (void)hipFree(h->gate_cpu); else (void)hipHostFree(h->gate_cpu); }
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
   for (uint32_t *p : up)
@@ -194,6 +195,8 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_gen[1], sizeof(float) * KT2));
   h->v_buf = h->d_gen[0];
   h->gen_async = (size_t)h->K * (size_t)h->T >= ((size_t)1 << 20);
+  CR(hipMalloc(&h->d_ug, sizeof(unsigned long long) * 2 * (size_t)h->T));
+  CR(hipMemset(h->d_ug, 0, sizeof(unsigned long long) * 2 * (size_t)h->T));
   CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
   CR(hipMemset(h->d_counter, 0, sizeof(unsigned) * (1 + (size_t)h->T)));
   if (h->K > 4096) {
@@ -232,7 +235,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   }
   {
     // gate block of the chained control ticks: fine-grained device memory the host can store into (large BAR), else host-mapped
-    const size_t gate_bytes = sizeof(unsigned) * 16 * kGateReplicas;
+    const size_t gate_bytes = sizeof(float) * gate_block_floats(h->T);  // replicas of [state, gate word], then U[T][2], hist[4]
     void *gp = nullptr;
     if (prop.isLargeBar && hipExtMallocWithFlags(&gp, gate_bytes, hipDeviceMallocFinegrained) == hipSuccess && gp != nullptr) {
       h->gate_cpu = h->d_gate = static_cast<unsigned *>(gp);

@@ -61,6 +61,11 @@ struct RolloutArgs {
   CostArgs cost;
 };
 constexpr int kGateReplicas = 8;
+// behind the replicas: the nominal control sequence U[T][2] of the gated solve and the control history hist[4] its tail kernel
+// smooths with -- one copy each, written by the host before the gate words (float offsets into the block)
+constexpr int kGateUOffset = 16 * kGateReplicas;
+inline int gate_hist_offset(int T) { return kGateUOffset + 2 * T; }
+inline size_t gate_block_floats(int T) { return (size_t)gate_hist_offset(T) + 4; }
 constexpr unsigned kGateCancel = 0x80000000u;  // gate word = gate_seq | kGateCancel: the solve is called off (costs poisoned)
 
 // Argument block of the batched rollout kernels: grid (groups of the largest instance, instances), workgroup (x, y) runs

@@ -101,6 +101,9 @@ struct TailLaunch {
   // K > 8192 (solve_tail_stream_kernel): granule buffers (gx: 3 x 64 exchange granules; gpart: [T][K/64][2] chain results,
   // 8 B each, zero when allocated), the tag of this launch's granules (never 0, never the tag of an earlier launch on these
   // buffers), the deadline of every in-launch wait in 100 MHz ticks, and the tests' fault role (0: none)
+  unsigned long long *ug = nullptr;  // [T][2] granules of the raw weighted mean (every form)
+  int no_device_copy = 0;            // chained ticks: publish only
+  float *hist_out = nullptr;         // chained ticks, last solve: where the smoothing workgroup leaves hist[4]
   unsigned long long *gx = nullptr, *gpart = nullptr;
   unsigned epoch = 0, poll_ticks = 0;
   int fault = 0;

@@ -371,7 +371,7 @@ __device__ __forceinline__ void row_group(const RolloutArgs &a, RowShared<H> &sh
 #endif
   if (role < 4) row_dynamics<H, TREE, GATED>(a, sh, role);
   else if (role == R::kCost) { group_cost_wave4<SH, CTRL>(a, sh); RSTAMP(5); }  // costs stored
-  else if (role == R::kCtl) { group_control_wave(a, sh); RSTAMP(6); }
+  else if (role == R::kCtl) { group_control_wave(a, sh, GATED ? lds_addr(&sh.gate_open[0]) : 0u); RSTAMP(6); }
   else if (role == R::kPose) {
     if constexpr (GATED) {
       const int shut = row_gate_wait<H>(a, sh);

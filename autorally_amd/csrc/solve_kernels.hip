@@ -130,6 +130,18 @@ __device__ __forceinline__ void publish_entry(float *res, int entry, float v0, f
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// One value handed to another workgroup of the same launch: an 8-byte {value, tag} granule, ONE sc1 store (MI355X guide G16,
+// form R2: the data is the flag -- no fence, no flag word; the reader polls the granule with sc1 loads until the tag is this
+// launch's).
+__device__ __forceinline__ unsigned long long make_granule(unsigned epoch, float v)
+{
+  return ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+}
+__device__ __forceinline__ void store_granule(unsigned long long *g, unsigned epoch, float v)
+{
+  __hip_atomic_store(g, make_granule(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 sc1
+}
+
 struct TailArgs {
   const float *costs;   // [K]
   const float *V;       // [T][K][2] applied controls of this iteration
@@ -139,6 +151,11 @@ struct TailArgs {
   float *scal;          // [3] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup)
   float *res;           // host-mapped result block, T+2 entries of 16 B: rows [u0, seq, u1, seq], then
                         // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq]
+  int no_device_copy;   // inside chained ticks: the rows and scalars are published, nothing else -- no arrival, no smoothing of the
+                        // device copy, no slid copy (the next solve takes U from the host through its gate block)
+  float *hist_out;      // optional: the smoothing workgroup copies hist[4] here (the last solve of a chain read it from the gate block)
+  unsigned long long *ug;  // [T][2] the raw weighted mean of the last iteration as {value, seq} granules: from the row workgroups to the
+                        // workgroup that arrives last and smooths the device copy
   unsigned *counter;    // [1 + T] arrival counters (all rows, then per row), zero on entry, reset by the last arriver
   float *part;          // [T][K/64][2] chain results when a row is spread over several workgroups (K > kRedChunk)
   int K, T;
@@ -162,6 +179,7 @@ __device__ __forceinline__ void tail_arrive_and_smooth(const TailArgs &a, const 
 #ifdef MPPI_DIAG_TAIL_NOARRIVE  // diagnostic build: what do the arrival counter and the last workgroup's smoothing cost?
   return;
 #endif
+  if (a.no_device_copy) return;
   __syncthreads();  // is_last may still be read from the row hand-off above
   if (tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -172,16 +190,31 @@ __device__ __forceinline__ void tail_arrive_and_smooth(const TailArgs &a, const 
   if (!is_last) return;
   if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
   if (!a.last_iter) return;       // more iterations follow: U stays the raw weighted mean
-  last_arriver_acquire();
+  // The rows arrive as {value, seq} granules (round 5; until then: plain words behind an agent-scope acquire, 1.7 us of every
+  // tail kernel -- nothing while the next launch came 4 us later anyway, the whole gap to the next rollout in the chained
+  // ticks).  Every row workgroup stored its granules and drained them before its ticket, and this workgroup's ticket came
+  // last: the tags are normally all there at the first look; a granule that is not yet visible is simply read again.
   float *X = dyn + (K / 64) * 2;  // [(T+4)][2]
   float *Y = X + (T + 4) * 2;     // [T][2] smoothed sequence
-  for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
-    const int r = i >> 1, j = i & 1;
-    float v;
-    if (r < 2) v = a.hist[2 * r + j];
-    else if (r < T + 2) v = __hip_atomic_load(&a.U[2 * (r - 2) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else v = __hip_atomic_load(&a.U[2 * (T - 1) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    X[i] = v;
+  {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < (T + 4) * 2; i += kTailThreads) {
+      const int r = i >> 1, j = i & 1;
+      float v;
+      if (r < 2) {
+        v = a.hist[2 * r + j];
+      } else {
+        const unsigned long long *g = a.ug + 2 * (r < T + 2 ? r - 2 : T - 1) + j;
+        for (;;) {
+          const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = __uint_as_float((unsigned)x);
+          if ((unsigned)(x >> 32) == a.seq) break;
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000ull) { v = __builtin_nanf(""); break; }  // 10 ms: the next solve fails loudly
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      X[i] = v;
+    }
   }
   __syncthreads();
   {
@@ -199,6 +232,7 @@ __device__ __forceinline__ void tail_arrive_and_smooth(const TailArgs &a, const 
       a.U[i] = acc;  // the device copy the next solve perturbs (the host computes the same values itself)
       Y[i] = acc;    // and in LDS for the slid copy below
     }
+    if (a.hist_out != nullptr && tid < 4) a.hist_out[tid] = X[tid];
   }
   __syncthreads();
 
@@ -419,8 +453,9 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
       }
     }
     for (; mm < G; mm++) u += pj[mm];
-    // write-through (sc1) store: the hand-off to the last workgroup below needs no L2 write-back
-    __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // last iteration: a granule for the workgroup that smooths the device copy; else the raw mean, for the next iteration's rollout
+    if (a.last_iter) store_granule(a.ug + t * 2 + tid, a.seq, u);
+    else a.U[t * 2 + tid] = u;
   }
   if (tid < 64) {
     // The host gets row t NOW (last iteration): it smooths the sequence itself (5 taps per value) as
@@ -508,14 +543,6 @@ struct StreamTailArgs {
                              // its chain results, 34 = no leader publishes {beta, eta}
 };
 
-__device__ __forceinline__ unsigned long long make_granule(unsigned epoch, float v)
-{
-  return ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
-}
-__device__ __forceinline__ void store_granule(unsigned long long *g, unsigned epoch, float v)
-{
-  __hip_atomic_store(g, make_granule(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 sc1
-}
 
 // One granule of a replica line, polled by wave 0 (lane 0 loads): its value into *out (LDS); the caller's barrier follows.
 // NaN when the wait ran out of time.
@@ -870,7 +897,8 @@ __global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(cons
       }
     }
     for (; mm < G; mm++) u += pj[mm];
-    __hip_atomic_store(&a.U[t * 2 + tid], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by the last row-closing workgroup
+    if (a.last_iter) store_granule(a.ug + t * 2 + tid, a.seq, u);  // for the row-closing workgroup that arrives last
+    else a.U[t * 2 + tid] = u;
   }
   if (tid < 64) {
     const float u1 = __shfl(u, 1);
@@ -1021,7 +1049,8 @@ static TailArgs fill_tail(const TailLaunch &l)
 {
   TailArgs a;
   a.slid = l.slid; a.slide_stride = l.slide_stride; a.init0 = l.init0; a.init1 = l.init1;
-  a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res;
+  a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res; a.ug = l.ug;
+  a.no_device_copy = l.no_device_copy; a.hist_out = l.hist_out;
   a.counter = l.counter; a.part = l.part;
   a.K = l.K; a.T = l.T; a.gamma = l.gamma; a.last_iter = l.last_iter; a.seq = l.seq;
   return a;

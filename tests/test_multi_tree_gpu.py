@@ -71,6 +71,9 @@ def test_multi4_tree_against_its_mode_and_the_nominal_oracle(layers, K, T, varia
     assert abs(got["traj_cost"] - ref4["traj_cost"]) <= 1e-4 * abs(ref4["traj_cost"])
     # ---- the nominal oracle: north-star criteria
     err1 = rel_err(got["costs"], ref1["costs"])
+    print("nominal margin: K=%d T=%d %s: |dU|inf = %.3e, trajectory cost rel = %.3e (bound 1e-4 each), flipped %d of %d" % (
+        K, T, got["variant"], float(np.max(np.abs(got["U"] - ref1["U"]))),
+        abs(got["traj_cost"] - ref1["traj_cost"]) / abs(ref1["traj_cost"]), int(np.sum(err1 > 1e-4)), K))
     assert int(np.sum(err1 > 1e-4)) <= max(K // 200, 1), float(err1.max())
     assert np.max(np.abs(got["U"] - ref1["U"])) <= 1e-4
     assert abs(got["traj_cost"] - ref1["traj_cost"]) <= 1e-4 * abs(ref1["traj_cost"])

@@ -58,6 +58,10 @@ def _solve_both(cfg, U0=None, hist=None, seed=1234, variant=None):
         nom = O.Oracle(cfg, fma_mode=1, nthreads=8).compute_control(cfg["start_state"], U0, hist, eps, num_iters=iters)
         ref["nominal"] = nom
         if iters == 1:  # north star: controls and trajectory cost within 1e-4 of the reference's own summation order
+            # the margin at the contract's mark, visible in the log (pytest -s / pytest.log): VERDICT round 4, item 3
+            print("nominal margin: K=%d T=%d %s %s: |dU|inf = %.3e, trajectory cost rel = %.3e (bound 1e-4 each), flipped %d of %d" % (
+                cfg["K"], cfg["T"], "-".join(map(str, cfg["layers"])), got["variant"], float(np.max(np.abs(got["U"] - nom["U"]))),
+                abs(got["traj_cost"] - nom["traj_cost"]) / abs(nom["traj_cost"]), int(np.sum(rel_err(got["costs"], nom["costs"]) > 1e-4)), cfg["K"]))
             assert np.max(np.abs(got["U"] - nom["U"])) <= 1e-4
             assert abs(got["traj_cost"] - nom["traj_cost"]) <= 1e-4 * abs(nom["traj_cost"])
             assert int(np.sum(rel_err(got["costs"], nom["costs"]) > 1e-4)) <= max(cfg["K"] // 200, 1)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# tools/gq.sh <timeout s> <command...>: gpurun, waiting (not retrying a run) while no GPU slot is free (exit code 3: nothing ran)
+t=$1; shift
+for i in $(seq 1 30); do
+  /usr/local/graft/bin/gpurun --timeout "$t" -- "$@"; rc=$?
+  [ $rc -ne 3 ] && exit $rc
+  sleep 90
+done
+exit 3
