@@ -472,14 +472,15 @@ int enqueue_solve(mppi_handle *h, const float *state)
 // tools/ub/gate_ub.hip (profiles/r05_c_gate_ub.txt): 46.3 -> 43.0 us per step for stand-in kernels of the headline's length
 // with the gate in device memory written through the BAR, 44.5 with a host-mapped gate; two streams with the next rollout
 // resident beside the tail: 54 (the cross-stream events cost more than the launches they hide).
-// Results are bit for bit those of the unchained loop (tests/test_api_gpu.py).  Only for the case that gains: one handle, the
-// row form with its in-kernel generator, one iteration, no stage events, no capture, stride = optimization stride.
+// Results are bit for bit those of the unchained loop (tests/test_api_gpu.py).  Only for the cases that gain: one handle, a
+// latency form with riders (the row form; the automatic m44 form of 64-wide nets) and its in-kernel generator, one iteration,
+// no stage events, no capture, stride = optimization stride.
 static bool chain_ok(const mppi_handle *h, int n_ticks, int stride)
 {
   return h->chain && n_ticks >= 2 && h->d_gate != nullptr && stride == h->cfg.optimization_stride && wants_slid_copy(h) &&
          h->cfg.num_iters == 1 && !h->timing && !h->capture && h->explicit_iters == 0 && !h->prefetch_valid && !h->basis &&
-         h->fault_wave == 0 && h->have_nn && h->have_map && h->have_cost && !h->timed_out && form_is_row(form_of(h)) &&
-         has_noise_wave(h);
+         h->fault_wave == 0 && h->have_nn && h->have_map && h->have_cost && !h->timed_out &&
+         (form_is_row(form_of(h)) || form_of(h) == Form::M44) && has_noise_wave(h);
 }
 
 // the gate block of solve `word`: its nominal sequence and history (the host's copies, smoothed and slid), its state in every
@@ -501,7 +502,7 @@ static void write_gate(mppi_handle *h, const float *state, unsigned word)
 
 // solve (h->seq + 1), gated, behind the pending solve h->seq.  Its rollout takes state AND nominal sequence from the gate
 // block (the host has both in hand when it opens the gate: U smoothed and slid, as the reference uploads U_ with every
-// computeControl, mppi_controller.cu:606-612).  Its tail: inside the chain only the publication (no workgroup smooths a device
+// computeControl, mppi_controller.cu:608-610).  Its tail: inside the chain only the publication (no workgroup smooths a device
 // copy nobody reads: the kernel ends 2.5 us earlier, and the next rollout starts when it ends); the LAST solve of the chain
 // smooths and leaves the slid copy as every ordinary solve does, with hist from the gate block, so that the handle's device
 // state after the chain is the unchained loop's.

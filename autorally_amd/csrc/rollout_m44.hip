@@ -58,6 +58,8 @@ struct M44Shared {
   int rng_pub[64];
   int fail[4];
   int fin[8];
+  float gstate[8];   // gated launch: the vehicle state the pose wave took from the gate block, then 1 in gate_open[]
+  int gate_open[8];
   m44_f4 wo[4][64];             // output-layer weights of lane l (6-64x4-4: they do not fit the registers beside 192 + ...)
   float dump[NW][64 * kGRing];  // where the lanes that hold no record word put their copy (never read), per ring slot
 };
@@ -156,7 +158,7 @@ __device__ __forceinline__ float m44_out_tree(const f32x2 (&q)[4], const f32x2 (
   return v;
 }
 
-template <int NHID, bool SPLIT>
+template <int NHID, bool SPLIT, bool GATED = false>
 __device__ __forceinline__ void m44_dynamics(const RolloutArgs &a, M44Shared &sh, const int w)
 {
   constexpr bool OUT_LDS = (NHID > 2);
@@ -212,8 +214,16 @@ __device__ __forceinline__ void m44_dynamics(const RolloutArgs &a, M44Shared &sh
   constexpr uint32_t kRecStride = sizeof(float) * kRolloutsPerWave * 4;
   static_assert(kRecStride == sizeof(float) * 64, "dump rows move along with the record's ring slot");
 
-  float sv = a.state[3 + row];
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == w + 1);
+  float sv;
+  if constexpr (GATED) {  // the state arrives through the gate block: the pose wave has put it into LDS (group_gate_wait)
+    const uint32_t a_go = lds_addr(&sh.gate_open[0]);
+    while (lds_peek(a_go) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    const volatile float *gs = sh.gstate;
+    sv = gs[3 + row];
+  } else {
+    sv = a.state[3 + row];
+  }
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   f32x2 un = p_u[0];
   asm volatile("" : "+v"(un));
@@ -297,7 +307,8 @@ __device__ __forceinline__ void m44_dynamics(const RolloutArgs &a, M44Shared &sh
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[w]));
 }
 
-template <int NHID, bool AFFINE, bool CTRL, bool SPLIT>
+// GATED: enqueued one solve ahead (a.gate != nullptr), state and nominal sequence from the gate block: group_gate_wait
+template <int NHID, bool AFFINE, bool CTRL, bool SPLIT, bool GATED = false>
 __global__ __launch_bounds__(512) void rollout_m44_kernel(const RolloutArgs a)
 {
   using SH = M44Shared;
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(512) void rollout_m44_kernel(const RolloutArgs a)
     sh.rng_pub[lane] = 0;
     sh.fail[lane & 3] = 0;
     sh.fin[lane & 7] = 0;
+    sh.gate_open[lane & 7] = 0;
   }
   if (role == 1) {  // the output layer's weights into LDS
     const m44_f4 *src = reinterpret_cast<const m44_f4 *>(a.wpack) + m44_q_out<NHID>() * 64 + lane;
@@ -323,10 +335,19 @@ __global__ __launch_bounds__(512) void rollout_m44_kernel(const RolloutArgs a)
     for (int s = 0; s < 4; s++) sh.wo[s][lane] = src[s * 64];
   }
   __syncthreads();  // the only barrier
-  if (role < 4) m44_dynamics<NHID, SPLIT>(a, sh, role);
+  if (role < 4) m44_dynamics<NHID, SPLIT, GATED>(a, sh, role);
   else if (role == RO::kCost) group_cost_wave4<SH, CTRL>(a, sh);
-  else if (role == RO::kCtl) group_control_wave(a, sh);
-  else if (role == RO::kPose) group_pose_wave4<SH, AFFINE>(a, sh);
+  else if (role == RO::kCtl) group_control_wave(a, sh, GATED ? lds_addr(&sh.gate_open[0]) : 0u);
+  else if (role == RO::kPose) {
+    if constexpr (GATED) {
+      const int shut = group_gate_wait(a, sh);
+      const volatile float *gs = sh.gstate;
+      const float x0 = gs[0], y0 = gs[1], yaw0 = gs[2];
+      group_pose_wave4<SH, AFFINE>(a, sh, x0, y0, yaw0, shut);
+    } else {
+      group_pose_wave4<SH, AFFINE>(a, sh);
+    }
+  }
   else group_rng_wave<SH, true>(a, sh, g0);
 }
 
@@ -338,6 +359,17 @@ static hipError_t launch_m44(const RolloutArgs &a, hipStream_t stream)
 {
   const bool affine = a.cost.affine != 0, ctrl = a.cost.need_control_cost != 0;
   const dim3 grid(a.K / kRolloutsPerWave), block(512);
+  if (a.gate != nullptr) {  // the gated form exists for the automatic (split) form only: abi_solve.hip: chain_ok
+    if constexpr (SPLIT) {
+      if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, false, true, true>), grid, block, 0, stream, a);
+      else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, true, true, true>), grid, block, 0, stream, a);
+      else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, false, true, true>), grid, block, 0, stream, a);
+      else MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, true, true, true>), grid, block, 0, stream, a);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, false, SPLIT>), grid, block, 0, stream, a);
   else if (affine && ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, true, true, SPLIT>), grid, block, 0, stream, a);
   else if (!affine && !ctrl) MPPI_LAUNCH_ROLLOUT((rollout_m44_kernel<NHID, false, false, SPLIT>), grid, block, 0, stream, a);

@@ -573,6 +573,13 @@ def main():
                 "algorithmic_GBps": bpu * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
             }
+            if native and not args.no_chain and ("row8w" in variant or "m44_split" in variant):
+                out["roofline"]["chained_ticks"] = (
+                    "the timed steps run chained (mppi_control_ticks enqueues every solve but a block's first one tick ahead: DESIGN.md "
+                    "4.10); under rocprofv3 they appear as rollout_*_gated_kernel, whose duration INCLUDES its wait for the host's gate "
+                    "(about 1 us on average, rare long ones when the host thread is descheduled); kernel_ms / achieved here are the "
+                    "UNGATED kernel's (the stage-event pass runs unchained: the same code without the wait), which rocprofv3 lists "
+                    "as rollout_*_kernel (a block's first solve)")
             if "row8w" in variant:
                 # The latency form on the vector ALU (rollout_row.hip): no MFMA is issued; the f32 vector peak with packed
                 # multiply-adds equals the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), so the roofline block keeps

@@ -373,19 +373,20 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
     sol.close()
 
 
-@pytest.mark.parametrize("K,T,variant,opt", [(4096, 100, "auto", 1), (1920, 100, "row_exact", 1), (256, 40, "auto", 2), (8192, 60, "auto", 1)])
-def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, variant, opt):
+@pytest.mark.parametrize("K,T,variant,opt,layers", [(4096, 100, "auto", 1, None), (1920, 100, "row_exact", 1, None), (256, 40, "auto", 2, None),
+                                                    (8192, 60, "auto", 1, None), (1920, 50, "auto", 1, [6, 64, 64, 64, 64, 4]), (512, 30, "auto", 1, [6, 64, 64, 4])])
+def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, variant, opt, layers):
     """mppi_control_ticks on one handle in the row form enqueues every solve but the first one tick AHEAD, gated on a word
     the host writes once it holds the previous result (csrc/abi_solve.hip).  Same bits as launching every solve when its
     turn comes, and as a loop of compute_control + slide_control_seq; the handle's device state afterwards is the same too
     (the next ordinary solve agrees)."""
-    cfg = S.make_config(K, T, track="oval", opt_stride=opt)
+    cfg = S.make_config(K, T, track="oval", opt_stride=opt, layers=layers)
     st = cfg["start_state"]
     sols = [capi.Solver(cfg) for _ in range(3)]
     for sol in sols:
         sol.set_rollout_variant(variant)
         sol.seed(77, 0)
-    assert "row8w" in sols[0].rollout_variant()
+    assert ("row8w" if layers is None else "m44_split") in sols[0].rollout_variant()
     sols[1].debug_set_chained_ticks(0)
     n = 23
     sols[0].control_ticks(st, n, opt)   # chained
