@@ -414,6 +414,45 @@ def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, varian
         sol.close()
 
 
+def test_an_error_inside_chained_ticks_calls_the_solve_ahead_off():
+    """A solve of a chain fails on the host side (here: its wait runs out of time) while the NEXT solve is already enqueued
+    behind it, gated.  The gate must be opened with the cancel bit (a gated kernel left waiting would hold the queue for its
+    100 ms deadline and then poison a solve nobody asked for), the call returns the error, and the handle -- whose device
+    copies are stale by then -- works again from the host's copies: the next results are those of a fresh handle fed the same
+    control sequence."""
+    import time
+    cfg = S.make_config(8192, 100, track="oval")
+    st = cfg["start_state"]
+    sol = capi.Solver(cfg)
+    sol.seed(5, 0)
+    sol.control_ticks(st, 4, 1)
+    sol.set_wait_timeout(1e-6)
+    t0 = time.perf_counter()
+    with pytest.raises(capi.MppiError) as e:
+        sol.control_ticks(st, 6, 1)
+    assert e.value.status == capi.ERR_HIP and "timed out" in str(e.value)
+    assert time.perf_counter() - t0 < 0.05  # the solve ahead was called off at once, not left to its deadline
+    sol.set_wait_timeout(30.0)
+    U, hist = sol.get_control_seq().copy(), sol.get_control_hist().copy()
+    deadline = time.perf_counter() + 5.0
+    while True:
+        try:
+            sol.seed(9, 0)
+            break
+        except capi.MppiError:
+            assert time.perf_counter() < deadline
+            time.sleep(0.001)
+    sol.control_ticks(st, 3, 1)
+    ref = capi.Solver(cfg)
+    ref.set_control_seq(U)
+    ref.set_control_hist(hist)
+    ref.seed(9, 0)
+    ref.control_ticks(st, 3, 1)
+    np.testing.assert_array_equal(sol.get_control_seq().view(np.uint32), ref.get_control_seq().view(np.uint32))
+    np.testing.assert_array_equal(sol.get_control_hist().view(np.uint32), ref.get_control_hist().view(np.uint32))
+    sol.close(); ref.close()
+
+
 def test_wait_timeout_is_kept_and_the_lost_solve_is_not_waited_for_again():
     """mppi_set_wait_timeout: a limit far below the length of a solve (K = 65536, T = 150, 6-64-64-4: about a millisecond
     of device work) ends the blocking call in MPPI_ERR_HIP within about the limit; the calls that follow return at once
