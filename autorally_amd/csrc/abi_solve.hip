@@ -542,6 +542,7 @@ static void cancel_ahead(mppi_handle *h, const float *state)
 {
   write_gate(h, state, (h->seq + 1) | kGateCancel);
   (void)hipStreamSynchronize(h->stream);
+  h->seq++;  // the called-off solve's tail kernel has published (poisoned) entries under that number: it is spent
   h->ahead = false;
   h->u_dirty = true;
   h->slid_valid = false;

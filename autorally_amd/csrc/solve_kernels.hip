@@ -30,9 +30,10 @@ namespace mppi {
 // its raw weighted mean straight into host-mapped memory (16-B entries carrying the solve's sequence
 // number; the extra workgroup does the same for beta, eta and the trajectory cost): the host needs no D2H
 // copy and no stream synchronise, it polls the T+2 entries and applies the 5-tap smoothing itself.
-// The workgroup that finishes last (agent-scope arrival counter, MI355X guide G16) smooths the DEVICE
-// copy of the sequence -- the one the next solve perturbs; same operations as the host, bit-identical --
-// and leaves its stride-slid copy for slideControlSeq; none of that is on the host's critical path.
+// The workgroup that finishes last (agent-scope arrival counter; the rows come to it as {value, seq} granules,
+// MI355X guide G16) smooths the DEVICE copy of the sequence -- the one the next solve perturbs; same
+// operations as the host, bit-identical -- and leaves its stride-slid copy for slideControlSeq; none of
+// that is on the host's critical path, and inside chained control ticks (abi_solve.hip) none of it runs.
 // Sums over k are pairwise (LDS tree) instead of the host's sequential loop: same value to ~1e-7.
 // ---------------------------------------------------------------------------------------------
 // Diagnostic build only (-DMPPI_TAIL_STAMPS, tools/tail_stamps.py): s_memrealtime stamps (100 MHz, comparable across CUs) of
@@ -103,13 +104,12 @@ __device__ __forceinline__ float block_reduce(float v, float *red4)
   return r;
 }
 
-// Consumer side of the in-launch hand-overs below (MI355X guide, hand-off forms): the workgroup whose
-// counter add came last runs ONE agent-scope acquire (buffer_inv sc1: this CU's L1) and waits for it
-// before any of its waves loads what the other workgroups stored.  The producers store every handed-off
-// word sc1 (write-through), every storing wave drains its stores (s_waitcnt vmcnt(0)) and the workgroup
-// passes a barrier before one lane adds to the counter; the loads are sc1 as well.  The guide measures
-// the acquire-free variant only for one workgroup per CU; several of these workgroups share a CU, so
-// the acquire stays (~1.7 us, in a phase the host does not wait for).
+// Consumer side of the ONE counter hand-over left (the two chunks of a row in solve_tail_wide_kernel, 4096 < K <= 8192; every
+// other hand-over is a {value, tag} granule since round 5): the workgroup whose counter add came last runs ONE agent-scope
+// acquire (buffer_inv sc1: this CU's L1) and waits for it before any of its waves loads what the other workgroup stored.  The
+// producers store every handed-off word sc1 (write-through), every storing wave drains its stores (s_waitcnt vmcnt(0)) and the
+// workgroup passes a barrier before one lane adds to the counter; the loads are sc1 as well.  The guide measures the
+// acquire-free variant only for one workgroup per CU; several of these workgroups share a CU, so the acquire stays here.
 __device__ __forceinline__ void last_arriver_acquire()
 {
   if (threadIdx.x == 0) {
@@ -167,11 +167,11 @@ struct TailArgs {
   unsigned seq;         // sequence number published in res[3] once everything else is visible
 };
 
-// The end of every tail kernel: the workgroups that closed a row (and, single-launch forms, the extra one) meet at the arrival
-// counter; the last one smooths the DEVICE copy of the sequence and leaves its stride-slid copy.  Hand-off form R1 of the
-// MI355X guide (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores (s_waitcnt vmcnt(0)) and
-// only then one lane bumps the agent-scope counter; the last arriver runs one agent-scope acquire (last_arriver_acquire) and
-// reads every handed-off word with sc1 loads.  No buffer_wbl2 on this path.
+// The end of every tail kernel: the workgroups that closed a row (and, K <= 8192, the extra one) meet at the arrival counter;
+// the last one smooths the DEVICE copy of the sequence and leaves its stride-slid copy.  The raw rows reach it as {value, seq}
+// granules (G16, form R2); the counter only says WHO smooths (each workgroup drains its granule stores, s_waitcnt vmcnt(0),
+// before one lane bumps it).  Inside chained control ticks (a.no_device_copy) nothing of this runs: the kernel ends with the
+// publication.
 __device__ __forceinline__ void tail_arrive_and_smooth(const TailArgs &a, const int K, const int T, const unsigned n_arrivers, int &is_last,
                                                        float *dyn)
 {
@@ -466,11 +466,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
     if (tid == 0 && !extra && a.last_iter) publish_entry(a.res, t, u, u1, a.seq);
     TSTAMP(10);  // row published (store issued)
   }
-  // ---- arrival: the last workgroup smooths and publishes.  Hand-off form R1 of the MI355X guide
-  // (G16): every handed-off word is stored sc1 by wave 0, that wave drains its stores
-  // (s_waitcnt vmcnt(0)) and only then one lane bumps the agent-scope counter; the last arriver
-  // runs one agent-scope acquire (last_arriver_acquire) and reads every handed-off word with sc1
-  // loads.  No buffer_wbl2 on this path. ----
+  // ---- arrival: the last workgroup smooths the device copy (tail_arrive_and_smooth) ----
   tail_arrive_and_smooth(a, K, T, (unsigned)(T + 1), is_last, dyn);  // T rows + the extra workgroup
 }
 
