@@ -160,6 +160,7 @@ struct mppi_handle {
   bool gate_bar = false;
   bool chain = true;   // mppi_debug_set_chained_ticks
   bool ahead = false;  // a gated solve is enqueued behind the pending one
+  float *ahead_vbuf = nullptr;  // where that solve leaves its applied controls
   bool timed_out = false;        // a wait ran out of time and that solve's device work may still run: recover_timed_out (abi_solve.hip)
   bool no_result = false;        // the last solve was lost (timeout): mppi_get_results refuses until a solve completes
   bool timing = false;

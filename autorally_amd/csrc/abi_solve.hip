@@ -473,14 +473,23 @@ int enqueue_solve(mppi_handle *h, const float *state)
 // with the gate in device memory written through the BAR, 44.5 with a host-mapped gate; two streams with the next rollout
 // resident beside the tail: 54 (the cross-stream events cost more than the launches they hide).
 // Results are bit for bit those of the unchained loop (tests/test_api_gpu.py).  Only for the cases that gain: one handle, a
-// latency form with riders (the row form; the automatic m44 form of 64-wide nets) and its in-kernel generator, one iteration,
-// no stage events, no capture, stride = optimization stride.
-static bool chain_ok(const mppi_handle *h, int n_ticks, int stride)
+// latency form with riders (the row form; the automatic m44 form of 64-wide nets) and its in-kernel generator, or the
+// automatic multi4-tree form with its prefetched generator kernel; one iteration, no stage events, no capture, stride =
+// optimization stride.
+// 1: a latency form with riders and its in-kernel generator (the row form, the automatic m44 form); 2: the automatic multi4-tree
+// form with the stand-alone generator kernel prefetched on a second stream; 0: not chained
+static int chain_kind(const mppi_handle *h, int n_ticks, int stride)
 {
-  return h->chain && n_ticks >= 2 && h->d_gate != nullptr && stride == h->cfg.optimization_stride && wants_slid_copy(h) &&
-         h->cfg.num_iters == 1 && !h->timing && !h->capture && h->explicit_iters == 0 && !h->prefetch_valid && !h->basis &&
-         h->fault_wave == 0 && h->have_nn && h->have_map && h->have_cost && !h->timed_out &&
-         (form_is_row(form_of(h)) || form_of(h) == Form::M44) && has_noise_wave(h);
+  if (!(h->chain && n_ticks >= 2 && h->d_gate != nullptr && stride == h->cfg.optimization_stride && wants_slid_copy(h) &&
+        h->cfg.num_iters == 1 && !h->timing && !h->capture && h->explicit_iters == 0 && !h->basis && h->fault_wave == 0 &&
+        h->have_nn && h->have_map && h->have_cost && !h->timed_out))
+    return 0;
+  const Form f = form_of(h);
+  if ((form_is_row(f) || f == Form::M44) && has_noise_wave(h) && !h->prefetch_valid) return 1;
+  // (the generator kernel beside the rollout: up to one dynamics wave per SIMD.  Beyond, the phase behind the rollout is the
+  // generator's own 41 us at K = 65 536, whatever the launches cost: chained 0.3139, unchained 0.3131 ms)
+  if (f == Form::Multi4Tree && h->forced == Form::Auto && !has_noise_wave(h) && h->gen_async && h->K / kRolloutsPerWave <= h->num_simds) return 2;
+  return 0;
 }
 
 // the gate block of solve `word`: its nominal sequence and history (the host's copies, smoothed and slid), its state in every
@@ -506,20 +515,37 @@ static void write_gate(mppi_handle *h, const float *state, unsigned word)
 // copy nobody reads: the kernel ends 2.5 us earlier, and the next rollout starts when it ends); the LAST solve of the chain
 // smooths and leaves the slid copy as every ordinary solve does, with hist from the gate block, so that the handle's device
 // state after the chain is the unchained loop's.
-static int enqueue_ahead(mppi_handle *h, const float *state, bool last_of_chain)
+static int enqueue_ahead(mppi_handle *h, const float *state, bool last_of_chain, int kind)
 {
-  float *noise = h->d_gen[h->gen_cur];  // the in-kernel generator's solves all leave their applied controls here
+  float *noise = h->d_gen[h->gen_cur];  // kind 1: the in-kernel generator's solves all leave their applied controls here
+  int rc = MPPI_OK;
+  if (kind == 2) {
+    // The generator-kernel forms: this solve's eps were prefetched on gstream (into the other buffer) when the host opened the
+    // gate of the solve before.  The NEXT prefetch is NOT enqueued ahead: it writes the buffer the pending solve's tail kernel
+    // still reads, and -- measured -- a generator launch that becomes ready together with the rollout (both behind the same
+    // tail kernel) takes the CUs first and costs its whole stand-alone time (config 4: 0.2651 -> 0.2834 ms, K = 16 384: 0.0978 ->
+    // 0.1071; behind the rollout: 0.2837 / 0.1143; lowest stream priority for the generator: 0.2781).  The host launches it
+    // when it opens this solve's gate (control_ticks_chained): a few microseconds behind the rollout's start, where it has
+    // always been, filling the dynamics waves' bubbles.
+    if (!h->prefetch_valid) return fail(h, MPPI_ERR_STATE, "chained ticks: no prefetched draws");
+    rc = acquire_noise(h, &noise);
+    if (rc) return rc;
+  }
   RolloutArgs a;
   fill_rollout_args(h, state, noise, a);
   a.U = reinterpret_cast<const float *>(h->d_gate) + kGateUOffset;
-  a.inline_noise = 1;
-  a.rng_in = h->d_rng[h->rng_cur];
-  a.rng_out = h->d_rng[1 - h->rng_cur];
-  h->rng_cur = 1 - h->rng_cur;
+  if (kind == 1) {
+    a.inline_noise = 1;
+    a.rng_in = h->d_rng[h->rng_cur];
+    a.rng_out = h->d_rng[1 - h->rng_cur];
+    h->rng_cur = 1 - h->rng_cur;
+  }
   a.gate = h->d_gate;
   a.gate_seq = h->seq + 1;
-  int rc = launch_rollout(h, a);
+  rc = launch_rollout(h, a);
   if (rc) return rc;
+  if (kind == 2) HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));
+  if (++h->tail_epoch == 0) h->tail_epoch = 1;  // the tag of this tail launch's granules (many-chunk solves)
   TailLaunch l = tail_launch(h, noise, true);
   l.seq = h->seq + 1;
   l.hist = reinterpret_cast<const float *>(h->d_gate) + gate_hist_offset(h->T);
@@ -533,6 +559,7 @@ static int enqueue_ahead(mppi_handle *h, const float *state, bool last_of_chain)
   }
   HIPCHK(h, launch_solve_tail(l, h->stream));
   h->ahead = true;
+  h->ahead_vbuf = noise;
   return MPPI_OK;
 }
 
@@ -548,7 +575,7 @@ static void cancel_ahead(mppi_handle *h, const float *state)
   h->slid_valid = false;
 }
 
-static int control_ticks_chained(mppi_handle *h, const float *state, int n_ticks, int stride)
+static int control_ticks_chained(mppi_handle *h, const float *state, int n_ticks, int stride, int kind)
 {
   HIPCHK(h, ensure_device(h->cfg.device));
   int rc = enqueue_solve(h, state);
@@ -556,7 +583,7 @@ static int control_ticks_chained(mppi_handle *h, const float *state, int n_ticks
   for (int i = 0; i < n_ticks; i++) {
     const bool ahead = i + 1 < n_ticks, ahead_is_last = i + 2 == n_ticks;
     if (ahead) {
-      rc = enqueue_ahead(h, state, ahead_is_last);
+      rc = enqueue_ahead(h, state, ahead_is_last, kind);
       if (rc) {
         (void)wait_pending(h);
         return rc;
@@ -576,10 +603,14 @@ static int control_ticks_chained(mppi_handle *h, const float *state, int n_ticks
     if (ahead) {  // the host has result i, smoothed and slid: solve i+1 may start
       h->seq++;
       write_gate(h, state, h->seq);
+      if (kind == 2) {  // the draws of the solve after it, behind the opened gate (enqueue_solve: prefetch_noise behind the tail launch)
+        rc = prefetch_noise(h);
+        if (rc) return rc;
+      }
       h->ahead = false;
       h->pending = true;
       h->pending_timed = false;
-      h->v_buf = h->d_gen[h->gen_cur];
+      h->v_buf = h->ahead_vbuf;
       if (ahead_is_last) { h->u_dirty = false; h->slid_valid = true; }  // its tail smooths h->d_in and leaves the slid copy
     }
   }
@@ -776,7 +807,8 @@ int mppi_control_ticks_batch(mppi_handle *const *hs, const float *states, int n,
 int mppi_control_ticks(mppi_handle *h, const float state[MPPI_STATE_DIM], int n_ticks, int stride)
 {
   if (!h || n_ticks < 0 || stride < 0) return MPPI_ERR_INVALID;
-  if (state && chain_ok(h, n_ticks, stride)) return control_ticks_chained(h, state, n_ticks, stride);
+  const int kind = state ? chain_kind(h, n_ticks, stride) : 0;
+  if (kind) return control_ticks_chained(h, state, n_ticks, stride, kind);
   for (int i = 0; i < n_ticks; i++) {
     int rc = mppi_compute_control(h, state);
     if (rc) return rc;

@@ -239,32 +239,6 @@ __device__ __forceinline__ void group_control_wave(const RolloutArgs &a, SH &sh,
   spin_finish(budget, lds_addr(&sh.fail[0]), lds_addr(&sh.fin[R::kCtl]));
 }
 
-// Gated launch (the chained control ticks of abi_solve.hip; SH with gstate[8] and gate_open[8]: the row and m44 forms): the pose wave waits for the host to open the gate -- word 7 of this workgroup's copy of the gate block equal to
-// a.gate_seq -- and hands the block's vehicle state to the dynamics waves through LDS.  The gate word is host-written memory
-// (device memory the host stores into through the PCIe BAR, or host-mapped memory): system-scope loads.  The wait is bounded by
-// the 100 MHz real-time counter (100 ms); a gate that stays shut, or is opened with the cancel bit, leaves the pose wave with an
-// exhausted poll budget: the group's costs are poisoned (NaN) as after any other failed hand-over, the kernel ends.
-template <class SH>
-__device__ __forceinline__ int group_gate_wait(const RolloutArgs &a, SH &sh)
-{
-  const int lane = threadIdx.x & 63;
-  const unsigned *blk = a.gate + (size_t)((int)blockIdx.x % kGateReplicas) * 16;
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  unsigned v = 0;
-  for (;;) {
-    v = __hip_atomic_load(blk + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((v & ~kGateCancel) == a.gate_seq) break;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 10000000ull) { v = kGateCancel; break; }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  // the state words were stored before the gate word (the host fences between them): loaded only now
-  asm volatile("" ::: "memory");
-  const float sv = __uint_as_float(__hip_atomic_load(blk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-  if (lane < 7) sh.gstate[lane] = sv;
-  lds_publish(lds_addr(&sh.gate_open[0]), 1);
-  return (v & kGateCancel) ? 1 : 0;
-}
-
 // ---------------------------------- pose wave ----------------------------------
 // x, y, yaw of the group's rollouts and the two costmap texels per step.  Software-pipelined by one step: the
 // texels of step t are requested in iteration t and handed to the cost wave in iteration t+1.

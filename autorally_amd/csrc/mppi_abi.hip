@@ -180,7 +180,17 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     }                                                                   \
   } while (0)
   CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CR(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+  {
+    // the generator's stream at the LOWEST priority: where a rollout kernel on the handle's stream and a generator launch
+    // become ready together (chained ticks: both wait for the same tail kernel) the rollout's workgroups are placed first and
+    // the generator fills what they leave, not the other way round (MPPI_GSTREAM_PRIO=0: default priority, for the A/B)
+    int lo = 0, hi = 0;
+    const char *e = getenv("MPPI_GSTREAM_PRIO");
+    if ((e == nullptr || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      CR(hipStreamCreateWithPriority(&h->gstream, hipStreamNonBlocking, lo));
+    else
+      CR(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+  }
   CR(hipEventCreateWithFlags(&h->ev_gen, hipEventDisableTiming));
   CR(hipEventCreate(&h->ev_gt[0]));
   CR(hipEventCreate(&h->ev_gt[1]));

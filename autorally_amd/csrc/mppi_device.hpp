@@ -350,4 +350,32 @@ __device__ __forceinline__ void spin_finish(int budget, uint32_t a_fail, uint32_
   if (budget <= 0) lds_publish(a_fail, 1);
   lds_publish(a_fin, 1);
 }
+
+// Gated launch (the chained control ticks of abi_solve.hip; SH with gstate[8] and gate_open[8]: the row, m44 and multi4-tree forms): ONE wave of the group -- the pose wave; the multi form: the control wave -- waits for the host to open the gate -- word 7 of this workgroup's copy of the gate block equal to
+// a.gate_seq -- and hands the block's vehicle state to the dynamics waves through LDS.  The gate word is host-written memory
+// (device memory the host stores into through the PCIe BAR, or host-mapped memory): system-scope loads.  The wait is bounded by
+// the 100 MHz real-time counter (100 ms); a gate that stays shut, or is opened with the cancel bit, leaves the pose wave with an
+// exhausted poll budget: the group's costs are poisoned (NaN) as after any other failed hand-over, the kernel ends.
+template <class SH>
+__device__ __forceinline__ int group_gate_wait(const RolloutArgs &a, SH &sh)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned *blk = a.gate + (size_t)((int)blockIdx.x % kGateReplicas) * 16;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned v = 0;
+  for (;;) {
+    v = __hip_atomic_load(blk + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((v & ~kGateCancel) == a.gate_seq) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 10000000ull) { v = kGateCancel; break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // the state words were stored before the gate word (the host fences between them): loaded only now
+  asm volatile("" ::: "memory");
+  const float sv = __uint_as_float(__hip_atomic_load(blk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  if (lane < 7) sh.gstate[lane] = sv;
+  lds_publish(lds_addr(&sh.gate_open[0]), 1);
+  return (v & kGateCancel) ? 1 : 0;
+}
+
+
 }  // namespace mppi

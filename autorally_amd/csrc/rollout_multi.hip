@@ -45,6 +45,8 @@ struct MultiShared {
   int fetch_pub[64];                       // steps whose texels the fetch wave has published
   int fail[4];                             // word 0: raised by a wave whose waits ran out of budget
   int fin[8];                              // word r: wave r is through its T steps
+  float gstate[8];                         // gated launch: the vehicle state the control wave took from the gate block,
+  int gate_open[8];                        // then 1 here (group_gate_wait, mppi_device.hpp)
 };
 
 __device__ __forceinline__ void lds_put1(uint32_t addr, float v)
@@ -79,7 +81,7 @@ __device__ unsigned long long g_multi_stamps[8];
 
 // TREE: the output layer as a butterfly over the four lanes of a rollout (mfma_net.hpp: nn_last_tree) instead of KSH matrix
 // instructions; a lane then carries ONE state component, s[3 + g] -- exactly the layer-0 operand it feeds
-template <int H, int NHID, int ND, class SH, bool TREE = false>
+template <int H, int NHID, int ND, class SH, bool TREE = false, bool GATED = false>
 __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, const int w)
 {
   using N = MfmaNet<H, NHID>;
@@ -112,9 +114,18 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
   const lds_int_p p_cd = (lds_int_p)&sh.cost_done[0];
   const lds_float_p p_b1 = (lds_float_p)&sh.ctl_b1[0][w][lane];
 
-  float s3 = a.state[3], s4 = a.state[4], s5 = a.state[5], s6 = a.state[6];
-  float sv = a.state[3 + g];  // TREE: this lane's component
   int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == 1 + w);
+  float s3, s4, s5, s6, sv;
+  if constexpr (GATED) {  // the state arrives through the gate block: the control wave has put it into LDS
+    const uint32_t a_go = lds_addr(&sh.gate_open[0]);
+    while (lds_peek(a_go) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+    const volatile float *gs = sh.gstate;
+    s3 = gs[3]; s4 = gs[4]; s5 = gs[5]; s6 = gs[6];
+    sv = gs[3 + g];
+  } else {
+    s3 = a.state[3]; s4 = a.state[4]; s5 = a.state[5]; s6 = a.state[6];
+    sv = a.state[3 + g];  // TREE: this lane's component
+  }
   while (__builtin_amdgcn_readfirstlane(*p_pub) < 1 && --budget > 0) __builtin_amdgcn_s_sleep(1);
   // (s_setprio 3 here -- issue priority over the cost / control wave sharing this wave's SIMD -- changes nothing:
   //  cfg 4 304.4 us without, 305.5 us with; the co-resident wave's instructions cost their issue cycles either way)
@@ -202,7 +213,9 @@ __device__ __forceinline__ void multi_dynamics(const RolloutArgs &a, SH &sh, con
 
 // SPLIT_: the pose and fetch riders of the ND = 4 form (eight waves per workgroup); ND = 2 runs one cost wave.  (Round 3's
 // six-wave ND = 4 form, "multi4u", never won a bucket of the selection table and was removed in round 5.)
-template <int H, int NHID, int ND, bool SPLIT_ = (ND == 4), bool TREE = false>
+// GATED (the automatic ND = 4 tree form only): enqueued one solve ahead (a.gate != nullptr), state and nominal sequence from the
+// gate block -- the control wave, the first to need host data, waits for the gate (group_gate_wait)
+template <int H, int NHID, int ND, bool SPLIT_ = (ND == 4), bool TREE = false, bool GATED = false>
 __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLIT_) ? 3 : 1) void rollout_multi_kernel(const RolloutArgs a)
 {
   using SH = MultiShared<ND, SPLIT_>;
@@ -235,6 +248,7 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
     sh.fetch_pub[lane] = 0;
     sh.fail[lane & 3] = 0;
     sh.fin[lane & 7] = 0;
+    sh.gate_open[lane & 7] = 0;
   }
   if (role == kCtl)
     for (int q = 0; q < kMRing; q++)
@@ -242,7 +256,7 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
   __syncthreads();
 
   if (role < ND) {
-    multi_dynamics<H, NHID, ND, SH, TREE>(a, sh, role);
+    multi_dynamics<H, NHID, ND, SH, TREE, GATED>(a, sh, role);
   } else if (role == kCtl) {
     // -------------------------------- control wave: one lane per rollout --------------------------------
     const bool inl = a.inline_noise != 0;
@@ -261,14 +275,21 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
     const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
     const uint32_t a_cd = lds_addr(&sh.cost_done[0]);
     const uint32_t a_mypub = lds_addr(&sh.ctl_pub[lane]);
-    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kCtl + 1);
+    int shut = 0;
+    if constexpr (GATED) shut = group_gate_wait(a, sh);
+    int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kCtl + 1 || shut != 0);
     int seen_d = 0, seen_c = 0;  // steps published by all dynamics waves / consumed by the cost wave
     for (int t0 = 0; t0 < T; t0 += kMCtlChunk) {
       float2 Uq[kMCtlChunk], eq[kMCtlChunk];
 #pragma unroll
       for (int q = 0; q < kMCtlChunk; q++) {
         const int tq = min(t0 + q, T - 1);
-        Uq[q] = Useq[tq];
+        if constexpr (GATED) {  // the gate block is host-written memory: system-scope loads
+          const unsigned long long ub = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(Useq + tq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          Uq[q] = make_float2(__uint_as_float((unsigned)ub), __uint_as_float((unsigned)(ub >> 32)));
+        } else {
+          Uq[q] = Useq[tq];
+        }
         eq[q] = (active && !inl) ? noise[(size_t)tq * K + k] : make_float2(0.0f, 0.0f);
       }
 #pragma unroll
@@ -316,8 +337,16 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
     const uint32_t a_dynw = lds_addr(&sh.dyn_pub[lane & (ND - 1)][0]);
     const uint32_t a_fp = lds_addr(&sh.fetch_pub[0]);
     const uint32_t a_mypub = lds_addr(&sh.pose_pub[lane]);
-    float x = a.state[0], y = a.state[1], yaw = a.state[2];
     int budget = spin_budget_init(a.spin_budget, T, a.fault_wave == kPose + 1), seen = 0, fdone = 0;
+    float x, y, yaw;
+    if constexpr (GATED) {
+      const uint32_t a_go = lds_addr(&sh.gate_open[0]);
+      while (lds_peek(a_go) == 0 && --budget > 0) __builtin_amdgcn_s_sleep(1);
+      const volatile float *gs = sh.gstate;
+      x = gs[0]; y = gs[1]; yaw = gs[2];
+    } else {
+      x = a.state[0]; y = a.state[1]; yaw = a.state[2];
+    }
     for (int t = 0; t < T; t++) {
       while (seen < t + 1 && --budget > 0) {  // rec(t) is written before a dynamics wave publishes step t
         seen = dyn_pub_min<ND>(a_dynw);
@@ -516,6 +545,11 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
 template <int H, int NHID>
 static hipError_t launch_multi_t(const RolloutArgs &a, int nd, hipStream_t stream)
 {
+  if (a.gate != nullptr) {  // gated: the automatic form only (abi_solve.hip: chain_ok)
+    if (nd != 44) return hipErrorInvalidValue;
+    MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, true, true, true>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
+    return hipGetLastError();
+  }
   if (nd == 44) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4, true, true>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);  // tree output layer
   else if (nd == 4) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 4>), dim3(a.K / 64), dim3(8 * 64), 0, stream, a);
   else if (nd == 2) MPPI_LAUNCH_ROLLOUT((rollout_multi_kernel<H, NHID, 2>), dim3(a.K / 32), dim3(4 * 64), 0, stream, a);

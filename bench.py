@@ -573,7 +573,7 @@ def main():
                 "algorithmic_GBps": bpu * K * T / rollout_s / 1e9 if rollout_s > 0 else 0.0,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
             }
-            if native and not args.no_chain and ("row8w" in variant or "m44_split" in variant):
+            if native and not args.no_chain and ("row8w" in variant or "m44_split" in variant or ("multi4_tree_gen" in variant and K // 16 <= 1024 and K * T >= 1 << 20)):
                 out["roofline"]["chained_ticks"] = (
                     "the timed steps run chained (mppi_control_ticks enqueues every solve but a block's first one tick ahead: DESIGN.md "
                     "4.10); under rocprofv3 they appear as rollout_*_gated_kernel, whose duration INCLUDES its wait for the host's gate "

@@ -374,7 +374,10 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
 
 
 @pytest.mark.parametrize("K,T,variant,opt,layers", [(4096, 100, "auto", 1, None), (1920, 100, "row_exact", 1, None), (256, 40, "auto", 2, None),
-                                                    (8192, 60, "auto", 1, None), (1920, 50, "auto", 1, [6, 64, 64, 64, 64, 4]), (512, 30, "auto", 1, [6, 64, 64, 4])])
+                                                    (8192, 60, "auto", 1, None), (1920, 50, "auto", 1, [6, 64, 64, 64, 64, 4]), (512, 30, "auto", 1, [6, 64, 64, 4]),
+                                                    # the generator-kernel form (K T >= 2^20: its draws are prefetched on a second stream, beside the rollout),
+                                                    # 32- and 64-wide nets; at 65 536 rollouts (generator behind the rollout) the ticks are not chained
+                                                    (16384, 64, "auto", 1, None), (16384, 70, "auto", 1, [6, 64, 64, 4]), (65536, 20, "auto", 1, None)])
 def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, variant, opt, layers):
     """mppi_control_ticks on one handle in the row form enqueues every solve but the first one tick AHEAD, gated on a word
     the host writes once it holds the previous result (csrc/abi_solve.hip).  Same bits as launching every solve when its
@@ -386,7 +389,7 @@ def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, varian
     for sol in sols:
         sol.set_rollout_variant(variant)
         sol.seed(77, 0)
-    assert ("row8w" if layers is None else "m44_split") in sols[0].rollout_variant()
+    assert ("multi4_tree_gen" if K >= 16384 else "row8w" if layers is None else "m44_split") in sols[0].rollout_variant()
     sols[1].debug_set_chained_ticks(0)
     n = 23
     sols[0].control_ticks(st, n, opt)   # chained
