@@ -225,6 +225,7 @@ bool wants_slid_copy(const mppi_handle *h);
 TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last);
 int fail(mppi_handle *h, int code, const char *what, hipError_t e = hipSuccess);
 int recover_timed_out(mppi_handle *h);
+bool gen_beside_rollout(const mppi_handle *h);
 int own_stream(mppi_handle *h);
 void free_all(mppi_handle *h);
 

@@ -164,6 +164,25 @@ int acquire_noise(mppi_handle *h, float **buf_out)
   return MPPI_OK;
 }
 
+// Does the generator kernel of the NEXT solve start at once, beside this solve's rollout (on the lowest-priority stream: it
+// gets what the dynamics waves leave), or behind it, beside the tail kernel?  Beside, while it does not compete with rollout
+// workgroups that still wait for a slot (profiles/r05_p_generator_beside_rollout.txt, steps in ms, behind -> beside):
+//   one dynamics wave per SIMD (K <= 16 384): round 3's measurement (config 4 0.317 -> 0.309);
+//   64-wide nets at any K: K = 24 576 / T = 150 0.5245 -> 0.5090, K = 32 768 0.3684 -> 0.3584, K = 65 536 0.7121 -> 0.7014 (their
+//     matrix-instruction chains leave the bubbles even with four rounds of workgroups);
+//   32-wide nets while every rollout workgroup is resident at once (two per CU: K <= 32 768): K = 24 576 0.1709 -> 0.1551,
+//     K = 32 768 0.1757 -> 0.1610, 6-32x4-4 K = 32 768 0.3146 -> 0.2985; at K = 65 536 (two rounds) the generator's workgroups
+//     take the slots the second round waits for: 0.3112 -> 0.3639, so there it starts when the rollout ends.
+// MPPI_GEN_BESIDE=0 / 1 (tools only) forces either.
+bool gen_beside_rollout(const mppi_handle *h)
+{
+  static const int forced = [] { const char *e = getenv("MPPI_GEN_BESIDE"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  if (forced >= 0) return forced == 1;
+  if (h->K / kRolloutsPerWave <= h->num_simds) return true;
+  if (h->hidden >= 64) return true;
+  return h->K / 64 <= 2 * (h->num_simds / 4);
+}
+
 // The next solve's draws, requested right after this solve's rollout went out: they start when that rollout
 // ends (ev_s1) and run beside the weights / tail kernels.  Their target is the buffer of the solve BEFORE this
 // one, which the host has collected.  Only for single-iteration solves of a generator-kernel form.
@@ -176,11 +195,8 @@ int prefetch_noise(mppi_handle *h)
   // against h->stream is needed as long as no solve is pending here; a reader that does not synchronise would
   // have to be ordered explicitly (an event after the tail kernel, waited for by gstream).
   if (h->pending) return fail(h, MPPI_ERR_STATE, "prefetch with a solve pending");
-  // While every SIMD runs at most one dynamics wave (K <= 16 x #SIMDs) the generator starts at once, beside the
-  // rollout: its instructions fit the dependency bubbles of the dynamics waves (config 4 0.317 -> 0.309 ms per
-  // solve, K=16384 6-32-32-4 0.122 -> 0.117).  With several workgroups per CU there are no bubbles left
-  // (K=65536: 0.380 -> 0.470 ms), so there it starts when the rollout ends, beside the weights / tail kernels.
-  if (h->K / kRolloutsPerWave > h->num_simds) HIPCHK(h, hipStreamWaitEvent(h->gstream, h->ev_s1, 0));
+  // beside the rollout or behind it: gen_beside_rollout
+  if (!gen_beside_rollout(h)) HIPCHK(h, hipStreamWaitEvent(h->gstream, h->ev_s1, 0));
   int rc = launch_generator(h, h->d_gen[1 - h->gen_cur]);
   if (rc) return rc;
   h->prefetch_valid = true;
@@ -486,9 +502,9 @@ static int chain_kind(const mppi_handle *h, int n_ticks, int stride)
     return 0;
   const Form f = form_of(h);
   if ((form_is_row(f) || f == Form::M44) && has_noise_wave(h) && !h->prefetch_valid) return 1;
-  // (the generator kernel beside the rollout: up to one dynamics wave per SIMD.  Beyond, the phase behind the rollout is the
-  // generator's own 41 us at K = 65 536, whatever the launches cost: chained 0.3139, unchained 0.3131 ms)
-  if (f == Form::Multi4Tree && h->forced == Form::Auto && !has_noise_wave(h) && h->gen_async && h->K / kRolloutsPerWave <= h->num_simds) return 2;
+  // (where the generator kernel runs beside the rollout.  Where it runs behind it -- 32-wide nets at K = 65 536 -- the phase
+  // between two rollouts is the generator's own 41 us whatever the launches cost: chained 0.3139, unchained 0.3131 ms)
+  if (f == Form::Multi4Tree && h->forced == Form::Auto && !has_noise_wave(h) && h->gen_async && gen_beside_rollout(h)) return 2;
   return 0;
 }
 

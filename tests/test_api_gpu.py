@@ -377,7 +377,8 @@ def test_a_starved_wavefront_of_any_role_fails_the_solve_loudly(golden_dir, fami
                                                     (8192, 60, "auto", 1, None), (1920, 50, "auto", 1, [6, 64, 64, 64, 64, 4]), (512, 30, "auto", 1, [6, 64, 64, 4]),
                                                     # the generator-kernel form (K T >= 2^20: its draws are prefetched on a second stream, beside the rollout),
                                                     # 32- and 64-wide nets; at 65 536 rollouts (generator behind the rollout) the ticks are not chained
-                                                    (16384, 64, "auto", 1, None), (16384, 70, "auto", 1, [6, 64, 64, 4]), (65536, 20, "auto", 1, None)])
+                                                    (16384, 64, "auto", 1, None), (16384, 70, "auto", 1, [6, 64, 64, 4]), (65536, 20, "auto", 1, None),
+                                                    (24576, 50, "auto", 1, None), (32768, 40, "auto", 1, [6, 64, 64, 4])])
 def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, variant, opt, layers):
     """mppi_control_ticks on one handle in the row form enqueues every solve but the first one tick AHEAD, gated on a word
     the host writes once it holds the previous result (csrc/abi_solve.hip).  Same bits as launching every solve when its
