@@ -418,6 +418,106 @@ def test_chained_control_ticks_equal_the_unchained_loop_bit_for_bit(K, T, varian
         sol.close()
 
 
+@pytest.mark.parametrize("block", range(3))
+def test_random_call_sequences_with_chained_ticks_equal_unchained_ones(block):
+    """Stateful: the same random sequence of ABI calls on two handles -- runs of ticks (mppi_control_ticks: chained on one handle,
+    switched off on the other), single solves (blocking / asynchronous / explicit noise), slides by several strides, sequence /
+    history / limits / cost updates, resets, kernel-form switches, rollout_only, re-seeding -- with every read-back compared
+    bit for bit.  The chain keeps state of its own on the handle (the solve ahead, which copy of U the device holds, which
+    generator buffer is whose): whatever is called around it must find the handle where the unchained loop leaves it."""
+    for sq in range(block * 6, block * 6 + 6):
+        rng = np.random.RandomState(515100 + sq)
+        K = int(rng.choice([64, 512, 1920, 4096]))
+        T = int(rng.choice([5, 16, 33, 60]))
+        layers = [None, None, [6, 64, 64, 4], [6, 32, 32, 32, 32, 4]][rng.randint(4)]
+        iters = int(rng.choice([1, 1, 1, 2]))
+        opt = min(int(rng.choice([1, 1, 2])), T - 1)
+        cfg = S.make_config(K, T, layers=layers, track=str(rng.choice(["ring", "oval"])), num_iters=iters, opt_stride=opt)
+        a, b = capi.Solver(cfg), capi.Solver(cfg)
+        b.debug_set_chained_ticks(0)
+        seed = int(rng.randint(1, 1 << 30))
+        for s_ in (a, b):
+            s_.seed(seed, 0)
+        state = cfg["start_state"].copy()
+        log = []
+
+        def same(what):
+            tag = (sq, K, T, cfg["layers"], iters, opt, " ".join(log), what)
+            np.testing.assert_array_equal(a.get_control_seq().view(np.uint32), b.get_control_seq().view(np.uint32), err_msg=str(tag))
+            np.testing.assert_array_equal(a.get_control_hist().view(np.uint32), b.get_control_hist().view(np.uint32), err_msg=str(tag))
+
+        for step in range(16):
+            op = str(rng.choice(["ticks", "ticks", "ticks", "solve", "async", "explicit", "slide", "setU", "sethist", "reset", "cost",
+                                 "limits", "variant", "rollout_only", "seed"]))
+            log.append(op)
+            if op == "ticks":
+                n, stride = int(rng.choice([1, 2, 3, 7])), int(rng.choice([opt, opt, opt, 1, 0]))
+                log[-1] = "ticks(%d,%d)" % (n, stride)
+                for s_ in (a, b):
+                    s_.control_ticks(state, n, stride)
+                same("ticks")
+            elif op in ("solve", "async", "explicit"):
+                if op == "explicit":
+                    eps = np.stack([O.generate_noise(999, 2 * T * i + 7 * step * T, K, T) for i in range(iters)])
+                for s_ in (a, b):
+                    if op == "explicit":
+                        s_.set_noise(eps)
+                    if op == "async":
+                        s_.compute_control_async(state)
+                        s_.synchronize()
+                    else:
+                        s_.compute_control(state)
+                ra, rb = a.get_results(), b.get_results()
+                for key in ("U", "costs", "w"):
+                    np.testing.assert_array_equal(ra[key].view(np.uint32), rb[key].view(np.uint32), err_msg=str((sq, " ".join(log), key)))
+                assert ra["traj_cost"] == rb["traj_cost"]
+                gs, _ = a.nominal_traj(state)
+                state = gs[min(opt, T - 1)].copy()
+            elif op == "slide":
+                st = int(rng.choice([opt, opt, 1, 2, T]))
+                for s_ in (a, b):
+                    s_.slide_control_seq(st)
+                same("slide")
+            elif op == "setU":
+                U = warm_U(cfg, seed=step + sq)
+                for s_ in (a, b):
+                    s_.set_control_seq(U)
+            elif op == "sethist":
+                hist = rng.uniform(-0.3, 0.3, 4).astype(np.float32)
+                for s_ in (a, b):
+                    s_.set_control_hist(hist)
+            elif op == "reset":
+                for s_ in (a, b):
+                    s_.reset_controls()
+            elif op == "cost":
+                cost = dict(cfg["cost"], desired_speed=float(rng.choice([4.0, 8.0, 12.0])), track_coeff=float(rng.choice([100.0, 200.0])),
+                            steering_coeff=float(rng.choice([0.0, 0.5])), l1_cost=bool(rng.rand() < 0.3))
+                cfg = dict(cfg, cost=cost)
+                for s_ in (a, b):
+                    s_.set_cost_params(cost)
+            elif op == "limits":
+                lo, hi = (-0.8, -0.5), (0.9, float(rng.choice([0.3, 0.65])))
+                for s_ in (a, b):
+                    s_.set_control_limits(lo, hi)
+            elif op == "variant":
+                v = str(rng.choice(["auto", "auto", "row", "quad", "fused", "m44", "mfma"]))
+                for s_ in (a, b):
+                    try:
+                        s_.set_rollout_variant(v)
+                    except capi.MppiError:
+                        pass
+                assert a.rollout_variant() == b.rollout_variant()
+            elif op == "rollout_only":
+                ca, cb = a.rollout_only(state), b.rollout_only(state)
+                np.testing.assert_array_equal(ca.view(np.uint32), cb.view(np.uint32), err_msg=str((sq, " ".join(log))))
+            elif op == "seed":
+                seed += 1
+                for s_ in (a, b):
+                    s_.seed(seed, 0)
+        same("end")
+        a.close(); b.close()
+
+
 def test_an_error_inside_chained_ticks_calls_the_solve_ahead_off():
     """A solve of a chain fails on the host side (here: its wait runs out of time) while the NEXT solve is already enqueued
     behind it, gated.  The gate must be opened with the cancel bit (a gated kernel left waiting would hold the queue for its
