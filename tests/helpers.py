@@ -75,6 +75,13 @@ def first_order_bound(gamma, w_norm, dJ, costs_ref, flipped, V_ref, U_ref):
         rollout although it is one (sweep seeds 201853: 1.5e-5 of 2 262 on a rollout with 1.8 % of the weight; 209729: 5e-5 of
         240 on the rollout with 38 %) -- entered with its measured |dJ_k|; callers limit how many there may be;
       * beyond 1e-4: accounted for by their weight mass (not here).
+    What bounds the gray allowance a priori (ADVICE round 4 asked): a gray rollout's |dJ_k| is at most 1e-4 |J_k| by the
+    definition of the class, and callers admit at most max(2, K / 200) of them -- so the bound cannot grow with the device's
+    error beyond 2 gamma x (their weight) x 1e-4 |J| x max|V - U|.  Requiring instead that the oracle's own two arithmetic modes
+    disagree on such a rollout (a "proven" flip) does not work: on both named draws they AGREE to 1e-6 on it
+    (test_gray_zone_flip_on_a_weight_bearing_rollout asserts that) -- the flip is libm's tanh / sincos against the device's
+    forms, which no mode of the oracle reproduces.  What would a real arithmetic regression look like?  It moves MANY costs by a
+    similar relative amount: the p99 < 5e-6 criterion of the fixed cases and the count limit here catch that.
     Returns (bound, number of gray rollouts)."""
     keep = ~flipped
     ref = np.maximum(np.abs(costs_ref.astype(np.float64)), 1.0)
