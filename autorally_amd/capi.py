@@ -64,7 +64,7 @@ SYMBOLS = [
     "mppi_rollout_variant", "mppi_set_rollout_variant", "mppi_debug_dynamics",
     "mppi_debug_inject_handover_fault", "mppi_compute_feedback_gains_pair", "mppi_set_host_threads",
     "mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout", "mppi_debug_form_candidates",
-    "mppi_debug_set_chained_ticks",
+    "mppi_debug_set_chained_ticks", "mppi_debug_min_cost",
 ]
 
 ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi_set_costmap_transform",
@@ -72,7 +72,7 @@ ABI2_SYMBOLS = ("mppi_debug_inject_handover_fault", "mppi_savitsky_golay", "mppi
                 "mppi_nominal_traj_pair")
 ABI3_SYMBOLS = ("mppi_compute_feedback_gains_pair", "mppi_set_host_threads")
 ABI4_SYMBOLS = ("mppi_debug_capture_iterations", "mppi_debug_get_iterations", "mppi_set_wait_timeout", "mppi_debug_form_candidates")
-ABI5_SYMBOLS = ("mppi_debug_set_chained_ticks",)
+ABI5_SYMBOLS = ("mppi_debug_set_chained_ticks", "mppi_debug_min_cost")
 
 _lib = None
 
@@ -160,6 +160,7 @@ def lib():
         v5 = L.mppi_abi_version() >= 5
         if v5:
             L.mppi_debug_set_chained_ticks.argtypes = [hp, C.c_int]
+            L.mppi_debug_min_cost.argtypes = [hp, C.c_int, C.POINTER(C.c_int)]
         for s in SYMBOLS:  # every declared symbol of the library's ABI version must be there
             if (v2 or s not in ABI2_SYMBOLS) and (v3 or s not in ABI3_SYMBOLS) and (v4 or s not in ABI4_SYMBOLS) and \
                     (v5 or s not in ABI5_SYMBOLS):
@@ -333,6 +334,12 @@ class Solver:
 
     def debug_set_chained_ticks(self, on):
         self._ck(self.L.mppi_debug_set_chained_ticks(self.h, int(on)))
+
+    def debug_min_cost(self, on=-1):
+        """Switch beta-from-the-rollout-kernel on / off (on < 0: leave it); returns whether the LAST solve's tail kernel used it."""
+        got = C.c_int(0)
+        self._ck(self.L.mppi_debug_min_cost(self.h, int(on), C.byref(got)))
+        return bool(got.value)
 
     def compute_control_async(self, state):
         self._ck(self.L.mppi_compute_control_async(self.h, _fp(_f32(state, (7,)))))

@@ -98,6 +98,11 @@ struct mppi_handle {
   // K > 8192 (one-launch streaming tail): d_part holds 8-byte {value, epoch} granules instead of floats; d_gx the granules of
   // the column exchanges; tail_epoch the tag of the last tail launch; tail_poll_ticks the deadline of its waits (100 MHz ticks)
   unsigned long long *d_gx = nullptr;
+  // the rollout launch's minimum cost on its way to the tail kernel (mppi_device.hpp: publish_min_cost): kMinCostLines keys, all
+  // ones when allocated; the tag of the latest rollout launch that wrote d_costs (next_min_cost_tag); MPPI_MIN_COST=0: not used
+  unsigned long long *d_min_cost = nullptr;
+  unsigned min_cost_tag = 0;
+  bool use_min_cost = true;
   unsigned long long *d_ug = nullptr;  // [T][2] granules of the raw weighted mean: row workgroups -> the smoothing workgroup
   unsigned tail_epoch = 0, tail_poll_ticks = 2000000;  // 20 ms
   float *d_res_map = nullptr;   // device-side address of the host-mapped result block h_res
@@ -214,6 +219,8 @@ inline bool form_is_row64(Form f) { return f == Form::Row64R16; }
 hipStream_t batch_stream(int device);
 void fill_cost_args(const mppi_handle *h, CostArgs &c);
 void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, RolloutArgs &a);
+// a rollout launch that is followed by its tail kernel: the tag its minimum cost travels under (a.min_cost, a.min_cost_tag)
+int tag_min_cost(mppi_handle *h, RolloutArgs &a, hipStream_t stream);
 int launch_rollout(mppi_handle *h, const RolloutArgs &a);
 int check_ready(mppi_handle *h);
 int launch_generator(mppi_handle *h, float *dst);

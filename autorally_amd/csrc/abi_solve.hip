@@ -77,10 +77,33 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   a.inline_noise = 0;
   a.gate = nullptr;
   a.gate_seq = 0;
+  a.min_cost = nullptr;  // tag_min_cost
+  a.min_cost_tag = 0;
   // roles 32-34 are waits of the streaming tail kernel (tail_launch): the rollout runs with its defaults
   a.spin_budget = h->fault_wave >= 32 ? 0 : h->spin_budget;
   a.fault_wave = h->fault_wave >= 32 ? 0 : h->fault_wave;
   fill_cost_args(h, a.cost);
+}
+
+// Where the tail stage spans a chip's worth of workgroups (the streaming tail, K > 8192) beta comes out of the rollout kernel
+// (rollout_multi.hip; every other form leaves the keys alone and the tail falls back): -0.6 us of the step at K = 16 384, -1.2 at
+// config 4.  At K <= 8192 the same was measured a LOSS (headline 0.0393 -> 0.0403 ms: the device-scope atomic at the end of the
+// cost wave costs the rollout kernel 0.6 us, and the tail's own block reduction was never on its critical path) -- not used there.
+static unsigned long long *min_cost_keys(const mppi_handle *h)
+{
+  return (h->use_min_cost && tail_is_stream(h->K)) ? h->d_min_cost : nullptr;
+}
+
+int tag_min_cost(mppi_handle *h, RolloutArgs &a, hipStream_t stream)
+{
+  h->min_cost_tag++;  // also without the keys: whatever an earlier launch left there is not this launch's
+  if (h->min_cost_tag == 0xFFFFFFFFu) {  // 4e9 launches on: ~tag has run out -- all keys back to "none", tags from 1 again
+    HIPCHK(h, hipMemsetAsync(h->d_min_cost, 0xFF, sizeof(unsigned long long) * kMinCostLines * kMinCostStride, stream));
+    h->min_cost_tag = 1;
+  }
+  a.min_cost = min_cost_keys(h);
+  a.min_cost_tag = h->min_cost_tag;
+  return MPPI_OK;
 }
 
 int launch_rollout(mppi_handle *h, const RolloutArgs &a)
@@ -379,6 +402,8 @@ TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last)
   l.epoch = h->tail_epoch;
   l.fault = h->fault_wave >= 32 ? h->fault_wave : 0;
   l.poll_ticks = (l.fault && h->spin_budget > 0) ? (unsigned)h->spin_budget * 100u : h->tail_poll_ticks;
+  l.min_cost = min_cost_keys(h);
+  l.min_cost_tag = h->min_cost_tag;
   return l;
 }
 
@@ -422,6 +447,8 @@ int enqueue_solve(mppi_handle *h, const float *state)
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], h->stream));
     RolloutArgs a;
     fill_rollout_args(h, state, noise, a);
+    rc = tag_min_cost(h, a, h->stream);
+    if (rc) return rc;
     if (inline_noise) {  // the rollout kernel's noise wavefront draws eps itself
       a.inline_noise = 1;
       a.rng_in = h->d_rng[h->rng_cur];
@@ -549,6 +576,8 @@ static int enqueue_ahead(mppi_handle *h, const float *state, bool last_of_chain,
   }
   RolloutArgs a;
   fill_rollout_args(h, state, noise, a);
+  rc = tag_min_cost(h, a, h->stream);
+  if (rc) return rc;
   a.U = reinterpret_cast<const float *>(h->d_gate) + kGateUOffset;
   if (kind == 1) {
     a.inline_noise = 1;
@@ -765,6 +794,7 @@ int mppi_compute_control_batch_async(mppi_handle *const *hs, const float *states
       h->v_buf = noise;
       RolloutArgs &a = qb.inst[i];
       fill_rollout_args(h, states + (size_t)MPPI_STATE_DIM * i, noise, a);
+      if (int trc = tag_min_cost(h, a, S)) return trc;
       if (!explicit_noise) {
         a.inline_noise = 1;
         a.rng_in = h->d_rng[h->rng_cur];

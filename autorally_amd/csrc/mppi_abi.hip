@@ -50,6 +50,7 @@ void free_all(mppi_handle *h)
   if (h->d_invt) (void)hipFree(h->d_invt);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->d_gx) (void)hipFree(h->d_gx);
+  if (h->d_min_cost) (void)hipFree(h->d_min_cost);
   if (h->d_ug) (void)hipFree(h->d_ug);
   if (h->gate_cpu) { if (h->gate_bar) (void)hipFree(h->gate_cpu); else (void)hipHostFree(h->gate_cpu); }
   uint32_t *up[] = {h->d_rng[0], h->d_rng[1], h->d_jump, h->d_sub, h->d_one};
@@ -218,6 +219,10 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
     CR(hipMalloc(&h->d_gx, sizeof(unsigned long long) * kTailExchangeGranules));
     CR(hipMemset(h->d_gx, 0, sizeof(unsigned long long) * kTailExchangeGranules));
   }
+  CR(hipMalloc(&h->d_min_cost, sizeof(unsigned long long) * kMinCostLines * kMinCostStride));
+  CR(hipMemset(h->d_min_cost, 0xFF, sizeof(unsigned long long) * kMinCostLines * kMinCostStride));  // "no launch's key"
+  if (const char *e = getenv("MPPI_MIN_COST")) h->use_min_cost = atoi(e) != 0;  // A/B: 0 = every tail kernel reduces the costs itself
+  if (const char *e = getenv("MPPI_MIN_COST_TAG")) h->min_cost_tag = (unsigned)strtoul(e, nullptr, 0);  // tests: start near the wrap
   CR(hipMalloc(&h->d_stage, sizeof(float) * KT2));
   CR(hipMalloc(&h->d_costs, sizeof(float) * h->K));
   CR(hipMalloc(&h->d_w, sizeof(float) * h->K));
@@ -682,6 +687,22 @@ int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget)
   if (!h || wave < 0 || (wave > 12 && (wave < 32 || wave > 34)) || spin_budget < 0) return MPPI_ERR_INVALID;
   h->fault_wave = wave;
   h->spin_budget = spin_budget;
+  return MPPI_OK;
+}
+
+/* Test / tooling hook: beta = min cost out of the rollout kernel (many-chunk solves; abi_solve.hip: min_cost_keys) on / off
+ * (on < 0: unchanged), and whether the LAST solve's tail kernel took it from there (*from_rollout; may be NULL). */
+int mppi_debug_min_cost(mppi_handle *h, int on, int *from_rollout)
+{
+  if (!h) return MPPI_ERR_INVALID;
+  int rc = mppi_synchronize(h);
+  if (rc) return rc;
+  if (on >= 0) h->use_min_cost = on != 0;
+  if (from_rollout) {
+    float f = 0.0f;
+    if (tail_is_stream(h->K)) HIPCHK(h, hipMemcpy(&f, h->d_scal + 3, sizeof(float), hipMemcpyDeviceToHost));
+    *from_rollout = f != 0.0f;
+  }
   return MPPI_OK;
 }
 

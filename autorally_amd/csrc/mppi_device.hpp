@@ -58,6 +58,10 @@ struct RolloutArgs {
   // (kGateReplicas copies of 64 B each, written by the host; workgroup b polls copy b % kGateReplicas).  nullptr: not gated.
   const unsigned *gate;
   unsigned gate_seq;
+  // the launch's minimum cost for the tail kernel that follows (publish_min_cost below): kMinCostLines keys, the launch's tag.
+  // nullptr: not published (the tail takes the minimum itself)
+  unsigned long long *min_cost;
+  unsigned min_cost_tag;
   CostArgs cost;
 };
 constexpr int kGateReplicas = 8;
@@ -67,6 +71,76 @@ constexpr int kGateUOffset = 16 * kGateReplicas;
 inline int gate_hist_offset(int T) { return kGateUOffset + 2 * T; }
 inline size_t gate_block_floats(int T) { return (size_t)gate_hist_offset(T) + 4; }
 constexpr unsigned kGateCancel = 0x80000000u;  // gate word = gate_seq | kGateCancel: the solve is called off (costs poisoned)
+
+// ---- beta = min_k costs[k] on its way out of the rollout kernel (round 5) ----
+// The tail stage's first step is the minimum of all K costs (mppi_controller.cu:630-634: computeNormalizer's baseline).  It is
+// exact and order-free, so the waves that write costs[] leave it behind themselves: a wave's minimum (NaN and +inf left out,
+// as fminf over the costs leaves them out) goes as ONE 64-bit atomic minimum of the key {~tag, order-preserving bits of the
+// cost} to line blockIdx.x % kMinCostLines.  A later launch's tag is larger, its ~tag smaller: keys of this launch beat whatever
+// older launches left in a line, so nothing is ever reset; the tail takes the minimum of the kMinCostLines keys and uses it when
+// its tag is this launch's -- otherwise (a form that does not publish, every cost NaN or +inf) it reduces the costs itself as
+// before.  Same bits either way.  Eight lines: same-line atomics are served one after another (~100 per us); a launch of
+// 16 384 rollouts sends 256.  Published by rollout_multi.hip's forms, for solves whose tail is the streaming kernel
+// (abi_solve.hip: min_cost_keys -- at K <= 8192 it was measured a loss).
+constexpr int kMinCostLines = 8, kMinCostStride = 16;  // keys; 128 B apart
+__device__ __forceinline__ unsigned cost_order_bits(float x)
+{
+  const unsigned b = __float_as_uint(x);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float cost_from_order_bits(unsigned o)
+{
+  return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// Wave-wide reductions that stay out of the LDS pipeline (ds_bpermute: ~100 cycles a step): two quad_perm steps, then
+// row_half_mirror and row_mirror (after the quad steps a quad's lanes are equal, so the mirrored lane holds "the other quad" /
+// "the other half"), then the two cross-row steps of gfx950: v_permlane16_swap / v_permlane32_swap on two copies of the
+// value leave the even row's (lower half's) value in the first result and the odd row's (upper half's) in the second, in
+// every lane.  Every lane ends with the same bits (each step is one commutative operation on the same two values).  All 64
+// lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float wave_dpp(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <bool MIN>
+__device__ __forceinline__ float wave_reduce(float v)
+{
+#define MPPI_RED(A, B) (MIN ? fminf((A), (B)) : (A) + (B))
+  v = MPPI_RED(v, wave_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = MPPI_RED(v, wave_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = MPPI_RED(v, wave_dpp<0x141>(v));  // row_half_mirror
+  v = MPPI_RED(v, wave_dpp<0x140>(v));  // row_mirror
+  const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = MPPI_RED(__uint_as_float(x[0]), __uint_as_float(x[1]));
+  const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = MPPI_RED(__uint_as_float(y[0]), __uint_as_float(y[1]));
+#undef MPPI_RED
+  return v;
+}
+// Called by a whole wave (all 64 lanes active): `mine` = the cost the lane stored, +inf in a lane that stored none.
+__device__ __forceinline__ void publish_min_cost(const RolloutArgs &a, const float mine)
+{
+  if (a.min_cost == nullptr) return;
+  const float m = wave_reduce<true>((mine == mine) ? mine : INFINITY);
+  if ((threadIdx.x & 63) == 0 && m < INFINITY) {
+    const unsigned long long key = ((unsigned long long)(~a.min_cost_tag) << 32) | cost_order_bits(m);
+    (void)__hip_atomic_fetch_min(a.min_cost + (blockIdx.x % kMinCostLines) * kMinCostStride, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// The tail's side: true and beta when the keys hold this launch's minimum.
+__device__ __forceinline__ bool load_min_cost(const unsigned long long *min_cost, const unsigned tag, float &beta)
+{
+  if (min_cost == nullptr) return false;
+  unsigned long long k[kMinCostLines];
+#pragma unroll
+  for (int i = 0; i < kMinCostLines; i++) k[i] = __hip_atomic_load(min_cost + i * kMinCostStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long best = k[0];
+#pragma unroll
+  for (int i = 1; i < kMinCostLines; i++) best = (k[i] < best) ? k[i] : best;
+  beta = cost_from_order_bits((unsigned)best);
+  return (unsigned)(best >> 32) == ~tag;
+}
 
 // Argument block of the batched rollout kernels: grid (groups of the largest instance, instances), workgroup (x, y) runs
 // group x of inst[y]: every kernel indexes an instance's rollouts by blockIdx.x alone.

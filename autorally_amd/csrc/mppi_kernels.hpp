@@ -107,6 +107,9 @@ struct TailLaunch {
   unsigned long long *gx = nullptr, *gpart = nullptr;
   unsigned epoch = 0, poll_ticks = 0;
   int fault = 0;
+  // the rollout launch's minimum cost (mppi_device.hpp: publish_min_cost) and that launch's tag; nullptr: the tail reduces the costs itself
+  const unsigned long long *min_cost = nullptr;
+  unsigned min_cost_tag = 0;
 };
 // does a solve of K rollouts run the one-launch streaming tail (in-launch column exchanges; wait_pending then also checks the
 // published rows for the NaN a timed-out wait leaves)?

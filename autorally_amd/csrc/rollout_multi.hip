@@ -465,6 +465,7 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
       if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
     }
     if (active) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
+    publish_min_cost(a, active ? J + 0.0f : INFINITY);
   } else {
     // -------------------------------- cost wave: one lane per rollout --------------------------------
     // Software-pipelined by one step: the costmap texels of step t are requested in iteration t and
@@ -539,6 +540,7 @@ __global__ __launch_bounds__((ND + 2 + (SPLIT_ ? 2 : 0)) * 64, (ND == 4 && !SPLI
       if (budget <= 0 || lds_peek(lds_addr(&sh.fail[0])) != 0) J = __builtin_nanf("");
     }
     if (active) a.costs[k] = J + 0.0f;  // + terminalCost (= 0), costs.cu:411-414
+    publish_min_cost(a, active ? J + 0.0f : INFINITY);
   }
 }
 

@@ -62,31 +62,7 @@ __device__ unsigned long long g_tail_stamps[16];
 constexpr int kTailThreads = MPPI_TAIL_THREADS;
 constexpr int kRedChunk = 4096;  // rollouts staged per pass: 32 KiB of LDS (+ pad)
 
-// Wave-wide reductions that stay out of the LDS pipeline (ds_bpermute: ~100 cycles a step): two quad_perm steps, then
-// row_half_mirror and row_mirror (after the quad steps a quad's lanes are equal, so the mirrored lane holds "the other quad" /
-// "the other half"), then the two cross-row steps of gfx950: v_permlane16_swap / v_permlane32_swap on two copies of the
-// value leave the even row's (lower half's) value in the first result and the odd row's (upper half's) in the second, in
-// every lane.  Every lane ends with the same bits (each step is one commutative operation on the same two values).
-template <int CTRL>
-__device__ __forceinline__ float tail_dpp(float v)
-{
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <bool MIN>
-__device__ __forceinline__ float wave_reduce(float v)
-{
-#define MPPI_RED(A, B) (MIN ? fminf((A), (B)) : (A) + (B))
-  v = MPPI_RED(v, tail_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = MPPI_RED(v, tail_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = MPPI_RED(v, tail_dpp<0x141>(v));  // row_half_mirror
-  v = MPPI_RED(v, tail_dpp<0x140>(v));  // row_mirror
-  const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = MPPI_RED(__uint_as_float(x[0]), __uint_as_float(x[1]));
-  const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = MPPI_RED(__uint_as_float(y[0]), __uint_as_float(y[1]));
-#undef MPPI_RED
-  return v;
-}
+// wave_reduce: mppi_device.hpp
 __device__ __forceinline__ float wave_min(float v) { return wave_reduce<true>(v); }
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce<false>(v); }
 // Workgroup-wide (kTailThreads): ONE barrier -- every wave leaves its result in red4[wave], every thread combines the four
@@ -148,7 +124,8 @@ struct TailArgs {
   float *U;             // [T][2] in/out: receives Unew, smoothed in place on the last iteration
   const float *hist;    // [4]
   float *w;             // [K] exp weights (for mppi_get_results)
-  float *scal;          // [3] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup)
+  float *scal;          // [4] device scratch: beta, eta, trajectory cost (workgroup 0 -> last workgroup); streaming tail: [3] = 1 when
+                        // beta came out of the rollout kernel
   float *res;           // host-mapped result block, T+2 entries of 16 B: rows [u0, seq, u1, seq], then
                         // [beta, seq, eta, seq] and [trajectory cost, seq, 0, seq]
   int no_device_copy;   // inside chained ticks: the rows and scalars are published, nothing else -- no arrival, no smoothing of the
@@ -165,6 +142,8 @@ struct TailArgs {
   float init0, init1;
   int last_iter;        // smooth + publish results
   unsigned seq;         // sequence number published in res[3] once everything else is visible
+  const unsigned long long *min_cost;  // solve_tail_stream_kernel: beta as the rollout kernel left it (mppi_device.hpp: load_min_cost), or nullptr
+  unsigned min_cost_tag;
 };
 
 // The end of every tail kernel: the workgroups that closed a row (and, K <= 8192, the extra one) meet at the arrival counter;
@@ -480,16 +459,22 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
 //
 // Grid: C weights workgroups (one per chunk of kRedChunk rollouts; they stream no row, so their polls do not queue behind
 // their own loads), then the row workgroups (t, c) -- row t, chunk c -- dealt so that all chunks of a row run on ONE XCD.
-//  * Weights workgroup c: beta = the minimum of ALL costs where one load batch covers them (K <= 16 384), else the chunk minima
-//    exchanged among the C weights workgroups (exact, order-free); {beta} into its share of kBcastReplicas replica lines;
+//  * beta = min_k costs[k] comes out of the ROLLOUT kernel: its cost waves leave it behind as a tagged atomic minimum
+//    (mppi_device.hpp: publish_min_cost) and every workgroup here reads the eight keys with its first loads -- no hand-over
+//    for beta inside this launch (-0.6 us of the step at K = 16 384, -1.2 us at config 4; profiles/r05_s_*).  Where the keys are
+//    not this launch's (a rollout form that does not publish, no finite cost, mppi_debug_min_cost off) the first version's way
+//    runs: weights workgroup c takes the minimum of ALL costs where one load batch covers them (K <= 16 384), else the chunk
+//    minima are exchanged among the C weights workgroups (exact, order-free), and {beta} goes out in kBcastReplicas replica
+//    lines, of which a row workgroup polls ONE.
+//  * Weights workgroup c:
 //    w_k = expf(-gamma (J_k - beta)) of its chunk; the chunk sums exchanged, eta = their sum in chunk order (a fixed order: the
 //    same bits in every workgroup and every run; the reference's host loop is sequential over k, :641-652 -- the pairwise /
 //    chunked order differs from it by ~1e-7 relative, as the tree of the old weights pass did); {eta} into the replicas; w[]
 //    and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares in chunk order and
 //    publishes beta, eta and the trajectory cost.
-//  * Row workgroup (t, c) requests its chunk of the costs and its piece of V[t] at once, polls ONE replica line for beta
-//    (its block index picks the line: ~grid / kBcastReplicas pollers each), evaluates the exps of its chunk while the weights
-//    workgroups exchange their sums, polls eta, and keeps the chunk's weights w_k / eta (:244: a division per rollout, then
+//  * Row workgroup (t, c) requests the keys, its chunk of the costs and its piece of V[t] at once, evaluates the exps of its
+//    chunk while the weights workgroups exchange their sums, polls ONE replica line for eta (its block index picks the line:
+//    ~grid / kBcastReplicas pollers each), and keeps the chunk's weights w_k / eta (:244: a division per rollout, then
 //    the fma) to itself.  The (m, j) chains of 64 rollouts and the in-order sum of their results (:246, :256-260) are the
 //    reference's, untouched: the chain results of chunks 0 .. C-2 travel as granules, and the workgroup of the row's LAST chunk
 //    -- started right behind the others -- polls them, adds all K/64 results in order and publishes the row.  The T
@@ -614,6 +599,8 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
   constexpr int kCostV = kRedChunk / 4 / kTailThreads;
   constexpr int kAllV = 8;  // float4 per thread that cover all costs of K <= 16 384
   const bool full_min = K <= kAllV * 4 * kTailThreads;
+  float beta_pub;
+  const bool have_beta = load_min_cost(a.min_cost, a.min_cost_tag, beta_pub);  // the same answer in every workgroup of the launch
   float4 cv[kCostV];
   {
     const float4 *c4 = reinterpret_cast<const float4 *>(costs_p + base);
@@ -623,9 +610,12 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
       cv[i] = (q < n / 4) ? c4[q] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     }
   }
-  // ---- beta: the minimum of ALL costs where one load batch covers them (no exchange), else the chunk minima exchanged ----
+  // ---- beta: as the rollout kernel left it (the row workgroups read it there themselves: no hand-over); else the minimum of
+  // ALL costs where one load batch covers them (no exchange), else the chunk minima exchanged ----
   float m = INFINITY, beta;
-  if (full_min) {
+  if (have_beta) {
+    beta = beta_pub;
+  } else if (full_min) {
     float4 call[kAllV];
     const float4 *c4 = reinterpret_cast<const float4 *>(costs_p);
 #pragma unroll
@@ -650,9 +640,7 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
   }
   // {beta} goes out in this workgroup's share of the replica lines at once: the row workgroups evaluate their exps while the
   // chunk sums are exchanged
-#ifndef MPPI_STREAM_LATE_BETA
-  if (tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) store_granule(bcast + (size_t)tid * 16, epoch, beta);
-#endif
+  if (!have_beta && tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) store_granule(bcast + (size_t)tid * 16, epoch, beta);
   // ---- w_k, eta ----
   float part = 0.0f;
 #pragma unroll
@@ -672,12 +660,7 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
   __syncthreads();
   float eta = xsum[0];
   for (int i = 1; i < C; i++) eta += xsum[i];  // chunk order
-  if (tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) {
-#ifdef MPPI_STREAM_LATE_BETA
-    store_granule(bcast + (size_t)tid * 16, epoch, beta);
-#endif
-    store_granule(bcast + (size_t)tid * 16 + 1, epoch, eta);
-  }
+  if (tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) store_granule(bcast + (size_t)tid * 16 + 1, epoch, eta);
   // ---- w[] and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares in chunk order ----
   float tc = 0.0f;
 #pragma unroll
@@ -699,6 +682,7 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
     float traj = xtc[0];
     for (int i = 1; i < C; i++) traj += xtc[i];  // chunk order
     a.scal[0] = beta; a.scal[1] = eta; a.scal[2] = traj;
+    a.scal[3] = have_beta ? 1.0f : 0.0f;  // mppi_debug_min_cost
     if (a.last_iter) {
       publish_entry(a.res, T, beta, eta, a.seq);
       publish_entry(a.res, T + 1, traj, 0.0f, a.seq);
@@ -742,8 +726,10 @@ __global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(cons
   SSTAMP(0);
   const unsigned long long *const bcast = sa.gx + 3 * kMaxChunks + (size_t)(block % kBcastReplicas) * 16;  // {beta, epoch}, {eta, epoch}
 
-  // the chunk of the costs, then the piece of row t: requested together, before anything else; a wave's loads return in issue
-  // order -- the costs, which the weights wait for, first
+  // beta as the rollout kernel left it (no hand-over inside this launch), the chunk of the costs, then the piece of row t:
+  // requested together, before anything else; a wave's loads return in issue order -- what the weights wait for first
+  float beta_pub;
+  const bool have_beta = load_min_cost(a.min_cost, a.min_cost_tag, beta_pub);  // the same answer in every workgroup of the launch
   constexpr int kCostV = kRedChunk / 4 / kTailThreads;
   float4 cv[kCostV];
   {
@@ -766,11 +752,15 @@ __global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(cons
     }
   }
   SSTAMP(1);  // loads requested
-  // ---- beta from the replica line this block's index picks (~grid / kBcastReplicas pollers per line), the chunk's exps, eta ----
+  // ---- beta (where the rollout form left none: from the replica line this block's index picks, ~grid / kBcastReplicas pollers
+  // per line), the chunk's exps, eta ----
   SSTAMP(2);
-  poll_replica(bcast, epoch, t0, sa.poll_ticks, &bc[0]);
-  __syncthreads();
-  const float beta = bc[0];
+  float beta = beta_pub;
+  if (!have_beta) {
+    poll_replica(bcast, epoch, t0, sa.poll_ticks, &bc[0]);
+    __syncthreads();
+    beta = bc[0];
+  }
   SSTAMP(3);
 #pragma unroll
   for (int i = 0; i < kCostV; i++) {
@@ -1046,7 +1036,7 @@ static TailArgs fill_tail(const TailLaunch &l)
   TailArgs a;
   a.slid = l.slid; a.slide_stride = l.slide_stride; a.init0 = l.init0; a.init1 = l.init1;
   a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res; a.ug = l.ug;
-  a.no_device_copy = l.no_device_copy; a.hist_out = l.hist_out;
+  a.no_device_copy = l.no_device_copy; a.hist_out = l.hist_out; a.min_cost = l.min_cost; a.min_cost_tag = l.min_cost_tag;
   a.counter = l.counter; a.part = l.part;
   a.K = l.K; a.T = l.T; a.gamma = l.gamma; a.last_iter = l.last_iter; a.seq = l.seq;
   return a;

@@ -37,7 +37,7 @@ extern "C" {
 /* 5: solves of more than 8192 rollouts run a one-launch tail (in-launch hand-overs with a deadline: fault roles 32-34 of
  *    mppi_debug_inject_handover_fault); after a wait timeout the lost solve is not waited for again (mppi_set_wait_timeout);
  *    "mfma" / "valu" / "valu_lds" drop a form forced by name; variants "multi1", "multi4u[_gen]", "row64_r8" removed;
- *    + mppi_debug_set_chained_ticks (mppi_control_ticks enqueues one solve ahead). */
+ *    + mppi_debug_set_chained_ticks (mppi_control_ticks enqueues one solve ahead), + mppi_debug_min_cost. */
 #define MPPI_ABI_VERSION 5
 #define MPPI_STATE_DIM 7   /* [x, y, yaw, roll, u_x, u_y, yaw_mder]  NeuralNetModel<7,2,3,...> */
 #define MPPI_CONTROL_DIM 2 /* [steering, throttle] */
@@ -321,6 +321,14 @@ int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max
  * chained control ticks; the launch call and the dispatch leave the step's critical path); on = 0 launches every solve when
  * its turn comes.  The results are bit for bit the same. */
 int mppi_debug_set_chained_ticks(mppi_handle *h, int on);
+
+/* Test / tooling hook.  In solves of more than 8192 rollouts the rollout kernel leaves beta = min_k costs[k]
+ * (mppi_controller.cu:630-634, computeNormalizer's baseline: exact, order-free) behind as a tagged atomic minimum and the tail
+ * kernel reads it instead of reducing the costs and handing the result round (csrc/mppi_device.hpp: publish_min_cost); a rollout
+ * form that does not publish, or costs without one finite value, make the tail kernel reduce them itself.  Same bits either way.
+ * on = 0 / 1 switches the publication off / on (default on; on < 0 leaves it); *from_rollout (may be NULL) receives whether the
+ * LAST solve's tail kernel took beta from the rollout kernel (0 for solves of <= 8192 rollouts, which never do). */
+int mppi_debug_min_cost(mppi_handle *h, int on, int *from_rollout);
 
 /* How long a blocking call (mppi_compute_control, mppi_synchronize, mppi_get_results ...) polls for a solve's result block
  * before it gives up with MPPI_ERR_HIP; default 30 s.  (The reference blocks in cudaStreamSynchronize without a limit,
