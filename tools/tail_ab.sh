@@ -1,6 +1,10 @@
 #!/bin/bash
-# tools/tail_ab.sh: the tail stage of many-chunk solves (K > 8192), old two-launch form (MPPI_TAIL_FORM=old: weights_kernel +
-# solve_tail_kernel<PRE>) against the one-launch streaming form, same box, alternating, bench.py's own stage events and step time.
+# tools/tail_ab.sh: the tail stage of many-chunk solves (K > 8192), builds against each other on one box, alternating, bench.py's own
+# stage events and step time.  A form is a variant build tools/variants/<form>.so (tools/build_variant.sh, or a copy of an older
+# libmppi_hip.so); a name without such a file runs the product build.  HISTORY: profiles/r05_a_tail_stream_probe.txt was made with
+# FORMS="old new", "old" being the round-4 two-launch tail (weights_kernel + solve_tail_kernel<PRE>) that the library then still
+# carried behind MPPI_TAIL_FORM=old; that switch was removed with the old kernels at the end of round 5 -- to
+# repeat that A/B, build the library of commit aa93161 as tools/variants/old.so.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/tail_ab
 row() {  # tag, form, then bench.py arguments
@@ -16,7 +20,7 @@ print("%-12s %-4s %-36s %8.2f M/s  step %.4f ms (min %.4f) | rollout %.4f noise 
 PY
 }
 for rep in 1 2; do
-for form in ${FORMS:-old new}; do
+for form in ${FORMS:-new}; do
 row k16384 $form --K 16384
 row k65536 $form --K 65536 --steps 100
 row cfg4 $form --K 16384 --T 150 --layers 6-64-64-4 --steps 100 --warmup 10
