@@ -114,7 +114,7 @@ struct TailLaunch {
 // does a solve of K rollouts run the one-launch streaming tail (in-launch column exchanges; wait_pending then also checks the
 // published rows for the NaN a timed-out wait leaves)?
 bool tail_is_stream(int K);
-constexpr int kTailExchangeGranules = 3 * 64 + 32 * 16;  // solve_kernels.hip: 3 x kMaxChunks + kBcastReplicas lines
+constexpr int kTailExchangeGranules = 3 * 64 + 32 * 16 + 32 * 64;  // solve_kernels.hip: 3 x kMaxChunks + kBcastReplicas lines + kBcastReplicas x kMaxChunks
 hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream);
 // the tails of n <= kMaxBatch instances (K <= 4096 each) in one launch
 hipError_t launch_solve_tail_batch(const TailLaunch *l, int n, hipStream_t stream);

@@ -466,15 +466,17 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
 //    runs: weights workgroup c takes the minimum of ALL costs where one load batch covers them (K <= 16 384), else the chunk
 //    minima are exchanged among the C weights workgroups (exact, order-free), and {beta} goes out in kBcastReplicas replica
 //    lines, of which a row workgroup polls ONE.
-//  * Weights workgroup c:
-//    w_k = expf(-gamma (J_k - beta)) of its chunk; the chunk sums exchanged, eta = their sum in chunk order (a fixed order: the
-//    same bits in every workgroup and every run; the reference's host loop is sequential over k, :641-652 -- the pairwise /
-//    chunked order differs from it by ~1e-7 relative, as the tree of the old weights pass did); {eta} into the replicas; w[]
-//    and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares in chunk order and
-//    publishes beta, eta and the trajectory cost.
+//  * Weights workgroup c: w_k = expf(-gamma (J_k - beta)) of its chunk; the chunk's sum goes into column c of EVERY one of the
+//    kBcastReplicas sum replicas (32 stores of one wave), and a workgroup -- weights and row workgroups alike -- collects the C
+//    columns of ONE replica and adds them in chunk order: eta is ONE hand-over away from the chunk sums (the first version
+//    exchanged the sums among the weights workgroups and sent {eta} out in replica lines: two; -0.5 us of the step at K <= 16 384,
+//    profiles/r05_x_*), and the fixed order makes it the same bits in every workgroup and every run (the reference's host loop
+//    is sequential over k, :641-652 -- the pairwise / chunked order differs from it by ~1e-7 relative, as the tree of the old
+//    weights pass did); w[] and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares
+//    in chunk order and publishes beta, eta and the trajectory cost.
 //  * Row workgroup (t, c) requests the keys, its chunk of the costs and its piece of V[t] at once, evaluates the exps of its
-//    chunk while the weights workgroups exchange their sums, polls ONE replica line for eta (its block index picks the line:
-//    ~grid / kBcastReplicas pollers each), and keeps the chunk's weights w_k / eta (:244: a division per rollout, then
+//    chunk while the weights workgroups reduce theirs, collects the C chunk sums of ONE sum replica (its block index picks it:
+//    ~grid / kBcastReplicas pollers each) for eta, and keeps the chunk's weights w_k / eta (:244: a division per rollout, then
 //    the fma) to itself.  The (m, j) chains of 64 rollouts and the in-order sum of their results (:246, :256-260) are the
 //    reference's, untouched: the chain results of chunks 0 .. C-2 travel as granules, and the workgroup of the row's LAST chunk
 //    -- started right behind the others -- polls them, adds all K/64 results in order and publishes the row.  The T
@@ -511,17 +513,19 @@ __device__ unsigned long long g_stream_stamps[2][16];  // [0]: the row-closing w
 #endif
 constexpr int kMaxChunks = 64;  // one wave polls a column exchange: K <= 64 * kRedChunk = 262 144
 constexpr int kBcastReplicas = 32;  // lines (128 B each) that carry {beta, eta} to the workgroups of rows 1 .. T-1
-static_assert(kTailExchangeGranules == 3 * kMaxChunks + kBcastReplicas * 16, "mppi_kernels.hpp");
+constexpr int kGxSumReplicas = 3 * kMaxChunks + kBcastReplicas * 16;  // [kBcastReplicas][kMaxChunks]: every chunk's sum in every replica
+static_assert(kTailExchangeGranules == kGxSumReplicas + kBcastReplicas * kMaxChunks, "mppi_kernels.hpp");
 static_assert(2 * kBcastReplicas <= kTailThreads, "one lane per replica granule");
 struct StreamTailArgs {
   TailArgs a;                // a.part is unused; a.counter[0] is the arrival counter of the T row-closing workgroups
-  unsigned long long *gx;    // [3][kMaxChunks] exchange granules: chunk minima, chunk sums, chunk shares of the trajectory cost;
-                             // then [kBcastReplicas][16]: {beta, eta} for the rows that do not take part in the exchanges
+  unsigned long long *gx;    // [3][kMaxChunks] exchange granules: chunk minima (no published beta), unused, chunk shares of the trajectory
+                             // cost; then [kBcastReplicas][16]: {beta} lines (no published beta); then [kBcastReplicas][kMaxChunks]: the
+                             // chunk sums, every chunk's in every replica
   unsigned long long *gpart; // [T][K/64][2] chain-result granules
   unsigned epoch;            // tag of this launch's granules (never 0, differs from every earlier launch on these buffers)
   unsigned poll_ticks;       // deadline of every wait, in ticks of s_memrealtime (100 MHz)
-  int fault;                 // tests only: 32 = leader 0 never publishes its chunk sum, 33 = chunk 0 of every row never publishes
-                             // its chain results, 34 = no leader publishes {beta, eta}
+  int fault;                 // tests only: 32 = weights workgroup 0 never publishes its chunk sum, 33 = chunk 0 of every row never
+                             // publishes its chain results, 34 = no weights workgroup publishes its chunk sum (nor {beta})
 };
 
 
@@ -583,8 +587,8 @@ __device__ __forceinline__ int img_v(int g, int j, int e) { return g * 64 + ((((
 __device__ __forceinline__ int img_w(int g, int e) { return g * 64 + ((((e >> 2) ^ (g & 7)) & 15) << 2) + (e & 3); }
 
 // The weights workgroups of solve_tail_stream_kernel (blocks 0 .. C-1 of the grid, one per chunk; they stream no row, so
-// their polls do not queue behind 48 KB of their own loads): beta, the chunk's exps, eta, {beta, eta} into the replica
-// lines, w[] and the trajectory cost.
+// their polls do not queue behind 48 KB of their own loads): beta, the chunk's exps, the chunk's sum into the sum replicas, eta,
+// w[] and the trajectory cost.
 __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, const float *costs_p, const int K, const int T, const int c,
                                                     float *redm, float *reds, float *redt, float *xmin, float *xsum, float *xtc)
 {
@@ -656,11 +660,14 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
     }
   }
   const float csum = block_reduce<false>(part, reds);
-  column_exchange(sa.gx + kMaxChunks, C, c, csum, epoch, !(sa.fault == 32 && c == 0), t0, sa.poll_ticks, xsum);
+  // the chunk's sum into column c of EVERY replica (32 stores of one wave); a workgroup -- this one too -- collects the C
+  // columns of ONE replica and adds them in chunk order: eta is one hand-over away from the chunk sums
+  if (tid < kBcastReplicas && !(sa.fault == 32 && c == 0) && sa.fault != 34)
+    store_granule(sa.gx + kGxSumReplicas + (size_t)tid * kMaxChunks + c, epoch, csum);
+  column_exchange(sa.gx + kGxSumReplicas + (size_t)(c % kBcastReplicas) * kMaxChunks, C, -1, 0.0f, epoch, false, t0, sa.poll_ticks, xsum);
   __syncthreads();
   float eta = xsum[0];
   for (int i = 1; i < C; i++) eta += xsum[i];  // chunk order
-  if (tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) store_granule(bcast + (size_t)tid * 16 + 1, epoch, eta);
   // ---- w[] and the chunk's share of the trajectory cost sum w^2/eta (:651, Q8); workgroup 0 adds the shares in chunk order ----
   float tc = 0.0f;
 #pragma unroll
@@ -774,9 +781,10 @@ __global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(cons
     }
   }
   SSTAMP(4);
-  poll_replica(bcast + 1, epoch, t0, sa.poll_ticks, &bc[1]);
+  column_exchange(sa.gx + kGxSumReplicas + (size_t)(block % kBcastReplicas) * kMaxChunks, C, -1, 0.0f, epoch, false, t0, sa.poll_ticks, xsum);
   __syncthreads();
-  const float eta = bc[1];
+  float eta = xsum[0];
+  for (int i = 1; i < C; i++) eta += xsum[i];  // chunk order: the bits of the weights workgroups' eta
   SSTAMP(5);
   // ---- weight = w/normalizer (:244), the piece of the row: into LDS ----
 #pragma unroll

@@ -294,9 +294,9 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
  * Roles of the row form and of the oct form: 1 .. 4 = dynamics waves, 5 = pose, 6 = cost, 7 = control, 8 = noise wave.
  * Roles of the multi form: 1 .. ND = dynamics waves, then the cost wave and the control wave (ND = 4: the pose
  * wave, the cost wave, the control wave).
- * Roles 32 .. 34: waits of the one-launch tail kernel of solves with more than 8192 rollouts -- the leader of column 0
- * never publishes its chunk sum of weights (32), chunk 0 of every row never publishes its chain results (33), no leader
- * publishes {beta, eta} to the other rows (34) -- with a deadline of spin_budget microseconds for every wait (0: the default, 20 ms). */
+ * Roles 32 .. 34: waits of the one-launch tail kernel of solves with more than 8192 rollouts -- the weights workgroup of
+ * chunk 0 never publishes its chunk sum of weights (32), chunk 0 of every row never publishes its chain results (33), no
+ * weights workgroup publishes its chunk sum, nor beta where the tail kernel takes the minimum itself (34) -- with a deadline of spin_budget microseconds for every wait (0: the default, 20 ms). */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
 
 /* Test hooks (not part of the drop-in surface): what EVERY iteration of a solve with num_iters > 1 left behind.  The
