@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""tools/nominal_margin.py <model: nn32 | wd> <draws> [first seed]  |  merge <raw json ...>: what re-association costs at the contract's 1e-4 mark.
+"""tools/nominal_margin.py <model: nn32 | wd | nn32_big> <draws> [first seed]  |  merge <raw json ...>: what re-association costs at the contract's 1e-4 mark.
 
 Whole solves at the LAUNCH DEFAULTS only (path_integral_nn.launch: gamma 0.15, nu (0.275, 0.3), the cost coefficients, T = 100,
 num_iters 1, opt_stride 1) with the shipped weights -- nn32 = autorally_nnet_09_12_2018 (6-32-32-4), wd =
 wider_deeper_network_08_20_2020 (6-64-64-64-64-4, negate_yaw_der = false) -- K alternating between 1920 (the reference's
-build) and 4096 (BASELINE configs[2]), on the oval track map, from random poses ON the track (a point of the centre line, a
+build) and 4096 (BASELINE configs[2]) -- nn32_big: the 6-32-32-4 weights at K = 12 288 / 16 384, where "auto" is the multi4-tree form --, on the oval track map, from random poses ON the track (a point of the centre line, a
 lateral offset, a heading error, a speed of 3-8 m/s) with the WARM sequence a controller standing there holds (the result of
 a first solve at that pose, slid by one step).  Every kernel form that serves the shape solves the SAME draw (device
 generator, same seed): the forms that keep the reference's summation order and the re-associated ("tree" / "split") ones, each
@@ -77,18 +77,25 @@ if sys.argv[1] == "merge":
 model = sys.argv[1]
 n_draws = int(sys.argv[2])
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 500000
-assert model in ("nn32", "wd")
+assert model in ("nn32", "wd", "nn32_big")
 gd = os.path.join(ROOT, "tests", "golden", "models")
+KS = (1920, 4096)
 if model == "nn32":
     layers, theta = P.load_model_npz(os.path.join(gd, "autorally_nnet_09_12_2018.npz"))
     over = {}
     FORMS = ["row_exact", "row_tree"]  # "auto" = row_tree
+elif model == "nn32_big":
+    # the third automatic re-associated form: beyond 8192 rollouts "auto" is multi4_tree (+ generator kernel, one-launch streaming
+    # tail); "multi4_gen" keeps the reference's order in the network.  The shipped 6-32-32-4 weights at K = 12 288 / 16 384.
+    layers, theta = P.load_model_npz(os.path.join(gd, "autorally_nnet_09_12_2018.npz"))
+    over = {}
+    FORMS = ["multi4_gen", "multi4_tree_gen"]  # "auto" = multi4_tree_gen
+    KS = (12288, 16384)
 else:
     layers, theta = P.load_model_npz(os.path.join(gd, "wider_deeper_network_08_20_2020.npz"))
     over = {"negate_yaw_der": False}   # params/models/README.md:20
     FORMS = ["oct", "m44_chain", "m44"]  # "auto" = m44 (two chains per hidden layer)
 T = 100
-KS = (1920, 4096)
 STRAIGHT, RADIUS = 12.0, 10.0  # synthetic.oval_track_map
 
 
