@@ -95,7 +95,7 @@ struct mppi_handle {
   hipStream_t batch_s = nullptr;  // the device's batch stream, looked up once (mppi_compute_control_batch)
   unsigned *d_counter = nullptr;  // [1 + T] arrival counters of the tail kernel
   float *d_part = nullptr;        // [T][K/64][2] chain results of the tail kernel when K > 4096
-  // K > 8192 (one-launch streaming tail): d_part holds 8-byte {value, epoch} granules instead of floats; d_gx the granules of
+  // K > 4096 (one-launch streaming tail): d_part holds 8-byte {value, epoch} granules; d_gx the granules of
   // the column exchanges; tail_epoch the tag of the last tail launch; tail_poll_ticks the deadline of its waits (100 MHz ticks)
   unsigned long long *d_gx = nullptr;
   // the rollout launch's minimum cost on its way to the tail kernel (mppi_device.hpp: publish_min_cost): kMinCostLines keys, all

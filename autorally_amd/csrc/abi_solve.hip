@@ -85,13 +85,15 @@ void fill_rollout_args(const mppi_handle *h, const float *state, float *noise, R
   fill_cost_args(h, a.cost);
 }
 
-// Where the tail stage spans a chip's worth of workgroups (the streaming tail, K > 8192) beta comes out of the rollout kernel
-// (rollout_multi.hip; every other form leaves the keys alone and the tail falls back): -0.6 us of the step at K = 16 384, -1.2 at
-// config 4.  At K <= 8192 the same was measured a LOSS (headline 0.0393 -> 0.0403 ms: the device-scope atomic at the end of the
+// Where the tail stage is the streaming kernel (K > 4096) AND the rollout form is one of rollout_multi.hip's (the automatic ones
+// beyond 8192 rollouts) beta comes out of the rollout kernel: -0.8 us of the step at K = 16 384, -1.7 at config 4.  With the row /
+// m44 forms (every K <= 8192 by default) the same was measured a LOSS (headline 0.0393 -> 0.0403 ms: the device-scope atomic at the end of the
 // cost wave costs the rollout kernel 0.6 us, and the tail's own block reduction was never on its critical path) -- not used there.
 static unsigned long long *min_cost_keys(const mppi_handle *h)
 {
-  return (h->use_min_cost && tail_is_stream(h->K)) ? h->d_min_cost : nullptr;
+  const Form f = form_of(h);
+  const bool publishes = f == Form::Multi2 || f == Form::Multi4 || f == Form::Multi4Tree;  // rollout_multi.hip
+  return (h->use_min_cost && tail_is_stream(h->K) && publishes) ? h->d_min_cost : nullptr;
 }
 
 int tag_min_cost(mppi_handle *h, RolloutArgs &a, hipStream_t stream)
@@ -390,12 +392,12 @@ TailLaunch tail_launch(const mppi_handle *h, const float *V, bool last)
 {
   TailLaunch l;
   l.costs = h->d_costs; l.V = V; l.U = h->d_in; l.hist = h->d_in + 2 * h->T; l.w = h->d_w; l.scal = h->d_scal;
-  l.res = h->d_res_map; l.counter = h->d_counter; l.part = h->d_part;
+  l.res = h->d_res_map; l.counter = h->d_counter;
   l.K = h->K; l.T = h->T; l.gamma = h->cfg.gamma; l.last_iter = last ? 1 : 0; l.seq = h->seq;
   l.slid = (last && wants_slid_copy(h)) ? h->d_in_buf[1 - h->in_cur] : nullptr;
   l.slide_stride = h->cfg.optimization_stride;
   l.init0 = h->cfg.init_control[0]; l.init1 = h->cfg.init_control[1];
-  // the one-launch streaming tail (K > 8192): granule buffers, this launch's tag (the caller advanced it), wait deadline; the
+  // the one-launch streaming tail (K > 4096): granule buffers, this launch's tag (the caller advanced it), wait deadline; the
   // tests' fault roles 32-34 shorten the deadline to spin_budget x 1 us
   l.ug = h->d_ug;
   l.gx = h->d_gx; l.gpart = reinterpret_cast<unsigned long long *>(h->d_part);

@@ -211,7 +211,7 @@ int mppi_create(const mppi_config *cfg, mppi_handle **out)
   CR(hipMalloc(&h->d_counter, sizeof(unsigned) * (1 + (size_t)h->T)));
   CR(hipMemset(h->d_counter, 0, sizeof(unsigned) * (1 + (size_t)h->T)));
   if (h->K > 4096) {
-    // chain results of a row spread over several workgroups: floats (K <= 8192, counter hand-off), 8-byte granules beyond
+    // chain results of a row spread over several workgroups: 8-byte {value, tag} granules
     // (solve_tail_stream_kernel); zeroed once -- a granule counts only with the tag of the launch that reads it
     const size_t part_bytes = sizeof(unsigned long long) * (size_t)h->T * (h->K / 64) * 2;
     CR(hipMalloc(&h->d_part, part_bytes));

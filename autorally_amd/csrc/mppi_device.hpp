@@ -81,7 +81,7 @@ constexpr unsigned kGateCancel = 0x80000000u;  // gate word = gate_seq | kGateCa
 // its tag is this launch's -- otherwise (a form that does not publish, every cost NaN or +inf) it reduces the costs itself as
 // before.  Same bits either way.  Eight lines: same-line atomics are served one after another (~100 per us); a launch of
 // 16 384 rollouts sends 256.  Published by rollout_multi.hip's forms, for solves whose tail is the streaming kernel
-// (abi_solve.hip: min_cost_keys -- at K <= 8192 it was measured a loss).
+// (abi_solve.hip: min_cost_keys -- with the row / m44 forms of K <= 8192 it was measured a loss).
 constexpr int kMinCostLines = 8, kMinCostStride = 16;  // keys; 128 B apart
 __device__ __forceinline__ unsigned cost_order_bits(float x)
 {

@@ -90,15 +90,15 @@ hipError_t launch_dynamics_bf(const float *W, const float *states, const float *
                               hipStream_t stream);
 
 // solve_kernels.hip
-// everything of one solve iteration after the rollout (solve_tail_kernel / _wide_kernel up to 8192 rollouts, solve_tail_stream_kernel beyond)
+// everything of one solve iteration after the rollout (solve_tail_kernel up to 4096 rollouts, solve_tail_stream_kernel beyond)
 struct TailLaunch {
   const float *costs, *V, *hist;
-  float *U, *w, *scal, *res, *part, *slid;
+  float *U, *w, *scal, *res, *slid;
   unsigned *counter;
   int K, T, last_iter, slide_stride;
   unsigned seq;
   float gamma, init0, init1;
-  // K > 8192 (solve_tail_stream_kernel): granule buffers (gx: 3 x 64 exchange granules; gpart: [T][K/64][2] chain results,
+  // K > 4096 (solve_tail_stream_kernel): granule buffers (gx: 3 x 64 exchange granules; gpart: [T][K/64][2] chain results,
   // 8 B each, zero when allocated), the tag of this launch's granules (never 0, never the tag of an earlier launch on these
   // buffers), the deadline of every in-launch wait in 100 MHz ticks, and the tests' fault role (0: none)
   unsigned long long *ug = nullptr;  // [T][2] granules of the raw weighted mean (every form)

@@ -20,13 +20,11 @@ namespace mppi {
 //       here, so U is bit-identical to the reference order given the same weights.
 //   U = SavitzkyGolay([hist | Unew | pad])   (last iteration only), mppi_controller.cu:468-499
 //
-// K <= 8192 (solve_tail_kernel, solve_tail_wide_kernel; beyond: solve_tail_stream_kernel below):
-// Grid = T*C workgroups (one per timestep and chunk of kRedChunk rollouts; C = 1 up to K = 4096, 2 up to
-// 8192) + one that publishes the weights and scalars.  Every workgroup recomputes beta and eta from the K
-// costs (16 KB at K=4096, L2 resident; same code in every workgroup => the same bits), stages its
-// piece of row V[t][*][*] (contiguous bytes of the time-major buffer) through LDS with 16-B loads and
-// runs the (m, j) chains.  With C = 2 the chain results go to a global scratch and the workgroup that
-// arrives last at the row's counter adds them in order.  On the last iteration every row workgroup writes
+// K <= 4096 (solve_tail_kernel; beyond: solve_tail_stream_kernel below):
+// Grid = T workgroups (one per timestep) + one that publishes the weights and scalars.  Every workgroup recomputes beta and
+// eta from the K costs (16 KB at K=4096, L2 resident; same code in every workgroup => the same bits), stages its row
+// V[t][*][*] (contiguous bytes of the time-major buffer) through LDS with 16-B loads and runs the (m, j) chains.  On the last
+// iteration every row workgroup writes
 // its raw weighted mean straight into host-mapped memory (16-B entries carrying the solve's sequence
 // number; the extra workgroup does the same for beta, eta and the trajectory cost): the host needs no D2H
 // copy and no stream synchronise, it polls the T+2 entries and applies the 5-tap smoothing itself.
@@ -43,7 +41,7 @@ namespace mppi {
 __device__ unsigned long long g_tail_stamps[16];
 #define TSTAMP(i)                                                                                   \
   do {                                                                                              \
-    if (block == (T / 2) * ((K + kRedChunk - 1) / kRedChunk) && threadIdx.x == 0) {                 \
+    if (block == T / 2 && threadIdx.x == 0) {                                                       \
       unsigned long long t__;                                                                       \
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
       g_tail_stamps[i] = t__;                                                                       \
@@ -78,21 +76,6 @@ __device__ __forceinline__ float block_reduce(float v, float *red4)
 #pragma unroll
   for (int i = 1; i < kTailThreads / 64; i++) r = MIN ? fminf(r, red4[i]) : r + red4[i];
   return r;
-}
-
-// Consumer side of the ONE counter hand-over left (the two chunks of a row in solve_tail_wide_kernel, 4096 < K <= 8192; every
-// other hand-over is a {value, tag} granule since round 5): the workgroup whose counter add came last runs ONE agent-scope
-// acquire (buffer_inv sc1: this CU's L1) and waits for it before any of its waves loads what the other workgroup stored.  The
-// producers store every handed-off word sc1 (write-through), every storing wave drains its stores (s_waitcnt vmcnt(0)) and the
-// workgroup passes a barrier before one lane adds to the counter; the loads are sc1 as well.  The guide measures the
-// acquire-free variant only for one workgroup per CU; several of these workgroups share a CU, so the acquire stays here.
-__device__ __forceinline__ void last_arriver_acquire()
-{
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
 }
 
 // One result entry (16 B) straight into host-mapped memory: [v0, seq, v1, seq], one uncached
@@ -133,8 +116,7 @@ struct TailArgs {
   float *hist_out;      // optional: the smoothing workgroup copies hist[4] here (the last solve of a chain read it from the gate block)
   unsigned long long *ug;  // [T][2] the raw weighted mean of the last iteration as {value, seq} granules: from the row workgroups to the
                         // workgroup that arrives last and smooths the device copy
-  unsigned *counter;    // [1 + T] arrival counters (all rows, then per row), zero on entry, reset by the last arriver
-  float *part;          // [T][K/64][2] chain results when a row is spread over several workgroups (K > kRedChunk)
+  unsigned *counter;    // [0]: the arrival counter of the row-closing workgroups (+ the extra one), zero on entry, reset by the last arriver
   int K, T;
   float gamma;
   float *slid;          // optional [2T + 4]: receives [U | hist] slid by slide_stride (or nullptr)
@@ -146,7 +128,7 @@ struct TailArgs {
   unsigned min_cost_tag;
 };
 
-// The end of every tail kernel: the workgroups that closed a row (and, K <= 8192, the extra one) meet at the arrival counter;
+// The end of every tail kernel: the workgroups that closed a row (and, K <= 4096, the extra one) meet at the arrival counter;
 // the last one smooths the DEVICE copy of the sequence and leaves its stride-slid copy.  The raw rows reach it as {value, seq}
 // granules (G16, form R2); the counter only says WHO smooths (each workgroup drains its granule stores, s_waitcnt vmcnt(0),
 // before one lane bumps it).  Inside chained control ticks (a.no_device_copy) nothing of this runs: the kernel ends with the
@@ -240,19 +222,15 @@ __device__ __forceinline__ void tail_arrive_and_smooth(const TailArgs &a, const 
 
 // body of solve_tail_kernel for workgroup `block` of the instance `a` (the batched kernel passes blockIdx.x minus
 // the instance's first workgroup)
-// CV: float4 of the cost vector a thread holds (every workgroup computes beta and eta itself): 4 covers K <= 4096 (one chunk per
-// row: the latency path, untouched since round 2), 8 covers K <= 8192 ("wide": rows of two chunks, every workgroup still
-// recomputes beta and eta from all K costs -- 32 KB of L2 reads and 32 exps per thread; round 4: K = 8192 19.3 -> 15 us behind
-// the rollout kernel against a one-workgroup weights pass in front).  With 16 float4 it would reach K = 16384, measured in round
-// 4: T=100 23.8 -> 21.3 us, but T=150 30.0 -> 32.2 us -- beyond 8192 the weights come from the weights workgroups of
-// solve_tail_stream_kernel.
-constexpr int kWideK = 8192;
+// One chunk per row (K <= kRedChunk = 4096 rollouts: the latency path): every workgroup computes beta and eta from all K costs itself
+// (same code, same bits).  Rows of more chunks are solve_tail_stream_kernel's (until the end of round 5 a "wide" two-chunk form of
+// this body served 4096 < K <= 8192, its two workgroups per row meeting at an arrival counter: K = 8192 0.0651 -> 0.0640 ms per step
+// with the streaming kernel in its place, profiles/r05_aa_*).
 // `V`, `costs`, `K`, `T`: the values of a.V, a.costs, a.K, a.T as the kernel received them -- in the single-instance kernels
 // leading scalar parameters.  (Preloading them into scalar registers, -amdgpu-kernarg-preload-count, was measured: the
 // workgroup's first loads go out 0.1 us earlier and the step is unchanged; the same for the row rollout kernel -- its first
 // controls 0.28 us earlier, the STEP 0.3 us longer: the command processor reads the segment before it launches the first
 // wave.  profiles/r04_v_kernarg_preload.txt.  Not used.)
-template <int CV>
 __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int block, const float *V, const float *costs_p, const int K,
                                                 const int T)
 {
@@ -268,11 +246,10 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // partial[2][K/64], then X[(T+4)*2] for the smoothing
   float *partial = dyn;
   const int tid = threadIdx.x;
-  const int C = (K + kRedChunk - 1) / kRedChunk;  // workgroups per row
-  const bool extra = (block == T * C);  // (single-launch form) publishes w[], beta, eta, trajectory cost
-  const int t = extra ? 0 : block / C;
-  const int base = extra ? 0 : (block % C) * kRedChunk;
-  const int n = min(kRedChunk, K - base);  // rollouts of this workgroup's chunk (multiple of 64)
+  const bool extra = (block == T);  // publishes w[], beta, eta, trajectory cost
+  const int t = extra ? 0 : block;
+  constexpr int base = 0;
+  const int n = K;  // rollouts of the row (multiple of 64, at most kRedChunk)
   TSTAMP(0);  // first instructions
 
   // The chunk of row t is requested NOW, before anything else, so that its HBM latency overlaps the
@@ -295,7 +272,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
   {
     // The K <= kRedChunk costs, 16 per thread, are requested with four 16-B loads that are in flight
     // together (and together with the row above): one memory round trip for the min and the exp pass.
-    constexpr int kCostV = CV;
+    constexpr int kCostV = kRedChunk / 4 / kTailThreads;
     const float4 *c4 = reinterpret_cast<const float4 *>(costs_p);
     const int K4 = K / 4;
     float4 cv[kCostV];
@@ -394,27 +371,9 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
         acc = fmaf(wv.z, pv.z, acc);
         acc = fmaf(wv.w, pv.w, acc);
       }
-      if (C == 1) partial[j * G + ml] = acc;
-      else __hip_atomic_store(&a.part[((size_t)t * G + base / 64 + ml) * 2 + j], acc, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT);
+      partial[j * G + ml] = acc;
     }
     TSTAMP(8);  // chains
-    if (C > 1) {
-      // the row is spread over C workgroups: the last to arrive at the row's counter collects all
-      // chain results (same hand-off form as below: write-through stores, drained, then the counter)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(a.counter + 1 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (ticket == (unsigned)(C - 1)) ? 1 : 0;
-        if (is_last) __hip_atomic_store(a.counter + 1 + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-      }
-      __syncthreads();
-      if (!is_last) return;
-      last_arriver_acquire();
-      for (int i = tid; i < G * 2; i += kTailThreads)
-        partial[(i & 1) * G + (i >> 1)] = __hip_atomic_load(&a.part[(size_t)t * G * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
   }
   float u = 0.0f;
@@ -450,7 +409,7 @@ __device__ __forceinline__ void solve_tail_body(const TailArgs &a, const int blo
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve_tail_stream_kernel (K > kWideK, round 5): the whole tail stage of a many-chunk solve in ONE launch.
+// solve_tail_stream_kernel (K > kRedChunk, round 5): the whole tail stage of a many-chunk solve in ONE launch.
 //
 // Before (round 4: weights_kernel + solve_tail_kernel<PRE>): beta, the exps, eta and the trajectory cost of all K rollouts in
 // ONE 1 024-thread workgroup (8.7 us at K = 16 384, 23.6 us at 65 536), a kernel boundary, then T*C row workgroups whose
@@ -512,12 +471,13 @@ __device__ unsigned long long g_stream_stamps[2][16];  // [0]: the row-closing w
 #define MPPI_STREAM_SLEEP 1
 #endif
 constexpr int kMaxChunks = 64;  // one wave polls a column exchange: K <= 64 * kRedChunk = 262 144
-constexpr int kBcastReplicas = 32;  // lines (128 B each) that carry {beta, eta} to the workgroups of rows 1 .. T-1
+constexpr int kBcastReplicas = 32;  // copies of what the weights workgroups hand to everybody: {beta} lines (128 B; only where the rollout
+                                    // kernel left no beta) and the sum replicas (kMaxChunks granules each)
 constexpr int kGxSumReplicas = 3 * kMaxChunks + kBcastReplicas * 16;  // [kBcastReplicas][kMaxChunks]: every chunk's sum in every replica
 static_assert(kTailExchangeGranules == kGxSumReplicas + kBcastReplicas * kMaxChunks, "mppi_kernels.hpp");
 static_assert(2 * kBcastReplicas <= kTailThreads, "one lane per replica granule");
 struct StreamTailArgs {
-  TailArgs a;                // a.part is unused; a.counter[0] is the arrival counter of the T row-closing workgroups
+  TailArgs a;                // a.counter[0] is the arrival counter of the T row-closing workgroups
   unsigned long long *gx;    // [3][kMaxChunks] exchange granules: chunk minima (no published beta), unused, chunk shares of the trajectory
                              // cost; then [kBcastReplicas][16]: {beta} lines (no published beta); then [kBcastReplicas][kMaxChunks]: the
                              // chunk sums, every chunk's in every replica
@@ -642,8 +602,8 @@ __device__ __forceinline__ void stream_weights_body(const StreamTailArgs &sa, co
       beta = (x != x) ? x : fminf(beta, x);  // a wait that ran out of time left NaN: keep it
     }
   }
-  // {beta} goes out in this workgroup's share of the replica lines at once: the row workgroups evaluate their exps while the
-  // chunk sums are exchanged
+  // (no published beta) {beta} goes out in this workgroup's share of the replica lines at once: the row workgroups evaluate their
+  // exps while the chunk sums are reduced
   if (!have_beta && tid < kBcastReplicas && (tid % C) == c && sa.fault != 34) store_granule(bcast + (size_t)tid * 16, epoch, beta);
   // ---- w_k, eta ----
   float part = 0.0f;
@@ -731,7 +691,7 @@ __global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(cons
   const unsigned epoch = sa.epoch;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   SSTAMP(0);
-  const unsigned long long *const bcast = sa.gx + 3 * kMaxChunks + (size_t)(block % kBcastReplicas) * 16;  // {beta, epoch}, {eta, epoch}
+  const unsigned long long *const bcast = sa.gx + 3 * kMaxChunks + (size_t)(block % kBcastReplicas) * 16;  // {beta, epoch}
 
   // beta as the rollout kernel left it (no hand-over inside this launch), the chunk of the costs, then the piece of row t:
   // requested together, before anything else; a wave's loads return in issue order -- what the weights wait for first
@@ -905,12 +865,7 @@ __global__ __launch_bounds__(kTailThreads, 6) void solve_tail_stream_kernel(cons
 __global__ __launch_bounds__(kTailThreads) void solve_tail_kernel(const float *V, const float *costs, const int K, const int T,
                                                                   const TailArgs a)
 {
-  solve_tail_body<kRedChunk / 4 / kTailThreads>(a, (int)blockIdx.x, V, costs, K, T);
-}
-__global__ __launch_bounds__(kTailThreads) void solve_tail_wide_kernel(const float *V, const float *costs, const int K, const int T,
-                                                                       const TailArgs a)  // kRedChunk < K <= kWideK
-{
-  solve_tail_body<kWideK / 4 / kTailThreads>(a, (int)blockIdx.x, V, costs, K, T);
+  solve_tail_body(a, (int)blockIdx.x, V, costs, K, T);
 }
 
 // The tails of several instances (K <= kRedChunk each: T + 1 workgroups per instance) in one launch, behind
@@ -927,7 +882,7 @@ __global__ __launch_bounds__(kTailThreads) void solve_tail_batch_kernel(const Ta
 #define MPPI_TAIL_BODY(A)                                                   \
   do {                                                                      \
     if ((int)blockIdx.x > (A).T) return;                                    \
-    solve_tail_body<kRedChunk / 4 / kTailThreads>((A), (int)blockIdx.x, (A).V, (A).costs, (A).K, (A).T);    \
+    solve_tail_body((A), (int)blockIdx.x, (A).V, (A).costs, (A).K, (A).T);    \
   } while (0)
   MPPI_BATCH_DISPATCH(NB, b, MPPI_TAIL_BODY);
 #undef MPPI_TAIL_BODY
@@ -1045,19 +1000,18 @@ static TailArgs fill_tail(const TailLaunch &l)
   a.slid = l.slid; a.slide_stride = l.slide_stride; a.init0 = l.init0; a.init1 = l.init1;
   a.costs = l.costs; a.V = l.V; a.U = l.U; a.hist = l.hist; a.w = l.w; a.scal = l.scal; a.res = l.res; a.ug = l.ug;
   a.no_device_copy = l.no_device_copy; a.hist_out = l.hist_out; a.min_cost = l.min_cost; a.min_cost_tag = l.min_cost_tag;
-  a.counter = l.counter; a.part = l.part;
+  a.counter = l.counter;
   a.K = l.K; a.T = l.T; a.gamma = l.gamma; a.last_iter = l.last_iter; a.seq = l.seq;
   return a;
 }
 
-bool tail_is_stream(int K) { return K > kWideK; }
+bool tail_is_stream(int K) { return K > kRedChunk; }
 
 hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
 {
   const TailArgs a = fill_tail(l);
   const int K = l.K, T = l.T;
   const int C = (K + kRedChunk - 1) / kRedChunk;
-  if (C > 1 && l.part == nullptr) return hipErrorInvalidValue;
   if (tail_is_stream(K)) {
     if (C > kMaxChunks || !l.gx || !l.gpart || l.epoch == 0 || l.poll_ticks == 0) return hipErrorInvalidValue;
     StreamTailArgs sa;
@@ -1070,10 +1024,7 @@ hipError_t launch_solve_tail(const TailLaunch &l, hipStream_t stream)
     hipLaunchKernelGGL(solve_tail_stream_kernel, dim3(grid), dim3(kTailThreads), 0, stream, a.V, a.costs, K, T, sa);
     return hipGetLastError();
   }
-  if (K > kRedChunk)
-    hipLaunchKernelGGL(solve_tail_wide_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
-  else
-    hipLaunchKernelGGL(solve_tail_kernel, dim3(T * C + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
+  hipLaunchKernelGGL(solve_tail_kernel, dim3(T + 1), dim3(kTailThreads), tail_dyn_bytes(K, T), stream, a.V, a.costs, K, T, a);
   return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ extern "C" {
 /* 3: + mppi_set_host_threads, mppi_compute_feedback_gains_pair. */
 /* 4: + mppi_debug_capture_iterations, mppi_debug_get_iterations, mppi_set_wait_timeout, mppi_debug_form_candidates; variants
  *    "row_tree", "row_exact", "row64[_r8|_r16]", "m44"; names "valu_row8w_tree_*", "valu_row64_r*_tree_*", "mfma4x4x1_*_m44_split_tree" (automatic), "mfma4x4x1_*_m44_tree" ("m44_chain"). */
-/* 5: solves of more than 8192 rollouts run a one-launch tail (in-launch hand-overs with a deadline: fault roles 32-34 of
+/* 5: solves of more than 4096 rollouts run a one-launch tail (in-launch hand-overs with a deadline: fault roles 32-34 of
  *    mppi_debug_inject_handover_fault); after a wait timeout the lost solve is not waited for again (mppi_set_wait_timeout);
  *    "mfma" / "valu" / "valu_lds" drop a form forced by name; variants "multi1", "multi4u[_gen]", "row64_r8" removed;
  *    + mppi_debug_set_chained_ticks (mppi_control_ticks enqueues one solve ahead), + mppi_debug_min_cost. */
@@ -294,7 +294,7 @@ int mppi_debug_dynamics(mppi_handle *h, int n, const float *states, const float 
  * Roles of the row form and of the oct form: 1 .. 4 = dynamics waves, 5 = pose, 6 = cost, 7 = control, 8 = noise wave.
  * Roles of the multi form: 1 .. ND = dynamics waves, then the cost wave and the control wave (ND = 4: the pose
  * wave, the cost wave, the control wave).
- * Roles 32 .. 34: waits of the one-launch tail kernel of solves with more than 8192 rollouts -- the weights workgroup of
+ * Roles 32 .. 34: waits of the one-launch tail kernel of solves with more than 4096 rollouts -- the weights workgroup of
  * chunk 0 never publishes its chunk sum of weights (32), chunk 0 of every row never publishes its chain results (33), no
  * weights workgroup publishes its chunk sum, nor beta where the tail kernel takes the minimum itself (34) -- with a deadline of spin_budget microseconds for every wait (0: the default, 20 ms). */
 int mppi_debug_inject_handover_fault(mppi_handle *h, int wave, int spin_budget);
@@ -322,12 +322,14 @@ int mppi_debug_form_candidates(const mppi_handle *h, const char **names, int max
  * its turn comes.  The results are bit for bit the same. */
 int mppi_debug_set_chained_ticks(mppi_handle *h, int on);
 
-/* Test / tooling hook.  In solves of more than 8192 rollouts the rollout kernel leaves beta = min_k costs[k]
+/* Test / tooling hook.  In solves of more than 8192 rollouts (the rollout forms of csrc/rollout_multi.hip with the one-launch
+ * tail kernel of K > 4096) the rollout kernel leaves beta = min_k costs[k]
  * (mppi_controller.cu:630-634, computeNormalizer's baseline: exact, order-free) behind as a tagged atomic minimum and the tail
  * kernel reads it instead of reducing the costs and handing the result round (csrc/mppi_device.hpp: publish_min_cost); a rollout
  * form that does not publish, or costs without one finite value, make the tail kernel reduce them itself.  Same bits either way.
  * on = 0 / 1 switches the publication off / on (default on; on < 0 leaves it); *from_rollout (may be NULL) receives whether the
- * LAST solve's tail kernel took beta from the rollout kernel (0 for solves of <= 8192 rollouts, which never do). */
+ * LAST solve's tail kernel took beta from the rollout kernel (0 where the rollout form does not publish: by default every solve
+ * of <= 8192 rollouts). */
 int mppi_debug_min_cost(mppi_handle *h, int on, int *from_rollout);
 
 /* How long a blocking call (mppi_compute_control, mppi_synchronize, mppi_get_results ...) polls for a solve's result block

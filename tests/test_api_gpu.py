@@ -601,14 +601,15 @@ def test_wait_timeout_is_kept_and_the_lost_solve_is_not_waited_for_again():
     sol.close()
 
 
-@pytest.mark.parametrize("K", [12288 + 64, 20480 + 64])  # the leaders take beta from all costs / exchange chunk minima
+@pytest.mark.parametrize("K", [6400, 12288 + 64, 20480 + 64])  # two chunks on the row form (beta taken in the tail: from all costs), four with
+# beta out of the rollout kernel, six (without it the weights workgroups would exchange chunk minima)
 @pytest.mark.parametrize("role", [32, 33, 34])
 def test_stream_tail_wait_that_runs_out_of_time_is_an_error(role, K):
-    """K > 8192: the tail stage is ONE launch whose workgroups exchange chunk minima, chunk sums and chain results as
-    {value, epoch} granules (solve_kernels.hip: solve_tail_stream_kernel).  A workgroup that never publishes -- column 0's
-    sum of weights (32), chunk 0's chain results (33), the leaders' {beta, eta} for the other rows (34) -- must end the solve in MPPI_ERR_HIP within the
+    """K > 4096: the tail stage is ONE launch whose workgroups hand chunk sums and chain results (and, where the rollout kernel
+    left no beta, chunk minima and beta) over as {value, epoch} granules (solve_kernels.hip: solve_tail_stream_kernel).  A
+    workgroup that never publishes -- chunk 0's sum of weights (32), chunk 0's chain results (33), every chunk sum (34) -- must end the solve in MPPI_ERR_HIP within the
     deadline, never in a hang and never in finite controls; the handle keeps working afterwards, bit for bit."""
-    cfg = S.make_config(K, 30, track="oval")  # four / six chunks, the last one ragged
+    cfg = S.make_config(K, 30, track="oval")  # two / four / six chunks, the last one ragged
     sol = capi.Solver(cfg)
     sol.compute_control(cfg["start_state"])
     good = sol.get_results()

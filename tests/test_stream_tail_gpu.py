@@ -1,6 +1,6 @@
-"""The one-launch tail of many-chunk solves (K > 8192; csrc/solve_kernels.hip: solve_tail_stream_kernel) on its own: weights
+"""The one-launch tail of many-chunk solves (K > 4096; csrc/solve_kernels.hip: solve_tail_stream_kernel) on its own: weights
 workgroups + row workgroups that hand chunk minima / sums, {beta, eta} and chain results over as {value, tag} granules.  The
-randomised whole-solve tests draw K <= 6400 and never reach it; here random many-chunk shapes -- ragged last chunks, 3 to 20
+randomised whole-solve tests draw K <= 6400 and reach it with two chunks only; here many-chunk shapes -- ragged last chunks, 2 to 20
 chunks per row, the leaders' both ways to beta (all costs in one batch up to 16 384 rollouts, exchanged chunk minima beyond),
 short and long horizons -- are held to
   * the oracle's weighting + weighted reduction + smoothing fed with the GPU's OWN costs and applied controls (no threshold chaos
@@ -21,7 +21,7 @@ from tests.helpers import noise_for, rel_err, warm_U, solve_with_iterations, tea
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(8256, 7), (12288, 33), (12352, 100), (16384, 2), (16448, 41), (20480, 60), (24640, 19), (32768, 25), (40960, 12), (81984, 9)]
+SHAPES = [(4160, 9), (6400, 50), (8192, 100), (8256, 7), (12288, 33), (12352, 100), (16384, 2), (16448, 41), (20480, 60), (24640, 19), (32768, 25), (40960, 12), (81984, 9)]
 
 
 @pytest.mark.parametrize("K,T", SHAPES)
