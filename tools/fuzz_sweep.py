@@ -16,9 +16,11 @@ Third argument "row" / "row_tree": only the draws the vector-ALU row form serves
 that form ("row_tree": against the NOMINAL oracle, i.e. the north-star tolerance for the re-associated output layer);
 "multi4_tree[_gen]": the draws of the shapes the multi form has, forced onto its butterfly-output form, against the nominal oracle;
 "m44": only the 64-wide draws (6-64-64-4, 6-64-64-64-64-4, K <= 4096) on the 4x4x1-MFMA form, likewise against the nominal oracle.
-Prints one line per draw that needed a classification and a summary; exit code 1 if any draw is BAD."""
+Prints one line per draw that needed a classification and a summary; exit code 1 if any draw is BAD.  FUZZ_SECONDS=<s> in the
+environment stops the sweep after that time (the summary names the last seed done)."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -38,7 +40,12 @@ WANT = {"m44": ([6, 64, 64, 4], [6, 64, 64, 64, 64, 4]),
 KMAX = 1 << 30 if (only_row or "").startswith("multi4") else 4096  # the latency forms serve up to 4096 (8192) rollouts
 n_draws = n_iter = bad = conditioned = granular = illcond = 0
 worst_clean, worst_any, forms = 0.0, 0.0, {}
+t_stop = time.time() + float(os.environ.get("FUZZ_SECONDS", "1e9"))  # optional time budget: stop early, summary over the seeds done
+last = lo - 1
 for seed in range(lo, hi):
+    if time.time() > t_stop:
+        break
+    last = seed
     if seed % 500 == 0:
         print("# at seed %d: %d draws, %d BAD" % (seed, n_draws, bad), file=sys.stderr, flush=True)
     if only_row:  # the first three draws of F._draw decide whether the row form serves this seed: skip the rest cheaply
@@ -105,6 +112,6 @@ for seed in range(lo, hi):
 print("seeds %d..%d: %d draws, %d iterations, each compared with the oracle on identical inputs: %d BAD; %d conditioned (first-order bound "
       "of their own cost differences, capped at 3e-6 relative), %d granularity (<= 4 flipped rollouts are > 3 %% of K), %d ill-conditioned "
       "(the oracle's two modes differ by more); worst |dU| of a clean iteration without flipped weight %.3e, of any iteration %.3e" % (
-          lo, hi - 1, n_draws, n_iter, bad, conditioned, granular, illcond, worst_clean, worst_any))
+          lo, last, n_draws, n_iter, bad, conditioned, granular, illcond, worst_clean, worst_any))
 print("kernel forms drawn:", ", ".join("%s x%d" % kv for kv in sorted(forms.items())))
 sys.exit(1 if bad else 0)
