@@ -24,6 +24,7 @@ from autorally_amd import capi, params as P, synthetic as S  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t_end = time.time() + budget
+t_note = time.time() + 60.0
 nets = {32: None, 64: dict(zip(("layers", "theta"), P.synthetic_model([6, 64, 64, 4], seed=4)))}
 draws = bad = ticks_total = 0
 base = {}
@@ -76,6 +77,9 @@ while time.time() < t_end:
     draws += 1
     ticks_total += 3 * n
     seed += 1
+    if time.time() > t_note:  # a line a minute: a silent run is taken for a hung one on the GPU pool
+        print("# %d draws, %d mismatches" % (draws, bad), file=sys.stderr, flush=True)
+        t_note = time.time() + 60.0
 print(json.dumps({"draws": draws, "first_seed": seed0, "solves": ticks_total, "mismatches": bad, "forms": forms,
                   "chunks_per_row": {str(k): v for k, v in sorted(chunks.items())}}))
 sys.exit(1 if bad else 0)
