@@ -518,14 +518,15 @@ def test_random_call_sequences_with_chained_ticks_equal_unchained_ones(block):
         a.close(); b.close()
 
 
-def test_an_error_inside_chained_ticks_calls_the_solve_ahead_off():
+@pytest.mark.parametrize("K,T", [(8192, 100), (16384, 60)])  # the row form with its own noise wave / the generator-kernel form
+def test_an_error_inside_chained_ticks_calls_the_solve_ahead_off(K, T):
     """A solve of a chain fails on the host side (here: its wait runs out of time) while the NEXT solve is already enqueued
     behind it, gated.  The gate must be opened with the cancel bit (a gated kernel left waiting would hold the queue for its
     100 ms deadline and then poison a solve nobody asked for), the call returns the error, and the handle -- whose device
     copies are stale by then -- works again from the host's copies: the next results are those of a fresh handle fed the same
     control sequence."""
     import time
-    cfg = S.make_config(8192, 100, track="oval")
+    cfg = S.make_config(K, T, track="oval")
     st = cfg["start_state"]
     sol = capi.Solver(cfg)
     sol.seed(5, 0)
